@@ -1,0 +1,216 @@
+/*
+ * zigz_hip.h -- C ABI of libzigz_hip.so: the MI355X (gfx950) backend for zigz's data-parallel
+ * hot path (BabyBear MLE bind/eval, sumcheck rounds, SHA3 Merkle commit/open, Lasso fingerprints).
+ *
+ * This is the drop-in boundary.  The reference (Zig, single-threaded, no FFI of its own) keeps its
+ * host code; each entry point below replaces the body of ONE reference function, cited per
+ * declaration as reference file:line.  A Zig `extern "c"` shim that binds these symbols is shown
+ * in INTEGRATION.md.
+ *
+ * Conventions (mirroring the reference):
+ *  - Field elements cross the boundary as canonical u64 little-endian values in [0, p),
+ *    p = 2013265921 (BabyBear, src/core/field_presets.zig:19) -- the in-memory layout of
+ *    `[]F` for `F = Field(u64, p)` (src/core/field.zig:27), so Zig slices pass as-is.
+ *    Non-canonical inputs are rejected with ZIGZ_ERR_NOT_CANONICAL.
+ *  - Results are written into caller-allocated buffers (Zig callers own every returned slice);
+ *    opaque handles have an explicit *_destroy.
+ *  - Every function returns a zigz_status; the codes map 1:1 onto the Zig error names.
+ *  - No global state: all state lives in a zigz_ctx (one per thread / per GPU).  A context is
+ *    bound to one HIP device and one stream; calls on one context must not race.
+ *  - Device-resident variants (zigz_dev_*) take device pointers to packed u32 canonical elements
+ *    (4 B/element in HBM) and run on the context's stream; plain pointers, no torch types.
+ *  - The library never falls back to the CPU for field or hash work: without a usable gfx950
+ *    device zigz_ctx_create fails with ZIGZ_ERR_NO_DEVICE.
+ */
+#ifndef ZIGZ_HIP_H
+#define ZIGZ_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ZIGZ_BABYBEAR_P 2013265921ull
+#define ZIGZ_NUM_COLUMNS 43 /* src/prover/prover.zig:376-390 */
+#define ZIGZ_HASH_SIZE 32   /* src/commitments/merkle_tree.zig:24 */
+#define ZIGZ_ABI_VERSION 1
+
+typedef int32_t zigz_status;
+enum {
+    ZIGZ_OK = 0,
+    ZIGZ_ERR_EMPTY_EVALUATIONS = 1,         /* error.EmptyEvaluations      multilinear.zig:37-39 */
+    ZIGZ_ERR_LENGTH_NOT_POWER_OF_TWO = 2,   /* error.LengthNotPowerOfTwo   multilinear.zig:42-44 */
+    ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES = 3, /* error.WrongNumberOfVariables multilinear.zig:111-113 */
+    ZIGZ_ERR_NO_VARIABLES_TO_FIX = 4,       /* error.NoVariablesToFix      multilinear.zig:155-157 */
+    ZIGZ_ERR_NO_VARIABLES = 5,              /* error.NoVariables           multilinear.zig:206-208 */
+    ZIGZ_ERR_PROTOCOL_ERROR = 6,            /* error.ProtocolError         sumcheck_prover.zig:80-82 */
+    ZIGZ_ERR_EMPTY_VALUES = 7,              /* error.EmptyValues           merkle_tree.zig:284 */
+    ZIGZ_ERR_TOO_MANY_VALUES = 8,           /* error.TooManyValues         merkle_tree.zig:287 */
+    ZIGZ_ERR_INDEX_OUT_OF_BOUNDS = 9,       /* error.IndexOutOfBounds      merkle_tree.zig:325 */
+    ZIGZ_ERR_POINT_DIMENSION_MISMATCH = 10, /* error.PointDimensionMismatch polynomial_commit.zig:92-94 */
+    ZIGZ_ERR_NO_QUERIES = 11,               /* error.NoQueries             lasso_prover.zig:108-110 */
+    ZIGZ_ERR_TOO_MANY_QUERIES = 12,         /* error.TooManyQueries        lasso_prover.zig:131 */
+    ZIGZ_ERR_MAPPING_LENGTH_MISMATCH = 13,  /* error.MappingLengthMismatch lasso_prover.zig:185-187 */
+    ZIGZ_ERR_INVALID_MAPPING = 14,          /* error.InvalidMapping        lasso_prover.zig:191-193 */
+    ZIGZ_ERR_QUERY_TABLE_MISMATCH = 15,     /* error.QueryTableMismatch    lasso_prover.zig:198-200 */
+    ZIGZ_ERR_EMPTY_TRACE = 16,              /* error.EmptyTrace            prover.zig:147-149 */
+    ZIGZ_ERR_OUT_OF_MEMORY = 17,            /* error.OutOfMemory (host or device) */
+    ZIGZ_ERR_WRONG_NUMBER_OF_CHALLENGES = 18, /* error.WrongNumberOfChallenges sumcheck_prover.zig:105-107 */
+    /* backend-specific (no Zig counterpart) */
+    ZIGZ_ERR_NO_DEVICE = 100,     /* no HIP device / not gfx950 / kernels not loadable */
+    ZIGZ_ERR_HIP = 101,           /* a HIP runtime call failed; see zigz_last_error */
+    ZIGZ_ERR_NOT_CANONICAL = 102, /* a field element >= p crossed the boundary */
+    ZIGZ_ERR_INVALID_ARGUMENT = 103,
+    ZIGZ_ERR_BAD_STATE = 104      /* commit-job calls out of order */
+};
+
+typedef struct zigz_ctx zigz_ctx;
+typedef struct zigz_merkle zigz_merkle;         /* one committed column: all tree levels in HBM */
+typedef struct zigz_commit_job zigz_commit_job; /* a batch of columns going through commit -> open */
+typedef struct zigz_transcript zigz_transcript; /* host-side SHA3 Fiat-Shamir sponge */
+
+/* ---------------------------------------------------------------- context */
+uint32_t zigz_abi_version(void);
+const char *zigz_status_name(zigz_status s); /* the Zig error name, e.g. "LengthNotPowerOfTwo" */
+zigz_status zigz_device_count(int *count);
+/* Binds a context to HIP device `device` (must be gfx950) and creates its stream + workspace. */
+zigz_status zigz_ctx_create(int device, zigz_ctx **out);
+void zigz_ctx_destroy(zigz_ctx *ctx);
+const char *zigz_last_error(const zigz_ctx *ctx);
+/* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
+zigz_status zigz_ctx_set_stream(zigz_ctx *ctx, void *hip_stream);
+void *zigz_ctx_get_stream(zigz_ctx *ctx);
+zigz_status zigz_ctx_synchronize(zigz_ctx *ctx);
+/* Device memory for callers without their own allocator (hipMalloc / hipFree). */
+zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out);
+zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr);
+/* canonical u64 host -> packed u32 device (validates < p), and back */
+zigz_status zigz_dev_upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out);
+zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out);
+
+/* ---------------------------------------------------------------- Multilinear(F), host buffers
+ * Drop-in for src/poly/multilinear.zig; `in` is `self.evaluations` (len n = 2^v). */
+/* partialEval(self, r, allocator) !Self   multilinear.zig:154-180: out[i]=(1-r)a[i]+r*a[i+n/2], i<n/2 */
+zigz_status zigz_mle_bind(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t r, uint64_t *out);
+/* roundPolynomial(self, allocator) ![]F   multilinear.zig:205-232: out = [s0, s1 - s0] */
+zigz_status zigz_mle_round_poly(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t out[2]);
+/* sumOverHypercube(self) F                multilinear.zig:188-194 */
+zigz_status zigz_mle_sum(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *out);
+/* eval(self, point) !F                    multilinear.zig:110-144 (point[0] <-> LSB of the index) */
+zigz_status zigz_mle_eval(zigz_ctx *ctx, const uint64_t *in, size_t n, const uint64_t *point,
+                          size_t point_len, uint64_t *out);
+
+/* ---------------------------------------------------------------- SumcheckProver(F)
+ * prove(poly, allocator) !Proof           src/proofs/sumcheck_prover.zig:26-91
+ * rounds: 2*v values [c0,c1] per round; point: v challenges in binding order; SHA3 transcript
+ * (fresh per call, src/proofs/sumcheck_protocol.zig:161,176-184) runs on the host inside. */
+zigz_status zigz_sumcheck_prove(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *rounds,
+                                uint64_t *point, uint64_t *final_eval);
+/* proveInteractive(poly, challenges, allocator)  sumcheck_prover.zig:97-144 */
+zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint64_t *in, size_t n,
+                                            const uint64_t *challenges, size_t n_challenges,
+                                            uint64_t *rounds, uint64_t *point, uint64_t *final_eval);
+
+/* ---------------------------------------------------------------- SimpleMerkleTree(F, SHA3Hasher)
+ * build(values, allocator) !Self          src/commitments/merkle_tree.zig:283-318 (pads with hashLeaf(0)) */
+zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values, size_t n, uint8_t root[32],
+                               size_t *height, zigz_merkle **out);
+/* open(self, index) !OpeningProof(F)      merkle_tree.zig:324-360; siblings: 32*height B, dirs: height B */
+zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *tree, size_t index, uint8_t *siblings,
+                             uint8_t *dirs, uint64_t *leaf_value);
+void zigz_merkle_destroy(zigz_ctx *ctx, zigz_merkle *tree);
+/* CommitmentScheme.open(poly, tree, point, allocator) !Proof   src/commitments/polynomial_commit.zig:86-115
+ * = eval(point) + tree.open(point[0].value mod 2^v)  (pointToIndex, :178-183) */
+zigz_status zigz_commit_open(zigz_ctx *ctx, const uint64_t *evals, size_t n, const zigz_merkle *tree,
+                             const uint64_t *point, size_t point_len, uint64_t *value, uint64_t *index,
+                             uint8_t *siblings, uint8_t *dirs, uint64_t *leaf_value);
+
+/* ---------------------------------------------------------------- Prover.generateCommitments (batched)
+ * src/prover/prover.zig:366-467, split at the two transcript dependencies so the caller keeps its
+ * own Fiat-Shamir transcript:  begin (Merkle builds, async) -> roots -> [caller absorbs roots, draws
+ * ncols*v challenges] -> open_all (evals + paths) -> end.
+ * cols: column-major, column c at cols + c*col_stride (elements), each 2^nv long. */
+zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols, size_t col_stride,
+                              size_t nv, zigz_commit_job **out);
+/* device-resident columns (packed u32 canonical); the buffer must stay valid until zigz_commit_end */
+zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
+                                  size_t nv, zigz_commit_job **out);
+/* waits for the Merkle builds; roots: ncols*32 bytes (prover.zig:405-410) */
+zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots);
+/* points: ncols*nv challenges (row c = point of column c).  Outputs per column: value = eval(point)
+ * (prover.zig:427), index = point[0] mod 2^nv, leaf = evaluations[index], siblings ncols*nv*32 B,
+ * dirs ncols*nv B (prover.zig:431 -> polynomial_commit.zig:86-115 -> merkle_tree.zig:324-360). */
+zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, uint64_t *values,
+                                 uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);
+void zigz_commit_end(zigz_commit_job *job);
+
+/* ---------------------------------------------------------------- LassoProver(F)
+ * prove(table, queries, allocator) !Proof   src/lookups/lasso_prover.zig:103-173
+ * table / queries: row-major, each row = n_in input fields then n_out output fields.
+ * Outputs: nv = log2(ceilPow2(n_queries)); rounds 2*nv; point nv; the two flat SHA3 commitments. */
+zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, size_t table_rows, const uint64_t *queries,
+                             size_t n_queries, size_t n_in, size_t n_out, size_t *nv_out, uint64_t *rounds,
+                             uint64_t *point, uint64_t *final_eval, uint8_t query_commitment[32],
+                             uint8_t table_commitment[32]);
+/* proveWithMapping(table, queries, mapping, allocator)   lasso_prover.zig:179-205 */
+zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64_t *table, size_t table_rows,
+                                          const uint64_t *queries, size_t n_queries, size_t n_in, size_t n_out,
+                                          const uint64_t *mapping, size_t n_mapping, size_t *nv_out,
+                                          uint64_t *rounds, uint64_t *point, uint64_t *final_eval,
+                                          uint8_t query_commitment[32], uint8_t table_commitment[32]);
+/* hashEntry / hashQuery fingerprints (lasso_prover.zig:208-239) for `rows` rows of `width` fields */
+zigz_status zigz_lasso_fingerprints(zigz_ctx *ctx, const uint64_t *rows_in, size_t rows, size_t width,
+                                    uint64_t *out);
+
+/* ---------------------------------------------------------------- witness columns (K8)
+ * F.init(u64) = x mod p over raw 64-bit trace words (src/constraints/witness.zig:76,112,164-170,237-239):
+ * d_out[i] = h_in[i] mod p, packed u32, for building device-resident columns from raw trace data. */
+zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out);
+
+/* ---------------------------------------------------------------- device-resident MLE / sumcheck */
+zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out);
+/* fused: d_out = bind(d_in, r) and sums[0..1] = (sum of low half, sum of high half) of d_out */
+zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out,
+                                   uint64_t half_sums[2]);
+zigz_status zigz_dev_mle_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t half_sums[2]);
+zigz_status zigz_dev_mle_eval(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *point,
+                              size_t point_len, uint64_t *out);
+/* d_scratch: n/2 + n/4 ... < n elements of scratch (may be NULL: taken from the context workspace) */
+zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
+                                    const uint64_t *fixed_challenges, uint64_t *rounds, uint64_t *point,
+                                    uint64_t *final_eval);
+
+/* ---------------------------------------------------------------- host SHA3 sponge / transcript
+ * FiatShamirTranscript   src/core/hash.zig:255-324 (sequential by construction: stays on the host) */
+zigz_transcript *zigz_transcript_new(void);
+void zigz_transcript_free(zigz_transcript *t);
+void zigz_transcript_append_bytes(zigz_transcript *t, const uint8_t *data, size_t len);
+void zigz_transcript_append_field(zigz_transcript *t, uint64_t canonical_value);
+/* appends `count` times:  tag bytes then LE64((start + k) mod p), k = 0..count-1
+ * (the "LASSO_TABLE" loop of prover.zig:302-312 in one call) */
+void zigz_transcript_append_tagged_counter(zigz_transcript *t, const uint8_t *tag, size_t tag_len,
+                                           uint64_t start, uint64_t count);
+uint64_t zigz_transcript_challenge(zigz_transcript *t); /* BabyBear; hash.zig:301-316 */
+void zigz_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]);
+void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]);
+
+/* ---------------------------------------------------------------- measurement hooks (bench.py)
+ * Average device time (microseconds, HIP events on the context's stream) of the last call's
+ * dominant kernels; reset by each API call that records them. */
+typedef struct zigz_kernel_stats {
+    double merkle_build_us;   /* all Keccak leaf + level launches of the last commit_begin */
+    double eval_us;           /* all MLE fold / eval launches of the last commit_open_all */
+    double path_us;           /* path gather */
+    double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch */
+    uint64_t bind_launches;
+    uint64_t keccak_permutations;
+} zigz_kernel_stats;
+zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
+zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,338 @@
+"""GPU parity tests (-m gpu): the HIP path, called through the C ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden fixtures, and -- at BASELINE sizes -- through
+size-independent properties.  Bar: bit-exact (integer field / byte work)."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+
+P = O.P_BB
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zigz_amd
+    c = zigz_amd.Context(0)  # raises NoDevice (no CPU fallback) when the HIP path cannot run
+    yield c
+    c.close()
+
+
+def ints(xs):
+    return [int(x) for x in xs]
+
+
+def rnd(seed, n):
+    return O.splitmix64_field(seed, n)
+
+
+# ---------------------------------------------------------------- K1/K2/K3/K4: Multilinear seams
+@pytest.mark.parametrize("nv", [1, 2, 3, 5, 8, 11, 12, 13, 14, 16, 18])
+def test_mle_bind_round_sum(ctx, nv):
+    ev = rnd(100 + nv, 1 << nv)
+    for r in (0, 1, P - 1, int(rnd(7, 1)[0])):
+        got = ctx.mle_bind(ev, r)
+        assert np.array_equal(got, O.mle_partial_eval(P, ev, r)), (nv, r)
+    assert ctx.mle_round_poly(ev) == O.mle_round_poly(P, ev)
+    assert ctx.mle_sum(ev) == O.mle_sum(P, ev)
+
+
+def test_mle_edge_values(ctx):
+    # all p-1 (maximum sums), all zero, and the reference's own [1,2,3,4] table
+    for nv in (1, 4, 13, 16):
+        ev = np.full(1 << nv, P - 1, dtype=np.uint64)
+        assert ctx.mle_round_poly(ev) == O.mle_round_poly(P, ev)
+        assert ctx.mle_sum(ev) == O.mle_sum(P, ev)
+        assert np.array_equal(ctx.mle_bind(ev, P - 1), O.mle_partial_eval(P, ev, P - 1))
+        z = np.zeros(1 << nv, dtype=np.uint64)
+        assert ctx.mle_sum(z) == 0 and ctx.mle_round_poly(z) == [0, 0]
+    assert list(ctx.mle_bind([1, 2, 3, 4], 0)) == [1, 2]  # multilinear.zig:436-463
+    assert ctx.mle_sum([1, 2, 3, 4]) == 10 and ctx.mle_round_poly([1, 2, 3, 4]) == [3, 4]  # :465-506 (values < 17)
+
+
+@pytest.mark.parametrize("nv", [0, 1, 2, 3, 6, 10, 12, 13, 15])
+def test_mle_eval(ctx, nv):
+    ev = rnd(200 + nv, 1 << nv)
+    for s in range(3):
+        pt = rnd(300 + 10 * nv + s, nv)
+        assert ctx.mle_eval(ev, pt) == O.mle_eval(P, ev, pt), (nv, s)
+    # boolean points select table entries LSB-first (multilinear.zig:383-413)
+    if nv and nv <= 6:
+        for idx in range(1 << nv):
+            pt = [(idx >> v) & 1 for v in range(nv)]
+            assert ctx.mle_eval(ev, pt) == int(ev[idx])
+
+
+def test_mle_errors(ctx):
+    import zigz_amd
+    E = zigz_amd.errors
+    cases = [(lambda: ctx.mle_bind([1, 2, 3], 1), E.LENGTH_NOT_POWER_OF_TWO),
+             (lambda: ctx.mle_bind([], 1), E.EMPTY_EVALUATIONS),
+             (lambda: ctx.mle_bind([5], 1), E.NO_VARIABLES_TO_FIX),
+             (lambda: ctx.mle_round_poly([5]), E.NO_VARIABLES),
+             (lambda: ctx.mle_eval([1, 2, 3, 4], [1]), E.WRONG_NUMBER_OF_VARIABLES),
+             (lambda: ctx.sumcheck_prove([5]), E.NO_VARIABLES),
+             (lambda: ctx.sumcheck_prove([1, 2, 3, 4], [1]), E.WRONG_NUMBER_OF_CHALLENGES),
+             (lambda: ctx.mle_sum([P, 1]), E.NOT_CANONICAL),
+             (lambda: ctx.mle_bind([1, 2], P), E.NOT_CANONICAL)]
+    for fn, code in cases:
+        with pytest.raises(zigz_amd.ZigzError) as e:
+            fn()
+        assert e.value.code == code, e.value
+    assert ctx.mle_eval([9], []) == 9
+
+
+# ---------------------------------------------------------------- A5: sumcheck
+@pytest.mark.parametrize("nv", [1, 2, 3, 4, 7, 10, 12, 13, 14, 15, 17])
+def test_sumcheck_vs_oracle(ctx, nv):
+    ev = rnd(400 + nv, 1 << nv)
+    r, pt, fe = ctx.sumcheck_prove(ev)
+    r0, pt0, fe0 = O.sumcheck_prove(P, ev)
+    assert np.array_equal(r, r0) and np.array_equal(pt, pt0) and fe == fe0
+    assert O.sumcheck_to_bytes(r, pt, fe) == O.sumcheck_to_bytes(r0, pt0, fe0)
+    chs = rnd(500 + nv, nv)
+    r, pt, fe = ctx.sumcheck_prove(ev, chs)
+    r0, pt0, fe0 = O.sumcheck_prove(P, ev, chs)
+    assert np.array_equal(r, r0) and np.array_equal(pt, pt0) and fe == fe0
+
+
+@pytest.mark.parametrize("i", [i for i, e in enumerate(G["sumcheck"]) if e["p"] == str(P)])
+def test_sumcheck_golden(ctx, i):
+    e = G["sumcheck"][i]
+    if "evals" in e:
+        ev = ints(e["evals"])
+    elif e.get("evals_gen") == "iota1":
+        ev = [(k + 1) % P for k in range(1 << e["nv"])]  # config 1: 2^12-entry BabyBear MLE
+    else:
+        ev = rnd(e["evals_gen"]["splitmix64_seed"], 1 << e["nv"])
+    r, pt, fe = ctx.sumcheck_prove(ev)
+    assert [str(x) for x in r] == e["rounds"] and [str(x) for x in pt] == e["point"] and str(fe) == e["final_eval"]
+    assert hashlib.sha3_256(O.sumcheck_to_bytes(r, pt, fe)).hexdigest() == e["bytes_sha3"]
+
+
+def test_sumcheck_large_properties(ctx):
+    """2^20 and 2^22 elements: full oracle sumcheck would take long; check the size-independent
+    properties instead: round-0 sums, g_i(0)+g_i(1) chain, final_eval == eval(reverse(point))."""
+    for nv in (20, 22):
+        ev = rnd(600 + nv, 1 << nv)
+        r, pt, fe = ctx.sumcheck_prove(ev)
+        total = int(ev.sum(dtype=np.uint64) % np.uint64(P)) if nv <= 30 else None
+        s0 = int(r[0]); s1 = (int(r[0]) + int(r[1])) % P
+        assert (s0 + s1) % P == total
+        assert [s0, int(r[1])] == O.mle_round_poly(P, ev)
+        claim = total
+        for k in range(nv):
+            c0, c1 = int(r[2 * k]), int(r[2 * k + 1])
+            assert (2 * c0 + c1) % P == claim  # g(0) + g(1)
+            claim = (c0 + c1 * int(pt[k])) % P
+        assert claim == fe
+        # transcript: challenges re-derived by the oracle's transcript
+        t = O.Transcript()
+        for k in range(nv):
+            t.append_field(int(r[2 * k])); t.append_field(int(r[2 * k + 1]))
+            assert t.challenge(P) == int(pt[k])
+        assert ctx.mle_eval(ev, list(pt)[::-1]) == fe  # SURVEY s0 fact 7 (GPU eval, itself oracle-checked above)
+
+
+# ---------------------------------------------------------------- A7/A8/A9: Merkle + commitment scheme
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 8, 33, 256, 257, 512, 1000, 1024, 4096, 5000])
+def test_merkle_vs_oracle(ctx, n):
+    import zigz_amd
+    vals = rnd(700 + n, n)
+    t = zigz_amd.SimpleMerkleTree.build(ctx, vals)
+    root, h = O.merkle_build(vals)
+    assert t.getRoot() == root and t.height == h
+    for idx in sorted({0, n - 1, n // 2, (n * 7) // 11}):
+        o = t.open(idx)
+        sib, dirs, leaf = O.merkle_open(vals, idx)
+        assert o["siblings"] == sib and o["directions"] == dirs and o["value"] == leaf
+        assert O.merkle_verify(root, o["value"], o["siblings"], o["directions"])
+    with pytest.raises(zigz_amd.ZigzError) as e:
+        t.open(n)
+    assert e.value.code == zigz_amd.errors.INDEX_OUT_OF_BOUNDS
+    t.deinit()
+
+
+@pytest.mark.parametrize("i", range(len(G["merkle"])))
+def test_merkle_golden(ctx, i):
+    import zigz_amd
+    e = G["merkle"][i]
+    vals = ints(e["values"])
+    t = zigz_amd.SimpleMerkleTree.build(ctx, vals)
+    assert t.getRoot().hex() == e["root"] and t.height == e["height"]
+    for o in e["openings"]:
+        g = t.open(o["index"])
+        assert [g["siblings"][32 * k:32 * k + 32].hex() for k in range(t.height)] == o["siblings"]
+        assert list(g["directions"]) == o["dirs"]
+    t.deinit()
+
+
+def test_merkle_errors(ctx):
+    import zigz_amd
+    with pytest.raises(zigz_amd.ZigzError) as e:
+        zigz_amd.SimpleMerkleTree.build(ctx, [])
+    assert e.value.code == zigz_amd.errors.EMPTY_VALUES
+
+
+@pytest.mark.parametrize("i", range(len(G["commit_open"])))
+def test_commit_open_golden(ctx, i):
+    import zigz_amd
+    e = G["commit_open"][i]
+    ev = rnd(e["evals_seed"], 1 << e["nv"])
+    root, tree = zigz_amd.CommitmentScheme.commit(ctx, ev)
+    assert root.hex() == e["root"]
+    o = zigz_amd.CommitmentScheme.open(ctx, ev, tree, ints(e["point"]))
+    assert str(o["value"]) == e["value"] and o["index"] == e["index"] and str(o["leaf"]) == e["leaf"]
+    assert [o["siblings"][32 * k:32 * k + 32].hex() for k in range(e["nv"])] == e["siblings"]
+    assert list(o["directions"]) == e["dirs"]
+    with pytest.raises(zigz_amd.ZigzError) as err:
+        zigz_amd.CommitmentScheme.open(ctx, ev, tree, ints(e["point"])[:-1])
+    assert err.value.code == zigz_amd.errors.POINT_DIMENSION_MISMATCH
+    tree.deinit()
+
+
+# ---------------------------------------------------------------- A10: generateCommitments (43 columns)
+@pytest.mark.parametrize("nv", [0, 1, 2, 3, 5, 9, 10, 13])
+def test_commit_job_vs_oracle(ctx, nv):
+    import zigz_amd
+    N = 1 << nv
+    cols = rnd(0x5A49475A + nv, 43 * N).reshape(43, N)
+    # oracle: literal generateCommitments continuing a transcript
+    to = O.Transcript(); to.append_bytes(b"prefix")
+    exp = O.generate_commitments(P, to, cols, fast=(nv > 10))
+    # HIP path: begin -> roots -> host transcript -> open_all
+    job = zigz_amd.CommitJob(ctx, cols=cols)
+    roots = job.roots()
+    assert np.array_equal(roots, exp["roots"])
+    tg = zigz_amd.Transcript(); tg.append_bytes(b"prefix")
+    tg.append_bytes(b"POLY_COMMITMENTS")
+    for c in range(43):
+        tg.append_bytes(roots[c].tobytes())
+    points = np.array([[tg.challenge() for _ in range(nv)] for _ in range(43)], dtype=np.uint64).reshape(43, nv)
+    assert np.array_equal(points, exp["points"])
+    got = job.open_all(points)
+    job.end()
+    for k in ("values", "indices", "leaves", "siblings", "dirs"):
+        assert np.array_equal(got[k], exp[k]), k
+    tg.append_bytes(b"OPENING_CLAIMS")
+    for c in range(43):
+        tg.append_field(int(got["values"][c]))
+    assert tg.challenge() == to.challenge(P)
+
+
+def test_commit_job_large_properties(ctx):
+    """43 x 2^18 columns (BASELINE-scale shape): every opening verifies against its root through the
+    oracle's Merkle verifier; values match the oracle's fold-eval on sampled columns."""
+    import zigz_amd
+    nv = 18
+    N = 1 << nv
+    cols = rnd(991, 43 * N).reshape(43, N)
+    job = zigz_amd.CommitJob(ctx, cols=cols)
+    roots = job.roots()
+    points = rnd(992, 43 * nv).reshape(43, nv)
+    got = job.open_all(points)
+    job.end()
+    for c in range(43):
+        idx = int(points[c, 0]) % N
+        assert int(got["indices"][c]) == idx and int(got["leaves"][c]) == int(cols[c, idx])
+        assert O.merkle_verify(roots[c].tobytes(), int(got["leaves"][c]), got["siblings"][c].tobytes(),
+                               got["dirs"][c].tobytes())
+    for c in (0, 17, 42):
+        lv, h = O.merkle_levels(cols[c])
+        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == roots[c].tobytes()
+        # eval via oracle folds == sumcheck-interactive final eval with reversed point
+        _, _, fe = O.sumcheck_prove(P, cols[c], list(points[c])[::-1])
+        assert fe == int(got["values"][c])
+
+
+# ---------------------------------------------------------------- A11: Lasso
+@pytest.mark.parametrize("i", [i for i, e in enumerate(G["lasso"]) if e["p"] == str(P)])
+def test_lasso_golden(ctx, i):
+    e = G["lasso"][i]
+    tab = O.build_table(P, e["kind"], e["bits"])
+    q = np.array([ints(r) for r in e["queries"]], dtype=np.uint64)
+    d = ctx.lasso_prove(tab, q)
+    assert d["nv"] == e["nv"] and [str(x) for x in d["rounds"]] == e["rounds"]
+    assert [str(x) for x in d["point"]] == e["point"] and str(d["final_eval"]) == e["final_eval"]
+    assert d["query_commit"].hex() == e["query_commit"] and d["table_commit"].hex() == e["table_commit"]
+
+
+def test_lasso_vs_oracle_and_errors(ctx):
+    import zigz_amd
+    E = zigz_amd.errors
+    tab = O.build_table(P, 1, 8)  # 8-bit XOR subtable: 2^16 rows (table_decomposition scale)
+    rng = np.random.default_rng(3)
+    a = rng.integers(0, 256, 1000); b = rng.integers(0, 256, 1000)
+    q = np.stack([a, b, a ^ b], axis=1).astype(np.uint64)
+    mapping = (a * 256 + b).astype(np.uint64)
+    d = ctx.lasso_prove(tab, q, mapping=mapping)
+    o = O.lasso_prove(P, tab, q, mapping=mapping)
+    for k in ("nv", "final_eval", "query_commit", "table_commit"):
+        assert d[k] == o[k], k
+    assert np.array_equal(d["rounds"], o["rounds"]) and np.array_equal(d["point"], o["point"])
+    fp = ctx.lasso_fingerprints(q)
+    assert [int(x) for x in fp[:50]] == [O.lasso_hash_row(P, r) for r in q[:50]]
+    for fn, code in [(lambda: ctx.lasso_prove(tab, np.zeros((0, 3))), E.NO_QUERIES),
+                     (lambda: ctx.lasso_prove(tab, q[:1]), E.NO_VARIABLES),
+                     (lambda: ctx.lasso_prove(tab[:3], q[:2]), E.LENGTH_NOT_POWER_OF_TWO),
+                     (lambda: ctx.lasso_prove(tab, q[:2], mapping=[0]), E.MAPPING_LENGTH_MISMATCH),
+                     (lambda: ctx.lasso_prove(tab, q[:2], mapping=[1 << 20, 0]), E.INVALID_MAPPING),
+                     (lambda: ctx.lasso_prove(tab, q[:2], mapping=[0, 0]), E.QUERY_TABLE_MISMATCH)]:
+        with pytest.raises(zigz_amd.ZigzError) as e:
+            fn()
+        assert e.value.code == code, e.value
+
+
+# ---------------------------------------------------------------- device-resident entry points
+def test_device_resident_api(ctx):
+    nv = 16
+    n = 1 << nv
+    ev = rnd(1234, n)
+    d_in = ctx.dev_alloc(n * 4)
+    d_out = ctx.dev_alloc(n * 2)
+    try:
+        ctx.upload(ev, d_in)
+        assert np.array_equal(ctx.download(d_in, n), ev)
+        s = ctx.dev_mle_half_sums(d_in, n)
+        rp = O.mle_round_poly(P, ev)
+        assert s[0] == rp[0] and (s[1] - s[0]) % P == rp[1]
+        r = int(rnd(5, 1)[0])
+        ctx.dev_mle_bind(d_in, n, r, d_out)
+        exp = O.mle_partial_eval(P, ev, r)
+        assert np.array_equal(ctx.download(d_out, n // 2), exp)
+        s2 = ctx.dev_mle_bind_sums(d_in, n, r, d_out)
+        rp2 = O.mle_round_poly(P, exp)
+        assert s2[0] == rp2[0] and (s2[1] - s2[0]) % P == rp2[1]
+        assert np.array_equal(ctx.download(d_out, n // 2), exp)
+        pt = rnd(6, nv)
+        assert ctx.dev_mle_eval(d_in, n, pt) == O.mle_eval(P, ev, pt)
+        rr, pp, fe = ctx.dev_sumcheck_prove(d_in, n)
+        r0, p0, f0 = O.sumcheck_prove(P, ev)
+        assert np.array_equal(rr, r0) and np.array_equal(pp, p0) and fe == f0
+        assert np.array_equal(ctx.download(d_in, n), ev)  # input table untouched
+        # K8: F.init over raw 64-bit words
+        raw = np.array([0, 1, P - 1, P, P + 1, 2**32, 2**63, 2**64 - 1, 0xFFFFFFFFFFFFF000], dtype=np.uint64)
+        ctx.reduce_upload(raw, d_out)
+        assert [int(x) for x in ctx.download(d_out, len(raw))] == [int(x) % P for x in raw]
+    finally:
+        ctx.dev_free(d_in)
+        ctx.dev_free(d_out)
+
+
+def test_host_transcript_vs_oracle(ctx):
+    import zigz_amd
+    a, b = zigz_amd.Transcript(), O.Transcript()
+    for t in (a, b):
+        t.append_bytes(b"SUMCHECK_BEGIN"); t.append_field(12345)
+    a.append_tagged_counter(b"LASSO_TABLE", 0, 1000)
+    for i in range(1000):
+        b.append_bytes(b"LASSO_TABLE"); b.append_field(i)
+    for _ in range(5):
+        assert a.challenge() == b.challenge(P)

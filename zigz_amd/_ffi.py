@@ -1,0 +1,85 @@
+"""ctypes binding of include/zigz_hip.h (libzigz_hip.so).  The library is loaded from the in-tree
+zigz_amd/lib/ directory; a missing library is an ImportError -- there is no CPU fallback."""
+import ctypes as C
+import os
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libzigz_hip.so")
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -m zigz_amd.build` (hipcc, --offload-arch=gfx950). "
+        "zigz_amd has no CPU fallback.")
+
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+u64p = C.POINTER(C.c_uint64)
+u32p = C.POINTER(C.c_uint32)
+u8p = C.POINTER(C.c_uint8)
+szp = C.POINTER(C.c_size_t)
+vp = C.c_void_p
+
+
+class KernelStats(C.Structure):
+    _fields_ = [("merkle_build_us", C.c_double), ("eval_us", C.c_double), ("path_us", C.c_double),
+                ("bind_us", C.c_double), ("bind_launches", C.c_uint64), ("keccak_permutations", C.c_uint64)]
+
+
+# name -> (restype, argtypes).  Every symbol include/zigz_hip.h declares must appear here
+# (tests/test_abi.py cross-checks this table against the header and the shared object).
+SIGNATURES = {
+    "zigz_abi_version": (C.c_uint32, []),
+    "zigz_status_name": (C.c_char_p, [C.c_int32]),
+    "zigz_device_count": (C.c_int32, [C.POINTER(C.c_int)]),
+    "zigz_ctx_create": (C.c_int32, [C.c_int, C.POINTER(vp)]),
+    "zigz_ctx_destroy": (None, [vp]),
+    "zigz_last_error": (C.c_char_p, [vp]),
+    "zigz_ctx_set_stream": (C.c_int32, [vp, vp]),
+    "zigz_ctx_get_stream": (vp, [vp]),
+    "zigz_ctx_synchronize": (C.c_int32, [vp]),
+    "zigz_dev_alloc": (C.c_int32, [vp, C.c_size_t, C.POINTER(vp)]),
+    "zigz_dev_free": (C.c_int32, [vp, vp]),
+    "zigz_dev_upload_u64": (C.c_int32, [vp, u64p, C.c_size_t, vp]),
+    "zigz_dev_download_u64": (C.c_int32, [vp, vp, C.c_size_t, u64p]),
+    "zigz_mle_bind": (C.c_int32, [vp, u64p, C.c_size_t, C.c_uint64, u64p]),
+    "zigz_mle_round_poly": (C.c_int32, [vp, u64p, C.c_size_t, u64p]),
+    "zigz_mle_sum": (C.c_int32, [vp, u64p, C.c_size_t, u64p]),
+    "zigz_mle_eval": (C.c_int32, [vp, u64p, C.c_size_t, u64p, C.c_size_t, u64p]),
+    "zigz_sumcheck_prove": (C.c_int32, [vp, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "zigz_sumcheck_prove_interactive": (C.c_int32, [vp, u64p, C.c_size_t, u64p, C.c_size_t, u64p, u64p, u64p]),
+    "zigz_merkle_commit": (C.c_int32, [vp, u64p, C.c_size_t, u8p, szp, C.POINTER(vp)]),
+    "zigz_merkle_open": (C.c_int32, [vp, vp, C.c_size_t, u8p, u8p, u64p]),
+    "zigz_merkle_destroy": (None, [vp, vp]),
+    "zigz_commit_open": (C.c_int32, [vp, u64p, C.c_size_t, vp, u64p, C.c_size_t, u64p, u64p, u8p, u8p, u64p]),
+    "zigz_commit_begin": (C.c_int32, [vp, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
+    "zigz_commit_begin_dev": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
+    "zigz_commit_roots": (C.c_int32, [vp, u8p]),
+    "zigz_commit_open_all": (C.c_int32, [vp, u64p, u64p, u64p, u64p, u8p, u8p]),
+    "zigz_commit_end": (None, [vp]),
+    "zigz_lasso_prove": (C.c_int32, [vp, u64p, C.c_size_t, u64p, C.c_size_t, C.c_size_t, C.c_size_t, szp, u64p, u64p,
+                                     u64p, u8p, u8p]),
+    "zigz_lasso_prove_with_mapping": (C.c_int32, [vp, u64p, C.c_size_t, u64p, C.c_size_t, C.c_size_t, C.c_size_t, u64p,
+                                                  C.c_size_t, szp, u64p, u64p, u64p, u8p, u8p]),
+    "zigz_lasso_fingerprints": (C.c_int32, [vp, u64p, C.c_size_t, C.c_size_t, u64p]),
+    "zigz_dev_reduce_u64": (C.c_int32, [vp, u64p, C.c_size_t, vp]),
+    "zigz_dev_mle_bind": (C.c_int32, [vp, vp, C.c_size_t, C.c_uint64, vp]),
+    "zigz_dev_mle_bind_sums": (C.c_int32, [vp, vp, C.c_size_t, C.c_uint64, vp, u64p]),
+    "zigz_dev_mle_half_sums": (C.c_int32, [vp, vp, C.c_size_t, u64p]),
+    "zigz_dev_mle_eval": (C.c_int32, [vp, vp, C.c_size_t, u64p, C.c_size_t, u64p]),
+    "zigz_dev_sumcheck_prove": (C.c_int32, [vp, vp, C.c_size_t, vp, u64p, u64p, u64p, u64p]),
+    "zigz_transcript_new": (vp, []),
+    "zigz_transcript_free": (None, [vp]),
+    "zigz_transcript_append_bytes": (None, [vp, C.c_char_p, C.c_size_t]),
+    "zigz_transcript_append_field": (None, [vp, C.c_uint64]),
+    "zigz_transcript_append_tagged_counter": (None, [vp, C.c_char_p, C.c_size_t, C.c_uint64, C.c_uint64]),
+    "zigz_transcript_challenge": (C.c_uint64, [vp]),
+    "zigz_sha3_256": (None, [C.c_char_p, C.c_size_t, u8p]),
+    "zigz_sha256": (None, [C.c_char_p, C.c_size_t, u8p]),
+    "zigz_ctx_enable_timing": (C.c_int32, [vp, C.c_int]),
+    "zigz_ctx_get_stats": (C.c_int32, [vp, C.POINTER(KernelStats)]),
+}
+
+for _name, (_res, _args) in SIGNATURES.items():
+    _f = getattr(lib, _name)  # AttributeError here = the .so does not export a declared symbol
+    _f.restype = _res
+    _f.argtypes = _args

@@ -1,0 +1,921 @@
+// C ABI of libzigz_hip.so (include/zigz_hip.h): contexts, workspaces, boundary conversion and the
+// orchestration of the gfx950 kernels.  No CPU fallback for field or hash work on the data path: the
+// only host arithmetic is the sequential SHA3 Fiat-Shamir sponge (K11) and O(v) scalar bookkeeping.
+#include "zigz_hip.h"
+
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <vector>
+
+#include "field.hpp"
+#include "host_hash.hpp"
+#include "kernels.hpp"
+
+using namespace zk;
+
+// ------------------------------------------------------------------ context
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_SLOTS };
+
+struct zigz_ctx {
+    int device;
+    hipStream_t own_stream;
+    hipStream_t stream;
+    char err[512];
+    void *ws[WS_SLOTS];
+    size_t ws_bytes[WS_SLOTS];
+    unsigned long long *d_sums;  // SUMS_SLOTS u64
+    uint32_t *d_flag;
+    uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
+    bool timing;
+    hipEvent_t ev[6];
+    zigz_kernel_stats stats;
+    zigz_commit_job *active_job;
+};
+static const size_t SUMS_SLOTS = 4096;
+static const size_t PIN_WORDS = 1 << 16;
+
+static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
+    if (!ctx) return;
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(ctx->err, sizeof(ctx->err), fmt, ap);
+    va_end(ap);
+}
+
+#define HIPCHK(ctx, call)                                                                        \
+    do {                                                                                         \
+        hipError_t e_ = (call);                                                                  \
+        if (e_ != hipSuccess) {                                                                  \
+            set_err(ctx, "%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+            return e_ == hipErrorOutOfMemory ? ZIGZ_ERR_OUT_OF_MEMORY : ZIGZ_ERR_HIP;            \
+        }                                                                                        \
+    } while (0)
+#define CHK(expr)                          \
+    do {                                   \
+        zigz_status s_ = (expr);           \
+        if (s_ != ZIGZ_OK) return s_;      \
+    } while (0)
+
+static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
+static unsigned log2_floor(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; l++; } return l; }
+static size_t ceil_pow2(size_t n) { size_t v = 1; while (v < n) v <<= 1; return v; }
+
+static zigz_status ws_get(zigz_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->ws_bytes[slot] < bytes) {
+        if (ctx->ws[slot]) {
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            HIPCHK(ctx, hipFree(ctx->ws[slot]));
+            ctx->ws[slot] = nullptr;
+            ctx->ws_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 8;  // a little slack so slowly growing sizes do not realloc each call
+        want = (want + 255) & ~(size_t)255;
+        hipError_t e = hipMalloc(&ctx->ws[slot], want);
+        if (e != hipSuccess) {
+            (void)hipGetLastError();
+            want = (bytes + 255) & ~(size_t)255;
+            HIPCHK(ctx, hipMalloc(&ctx->ws[slot], want));
+        }
+        ctx->ws_bytes[slot] = want;
+    }
+    *out = ctx->ws[slot];
+    return ZIGZ_OK;
+}
+
+extern "C" uint32_t zigz_abi_version(void) { return ZIGZ_ABI_VERSION; }
+
+extern "C" const char *zigz_status_name(zigz_status s) {
+    switch (s) {
+    case ZIGZ_OK: return "OK";
+    case ZIGZ_ERR_EMPTY_EVALUATIONS: return "EmptyEvaluations";
+    case ZIGZ_ERR_LENGTH_NOT_POWER_OF_TWO: return "LengthNotPowerOfTwo";
+    case ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES: return "WrongNumberOfVariables";
+    case ZIGZ_ERR_NO_VARIABLES_TO_FIX: return "NoVariablesToFix";
+    case ZIGZ_ERR_NO_VARIABLES: return "NoVariables";
+    case ZIGZ_ERR_PROTOCOL_ERROR: return "ProtocolError";
+    case ZIGZ_ERR_EMPTY_VALUES: return "EmptyValues";
+    case ZIGZ_ERR_TOO_MANY_VALUES: return "TooManyValues";
+    case ZIGZ_ERR_INDEX_OUT_OF_BOUNDS: return "IndexOutOfBounds";
+    case ZIGZ_ERR_POINT_DIMENSION_MISMATCH: return "PointDimensionMismatch";
+    case ZIGZ_ERR_NO_QUERIES: return "NoQueries";
+    case ZIGZ_ERR_TOO_MANY_QUERIES: return "TooManyQueries";
+    case ZIGZ_ERR_MAPPING_LENGTH_MISMATCH: return "MappingLengthMismatch";
+    case ZIGZ_ERR_INVALID_MAPPING: return "InvalidMapping";
+    case ZIGZ_ERR_QUERY_TABLE_MISMATCH: return "QueryTableMismatch";
+    case ZIGZ_ERR_EMPTY_TRACE: return "EmptyTrace";
+    case ZIGZ_ERR_OUT_OF_MEMORY: return "OutOfMemory";
+    case ZIGZ_ERR_WRONG_NUMBER_OF_CHALLENGES: return "WrongNumberOfChallenges";
+    case ZIGZ_ERR_NO_DEVICE: return "NoDevice";
+    case ZIGZ_ERR_HIP: return "HipError";
+    case ZIGZ_ERR_NOT_CANONICAL: return "NotCanonical";
+    case ZIGZ_ERR_INVALID_ARGUMENT: return "InvalidArgument";
+    case ZIGZ_ERR_BAD_STATE: return "BadState";
+    default: return "Unknown";
+    }
+}
+
+extern "C" zigz_status zigz_device_count(int *count) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) {
+        (void)hipGetLastError();
+        n = 0;
+    }
+    if (count) *count = n;
+    return n > 0 ? ZIGZ_OK : ZIGZ_ERR_NO_DEVICE;
+}
+
+extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
+    if (!out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    *out = nullptr;
+    int n = 0;
+    if (zigz_device_count(&n) != ZIGZ_OK || device < 0 || device >= n) return ZIGZ_ERR_NO_DEVICE;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, device) != hipSuccess) return ZIGZ_ERR_NO_DEVICE;
+    if (strncmp(prop.gcnArchName, "gfx950", 6) != 0) return ZIGZ_ERR_NO_DEVICE;  // kernels are built for gfx950 only
+    zigz_ctx *ctx = new (std::nothrow) zigz_ctx();
+    if (!ctx) return ZIGZ_ERR_OUT_OF_MEMORY;
+    memset(ctx, 0, sizeof(*ctx));
+    ctx->device = device;
+    zigz_status st = ZIGZ_OK;
+    auto fail = [&](hipError_t e) { return e != hipSuccess; };
+    if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
+        fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
+        fail(hipMalloc((void **)&ctx->d_flag, 64)) ||
+        fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)))
+        st = ZIGZ_ERR_HIP;
+    for (int i = 0; st == ZIGZ_OK && i < 6; i++)
+        if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
+    if (st != ZIGZ_OK) {
+        zigz_ctx_destroy(ctx);
+        return st;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return ZIGZ_OK;
+}
+
+extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < WS_SLOTS; i++)
+        if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
+    if (ctx->d_sums) (void)hipFree(ctx->d_sums);
+    if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    for (int i = 0; i < 6; i++)
+        if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+extern "C" const char *zigz_last_error(const zigz_ctx *ctx) { return ctx ? ctx->err : "no context"; }
+
+extern "C" zigz_status zigz_ctx_set_stream(zigz_ctx *ctx, void *hip_stream) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return ZIGZ_OK;
+}
+extern "C" void *zigz_ctx_get_stream(zigz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
+
+extern "C" zigz_status zigz_ctx_synchronize(zigz_ctx *ctx) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out) {
+    if (!ctx || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipSetDevice(ctx->device));
+    HIPCHK(ctx, hipMalloc(d_out, bytes ? bytes : 16));
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    HIPCHK(ctx, hipFree(d_ptr));
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    ctx->timing = enable != 0;
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
+    if (!ctx || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    *out = ctx->stats;
+    return ZIGZ_OK;
+}
+
+// ------------------------------------------------------------------ boundary conversion
+// canonical u64 host image -> packed u32 in device memory (validates < p)
+static zigz_status upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out, bool reduce) {
+    if (n == 0) return ZIGZ_OK;
+    void *d64;
+    CHK(ws_get(ctx, WS_IN64, n * sizeof(uint64_t), &d64));
+    HIPCHK(ctx, hipMemcpyAsync(d64, h_in, n * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    if (reduce) {
+        launch_reduce_u64((const uint64_t *)d64, d_out, n, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        return ZIGZ_OK;
+    }
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_flag, 0, 4, ctx->stream));
+    launch_narrow_u64((const uint64_t *)d64, d_out, n, ctx->d_flag, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    uint32_t *hflag = (uint32_t *)ctx->h_pin;
+    HIPCHK(ctx, hipMemcpyAsync(hflag, ctx->d_flag, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (*hflag) {
+        set_err(ctx, "input contains a value >= p (not a canonical BabyBear element)");
+        return ZIGZ_ERR_NOT_CANONICAL;
+    }
+    return ZIGZ_OK;
+}
+
+static zigz_status download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out) {
+    if (n == 0) return ZIGZ_OK;
+    void *d64;
+    CHK(ws_get(ctx, WS_OUT64, n * sizeof(uint64_t), &d64));
+    launch_widen_u32(d_in, (uint64_t *)d64, n, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(h_out, d64, n * sizeof(uint64_t), hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out) {
+    if (!ctx || (n && (!h_in || !d_out))) return ZIGZ_ERR_INVALID_ARGUMENT;
+    return upload_u64(ctx, h_in, n, d_out, false);
+}
+extern "C" zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out) {
+    if (!ctx || (n && (!h_in || !d_out))) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(upload_u64(ctx, h_in, n, d_out, true));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out) {
+    if (!ctx || (n && (!h_out || !d_in))) return ZIGZ_ERR_INVALID_ARGUMENT;
+    return download_u64(ctx, d_in, n, h_out);
+}
+
+static zigz_status mle_check(size_t n) {  // Multilinear.init, multilinear.zig:36-44
+    if (n == 0) return ZIGZ_ERR_EMPTY_EVALUATIONS;
+    if (!is_pow2(n)) return ZIGZ_ERR_LENGTH_NOT_POWER_OF_TWO;
+    return ZIGZ_OK;
+}
+
+static inline uint32_t host_to_mont(uint64_t canonical) { return (uint32_t)((canonical << 32) % (uint64_t)P); }
+
+// reads `words` u64 from device through the pinned staging buffer (synchronises the stream)
+static zigz_status read_u64(zigz_ctx *ctx, const void *d_src, size_t words, uint64_t *dst) {
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_src, words * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    memcpy(dst, ctx->h_pin, words * 8);
+    return ZIGZ_OK;
+}
+
+// ------------------------------------------------------------------ device-resident MLE ops
+static zigz_status dev_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t out[2]) {
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 16, ctx->stream));
+    launch_half_sums(d_in, n, n, 1, ctx->d_sums, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return read_u64(ctx, ctx->d_sums, 2, out);
+}
+
+extern "C" zigz_status zigz_dev_mle_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t half_sums[2]) {
+    if (!ctx || !d_in || !half_sums) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    uint64_t s[2];
+    CHK(dev_half_sums(ctx, d_in, n, s));
+    half_sums[0] = s[0] % P;
+    half_sums[1] = s[1] % P;
+    return ZIGZ_OK;
+}
+
+static zigz_status timed_begin(zigz_ctx *ctx, int ev) {
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[ev], ctx->stream));
+    return ZIGZ_OK;
+}
+static zigz_status timed_end(zigz_ctx *ctx, int ev, double *us_out) {
+    if (ctx->timing) {
+        HIPCHK(ctx, hipEventRecord(ctx->ev[ev + 1], ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->ev[ev + 1]));
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[ev], ctx->ev[ev + 1]));
+        *us_out = (double)ms * 1000.0;
+    }
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out) {
+    if (!ctx || !d_in || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
+    if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+    CHK(timed_begin(ctx, 0));
+    launch_bind(d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, nullptr, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(timed_end(ctx, 0, &ctx->stats.bind_us));
+    ctx->stats.bind_launches = 1;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r,
+                                              uint32_t *d_out, uint64_t half_sums[2]) {
+    if (!ctx || !d_in || !d_out || !half_sums) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
+    if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 16, ctx->stream));
+    CHK(timed_begin(ctx, 0));
+    launch_bind(d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, ctx->d_sums, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    CHK(timed_end(ctx, 0, &ctx->stats.bind_us));
+    ctx->stats.bind_launches = 1;
+    uint64_t s[2];
+    CHK(read_u64(ctx, ctx->d_sums, 2, s));
+    half_sums[0] = s[0] % P;
+    half_sums[1] = s[1] % P;
+    return ZIGZ_OK;
+}
+
+// eval(point), multilinear.zig:110-144: point[0] <-> LSB.  Computed as v MSB-first binds with the
+// point reversed (exact arithmetic => the same canonical value as the reference's O(v*2^v) loop).
+// Batched over `ncols` columns, column c using point row c.  Result words land in d_vals[ncols].
+static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t col_stride, size_t ncols, size_t nv,
+                                  const uint64_t *points /*host, ncols*nv*/, uint32_t *d_vals) {
+    const size_t N = (size_t)1 << nv;
+    if (nv == 0) {
+        launch_gather_first(d_cols, col_stride, d_vals, ncols, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        return ZIGZ_OK;
+    }
+    // r table in Montgomery form, [round][col], staged in the upper half of the pinned buffer so the
+    // asynchronous H2D copy never reads freed host memory
+    if (nv * ncols * 4 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *rt = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
+    for (size_t k = 0; k < nv; k++)
+        for (size_t c = 0; c < ncols; c++) {
+            uint64_t r = points[c * nv + (nv - 1 - k)];
+            if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+            rt[k * ncols + c] = host_to_mont(r);
+        }
+    void *d_rt;
+    CHK(ws_get(ctx, WS_MISC, nv * ncols * 4 + 64, &d_rt));
+    HIPCHK(ctx, hipMemcpyAsync(d_rt, rt, nv * ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    void *fold;
+    const size_t a_elems = ncols * (N / 2), b_elems = ncols * (N / 4 ? N / 4 : 1);
+    CHK(ws_get(ctx, WS_FOLD, (a_elems + b_elems) * 4, &fold));
+    uint32_t *bufA = (uint32_t *)fold, *bufB = bufA + a_elems;
+    const uint32_t *src = d_cols;
+    size_t src_stride = col_stride, len = N;
+    for (size_t k = 0; k < nv; k++) {
+        uint32_t *dst = (k % 2 == 0) ? bufA : bufB;
+        size_t half = len / 2;
+        size_t dst_stride = half < 4 ? 4 : half;  // keep 16-byte alignment of every column
+        launch_bind(src, src_stride, dst, dst_stride, half, ncols, 0, (const uint32_t *)d_rt + k * ncols, nullptr,
+                    ctx->stream);
+        src = dst;
+        src_stride = dst_stride;
+        len = half;
+    }
+    HIPCHK(ctx, hipGetLastError());
+    launch_gather_first(src, src_stride, d_vals, ncols, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_mle_eval(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *point,
+                                         size_t point_len, uint64_t *out) {
+    if (!ctx || !d_in || !out || (point_len && !point)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (point_len != log2_floor(n)) return ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES;
+    void *misc;
+    CHK(ws_get(ctx, WS_OUT32, 64, &misc));
+    CHK(dev_eval_folds(ctx, d_in, n, 1, point_len, point, (uint32_t *)misc));
+    uint32_t *h = (uint32_t *)ctx->h_pin;
+    HIPCHK(ctx, hipMemcpyAsync(h, misc, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *out = h[0];
+    return ZIGZ_OK;
+}
+
+// ------------------------------------------------------------------ sumcheck (device-resident core)
+// SumcheckProver.prove, sumcheck_prover.zig:26-91.  Per round: [s0, s1-s0] -> host transcript ->
+// challenge -> fused bind + next-round half sums (one launch, one 16-byte read-back per round).
+static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
+                                 const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    const size_t nv = log2_floor(n);
+    if (2 * (nv + 1) > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (!d_scratch) {
+        void *s;
+        CHK(ws_get(ctx, WS_SCRATCH, (n / 2 + n / 4 + 8) * 4, &s));
+        d_scratch = (uint32_t *)s;
+    }
+    uint32_t *bufA = d_scratch, *bufB = d_scratch + n / 2;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 2 * (nv + 1) * sizeof(unsigned long long), ctx->stream));
+    launch_half_sums(d_in, n, n, 1, ctx->d_sums, ctx->stream);  // K3/K2 for round 0 (sum = s0+s1, prover:39)
+    HIPCHK(ctx, hipGetLastError());
+    uint64_t s[2];
+    CHK(read_u64(ctx, ctx->d_sums, 2, s));
+    Transcript tr;  // fresh transcript per sumcheck, sumcheck_protocol.zig:161
+    const uint32_t *cur = d_in;
+    size_t len = n;
+    double bind_us = 0;
+    for (size_t round = 0; round < nv; round++) {
+        uint64_t c0 = s[0] % P, s1 = s[1] % P;
+        uint64_t c1 = s1 >= c0 ? s1 - c0 : s1 + P - c0;  // roundPolynomial: [q(0), q(1)-q(0)], multilinear.zig:228-229
+        rounds[2 * round] = c0;
+        rounds[2 * round + 1] = c1;
+        uint64_t ch;
+        if (fixed) {
+            ch = fixed[round];
+            if (ch >= P) return ZIGZ_ERR_NOT_CANONICAL;
+        } else {
+            tr.append_field(c0);  // generateChallenge, sumcheck_protocol.zig:176-184
+            tr.append_field(c1);
+            ch = tr.challenge();
+        }
+        point[round] = ch;
+        uint32_t *dst = (round % 2 == 0) ? bufA : bufB;
+        const bool last = (len == 2);
+        unsigned long long *d_s = last ? nullptr : ctx->d_sums + 2 * (round + 1);
+        if (ctx->timing) CHK(timed_begin(ctx, 0));
+        launch_bind(cur, len, dst, len / 2, len / 2, 1, host_to_mont(ch), nullptr, d_s, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        if (ctx->timing) {
+            double us = 0;
+            CHK(timed_end(ctx, 0, &us));
+            bind_us += us;
+        }
+        cur = dst;
+        len /= 2;
+        if (!last) CHK(read_u64(ctx, d_s, 2, s));
+    }
+    if (len != 1) return ZIGZ_ERR_PROTOCOL_ERROR;  // sumcheck_prover.zig:80-82
+    uint32_t *h = (uint32_t *)ctx->h_pin;
+    HIPCHK(ctx, hipMemcpyAsync(h, cur, 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    *final_eval = h[0];
+    if (ctx->timing) {
+        ctx->stats.bind_us = bind_us;
+        ctx->stats.bind_launches = nv;
+    }
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
+                                               const uint64_t *fixed_challenges, uint64_t *rounds, uint64_t *point,
+                                               uint64_t *final_eval) {
+    if (!ctx || !d_in || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
+    return sumcheck_core(ctx, d_in, n, d_scratch, fixed_challenges, rounds, point, final_eval);
+}
+
+// ------------------------------------------------------------------ host-buffer seams: Multilinear
+static zigz_status stage_in(zigz_ctx *ctx, const uint64_t *in, size_t n, uint32_t **d_out) {
+    void *d32;
+    CHK(ws_get(ctx, WS_IN32, n * 4, &d32));
+    CHK(upload_u64(ctx, in, n, (uint32_t *)d32, false));
+    *d_out = (uint32_t *)d32;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_mle_bind(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t r, uint64_t *out) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
+    if (!in || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    void *d_o;
+    CHK(ws_get(ctx, WS_OUT32, (n / 2) * 4, &d_o));
+    CHK(zigz_dev_mle_bind(ctx, d_in, n, r, (uint32_t *)d_o));
+    return download_u64(ctx, (uint32_t *)d_o, n / 2, out);
+}
+
+extern "C" zigz_status zigz_mle_round_poly(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t out[2]) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
+    if (!in || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    uint64_t s[2];
+    CHK(dev_half_sums(ctx, d_in, n, s));
+    uint64_t s0 = s[0] % P, s1 = s[1] % P;
+    out[0] = s0;
+    out[1] = s1 >= s0 ? s1 - s0 : s1 + P - s0;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_mle_sum(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *out) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (!in || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    uint64_t s[2];
+    CHK(dev_half_sums(ctx, d_in, n, s));
+    *out = (s[0] % P + s[1] % P) % P;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_mle_eval(zigz_ctx *ctx, const uint64_t *in, size_t n, const uint64_t *point,
+                                     size_t point_len, uint64_t *out) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (point_len != log2_floor(n)) return ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES;
+    if (!in || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    return zigz_dev_mle_eval(ctx, d_in, n, point, point_len, out);
+}
+
+extern "C" zigz_status zigz_sumcheck_prove(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *rounds,
+                                           uint64_t *point, uint64_t *final_eval) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
+    if (!in || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    return sumcheck_core(ctx, d_in, n, nullptr, nullptr, rounds, point, final_eval);
+}
+
+extern "C" zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint64_t *in, size_t n,
+                                                       const uint64_t *challenges, size_t n_challenges,
+                                                       uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
+    if (n_challenges != log2_floor(n)) return ZIGZ_ERR_WRONG_NUMBER_OF_CHALLENGES;
+    if (!in || !challenges || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *d_in;
+    CHK(stage_in(ctx, in, n, &d_in));
+    return sumcheck_core(ctx, d_in, n, nullptr, challenges, rounds, point, final_eval);
+}
+
+// ------------------------------------------------------------------ Merkle
+// builds all levels of `ncols` trees (leaf hashes + level merges), asynchronous on the stream
+static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
+                               uint8_t *d_tree, size_t ncols) {
+    const unsigned height = log2_floor(npad);
+    const size_t stride = tree_nodes(npad);
+    launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream);
+    for (unsigned l = 0; l < height; l++) {
+        const size_t n_out = npad >> (l + 1);
+        if (n_out <= 256) {
+            launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
+            break;
+        }
+        launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols,
+                            ctx->stream);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    return ZIGZ_OK;
+}
+
+struct zigz_merkle {
+    uint32_t *d_vals;  // stored values (SimpleMerkleTree.values, merkle_tree.zig:291)
+    uint8_t *d_tree;
+    size_t n_values, npad;
+    unsigned height;
+};
+
+extern "C" void zigz_merkle_destroy(zigz_ctx *ctx, zigz_merkle *t) {
+    if (!t) return;
+    if (ctx) (void)hipStreamSynchronize(ctx->stream);
+    if (t->d_vals) (void)hipFree(t->d_vals);
+    if (t->d_tree) (void)hipFree(t->d_tree);
+    delete t;
+}
+
+extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values, size_t n, uint8_t root[32],
+                                          size_t *height, zigz_merkle **out) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n == 0) return ZIGZ_ERR_EMPTY_VALUES;                      // merkle_tree.zig:284
+    if (n > ((size_t)1 << 40)) return ZIGZ_ERR_TOO_MANY_VALUES;    // merkle_tree.zig:287 (device-size cap)
+    if (!values || !root) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const size_t npad = ceil_pow2(n);
+    zigz_merkle *t = new (std::nothrow) zigz_merkle();
+    if (!t) return ZIGZ_ERR_OUT_OF_MEMORY;
+    memset(t, 0, sizeof(*t));
+    t->n_values = n;
+    t->npad = npad;
+    t->height = log2_floor(npad);
+    zigz_status st = ZIGZ_OK;
+    auto body = [&]() -> zigz_status {
+        HIPCHK(ctx, hipMalloc((void **)&t->d_vals, n * 4));
+        HIPCHK(ctx, hipMalloc((void **)&t->d_tree, tree_nodes(npad) * 32));
+        CHK(upload_u64(ctx, values, n, t->d_vals, false));
+        CHK(build_trees(ctx, t->d_vals, n, n, npad, t->d_tree, 1));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, t->d_tree + tree_level_offset(npad, t->height) * 32, 32,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        memcpy(root, ctx->h_pin, 32);
+        return ZIGZ_OK;
+    };
+    st = body();
+    if (st != ZIGZ_OK) {
+        zigz_merkle_destroy(ctx, t);
+        return st;
+    }
+    if (height) *height = t->height;
+    if (out) *out = t;
+    else zigz_merkle_destroy(ctx, t);
+    return ZIGZ_OK;
+}
+
+static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad, unsigned height, const uint32_t *d_vals,
+                              size_t val_stride, const uint64_t *h_idx, size_t ncols, uint8_t *siblings, uint8_t *dirs,
+                              uint64_t *leaves) {
+    // device scratch layout: idx[ncols] u64 | sib[ncols*h*32] | leaf[ncols] u32 | dirs[ncols*h]
+    const size_t sib_b = ncols * height * 32, idx_b = ncols * 8, leaf_b = ncols * 4, dir_b = ncols * height;
+    void *w;
+    CHK(ws_get(ctx, WS_OUT32, idx_b + sib_b + leaf_b + dir_b + 64, &w));
+    uint8_t *base = (uint8_t *)w;
+    uint64_t *d_idx = (uint64_t *)base;
+    uint8_t *d_sib = base + idx_b;
+    uint32_t *d_leaf = (uint32_t *)(d_sib + sib_b);
+    uint8_t *d_dirs = (uint8_t *)(d_leaf + ncols);
+    HIPCHK(ctx, hipMemcpyAsync(d_idx, h_idx, idx_b, hipMemcpyHostToDevice, ctx->stream));
+    launch_paths(d_tree, tree_nodes(npad), npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols,
+                 ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<uint32_t> hl(ncols);
+    if (sib_b) HIPCHK(ctx, hipMemcpyAsync(siblings, d_sib, sib_b, hipMemcpyDeviceToHost, ctx->stream));
+    if (dir_b) HIPCHK(ctx, hipMemcpyAsync(dirs, d_dirs, dir_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(hl.data(), d_leaf, leaf_b, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t c = 0; c < ncols; c++) leaves[c] = hl[c];
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *t, size_t index, uint8_t *siblings,
+                                        uint8_t *dirs, uint64_t *leaf_value) {
+    if (!ctx || !t || !leaf_value) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (index >= t->n_values) return ZIGZ_ERR_INDEX_OUT_OF_BOUNDS;  // merkle_tree.zig:325 (values.len)
+    if (t->height && (!siblings || !dirs)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint64_t idx = index;
+    return open_paths(ctx, t->d_tree, t->npad, t->height, t->d_vals, t->n_values, &idx, 1, siblings, dirs, leaf_value);
+}
+
+extern "C" zigz_status zigz_commit_open(zigz_ctx *ctx, const uint64_t *evals, size_t n, const zigz_merkle *tree,
+                                        const uint64_t *point, size_t point_len, uint64_t *value, uint64_t *index,
+                                        uint8_t *siblings, uint8_t *dirs, uint64_t *leaf_value) {
+    if (!ctx || !tree || !value || !index || !leaf_value) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n));
+    if (point_len != log2_floor(n)) return ZIGZ_ERR_POINT_DIMENSION_MISMATCH;  // polynomial_commit.zig:92-94
+    const uint32_t *d_ev = tree->d_vals;
+    if (evals) {
+        uint32_t *d;
+        CHK(stage_in(ctx, evals, n, &d));
+        d_ev = d;
+    } else if (tree->n_values != n) {
+        return ZIGZ_ERR_INVALID_ARGUMENT;
+    }
+    CHK(zigz_dev_mle_eval(ctx, d_ev, n, point, point_len, value));  // polynomial_commit.zig:97
+    size_t idx = point_len == 0 ? 0 : (size_t)(point[0] % ((uint64_t)1 << point_len));  // pointToIndex, :178-183
+    *index = idx;
+    return zigz_merkle_open(ctx, tree, idx, siblings, dirs, leaf_value);  // :105
+}
+
+// ------------------------------------------------------------------ batched commit job (generateCommitments)
+struct zigz_commit_job {
+    zigz_ctx *ctx;
+    size_t ncols, nv, N, col_stride;
+    const uint32_t *d_cols;
+    uint8_t *d_tree;
+    int state;  // 0 begun, 1 roots read, 2 opened
+    hipEvent_t built;
+};
+
+static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride, size_t nv,
+                             zigz_commit_job **out) {
+    if (ctx->active_job) {
+        set_err(ctx, "a commit job is already active on this context");
+        return ZIGZ_ERR_BAD_STATE;
+    }
+    zigz_commit_job *job = new (std::nothrow) zigz_commit_job();
+    if (!job) return ZIGZ_ERR_OUT_OF_MEMORY;
+    memset(job, 0, sizeof(*job));
+    job->ctx = ctx;
+    job->ncols = ncols;
+    job->nv = nv;
+    job->N = (size_t)1 << nv;
+    job->col_stride = col_stride;
+    job->d_cols = d_cols;
+    auto body = [&]() -> zigz_status {
+        void *tree;
+        CHK(ws_get(ctx, WS_TREE, ncols * tree_nodes(job->N) * 32, &tree));
+        job->d_tree = (uint8_t *)tree;
+        HIPCHK(ctx, hipEventCreateWithFlags(&job->built, hipEventDisableTiming));
+        CHK(timed_begin(ctx, 2));
+        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols));
+        if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+        // roots -> contiguous device buffer -> pinned staging (async), then the "built" event
+        void *d_roots;
+        CHK(ws_get(ctx, WS_MISC, ncols * 32 + nv * ncols * 4 + 128, &d_roots));
+        launch_gather_nodes(job->d_tree, tree_nodes(job->N), tree_level_offset(job->N, (unsigned)nv), (uint8_t *)d_roots,
+                            ncols, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
+        return ZIGZ_OK;
+    };
+    zigz_status st = body();
+    if (st != ZIGZ_OK) {
+        if (job->built) (void)hipEventDestroy(job->built);
+        delete job;
+        return st;
+    }
+    ctx->stats.keccak_permutations = (uint64_t)ncols * (2 * job->N - 1);
+    ctx->active_job = job;
+    *out = job;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
+                                             size_t nv, zigz_commit_job **out) {
+    if (!ctx || !d_cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (col_stride < ((size_t)1 << nv)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    return job_begin(ctx, d_cols, ncols, col_stride, nv, out);
+}
+
+extern "C" zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols, size_t col_stride,
+                                         size_t nv, zigz_commit_job **out) {
+    if (!ctx || !cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const size_t N = (size_t)1 << nv;
+    if (col_stride < N) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;
+    const size_t dstride = N < 4 ? 4 : N;
+    void *d;
+    CHK(ws_get(ctx, WS_COLS, ncols * dstride * 4, &d));
+    uint32_t *d_cols = (uint32_t *)d;
+    if (col_stride == N && dstride == N) {
+        CHK(upload_u64(ctx, cols, ncols * N, d_cols, false));
+    } else {
+        for (size_t c = 0; c < ncols; c++) CHK(upload_u64(ctx, cols + c * col_stride, N, d_cols + c * dstride, false));
+    }
+    return job_begin(ctx, d_cols, ncols, dstride, nv, out);
+}
+
+extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
+    if (!job || !roots) return ZIGZ_ERR_INVALID_ARGUMENT;
+    zigz_ctx *ctx = job->ctx;
+    if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
+    HIPCHK(ctx, hipEventSynchronize(job->built));
+    memcpy(roots, ctx->h_pin, job->ncols * 32);
+    if (ctx->timing) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
+        ctx->stats.merkle_build_us = (double)ms * 1000.0;
+    }
+    job->state = 1;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, uint64_t *values,
+                                            uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs) {
+    if (!job || !values || !indices || !leaves) return ZIGZ_ERR_INVALID_ARGUMENT;
+    zigz_ctx *ctx = job->ctx;
+    if (job->state != 1) return ZIGZ_ERR_BAD_STATE;
+    const size_t nv = job->nv, ncols = job->ncols;
+    if (nv && (!points || !siblings || !dirs)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    void *dv;
+    CHK(ws_get(ctx, WS_SCRATCH, ncols * 4 + 64, &dv));
+    CHK(timed_begin(ctx, 4));
+    CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, (uint32_t *)dv));
+    CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
+    std::vector<uint32_t> hv(ncols);
+    HIPCHK(ctx, hipMemcpyAsync(hv.data(), dv, ncols * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint64_t> idx(ncols);
+    for (size_t c = 0; c < ncols; c++) {
+        idx[c] = nv == 0 ? 0 : points[c * nv] % ((uint64_t)1 << nv);  // pointToIndex
+        indices[c] = idx[c];
+    }
+    CHK(open_paths(ctx, job->d_tree, job->N, (unsigned)nv, job->d_cols, job->col_stride, idx.data(), ncols, siblings,
+                   dirs, leaves));
+    for (size_t c = 0; c < ncols; c++) values[c] = hv[c];
+    job->state = 2;
+    return ZIGZ_OK;
+}
+
+extern "C" void zigz_commit_end(zigz_commit_job *job) {
+    if (!job) return;
+    zigz_ctx *ctx = job->ctx;
+    (void)hipStreamSynchronize(ctx->stream);
+    if (job->built) (void)hipEventDestroy(job->built);
+    if (ctx->active_job == job) ctx->active_job = nullptr;
+    delete job;
+}
+
+// ------------------------------------------------------------------ Lasso (simplified), lasso_prover.zig:103-252
+static void flat_commit(const uint32_t *ev, size_t n, uint8_t out[32]) {  // commitToPolynomial, :242-252 (K10, host)
+    Sha3_256 h;
+    for (size_t i = 0; i < n; i++) h.update_le64(ev[i]);
+    h.finalize(out);
+}
+
+extern "C" zigz_status zigz_lasso_fingerprints(zigz_ctx *ctx, const uint64_t *rows_in, size_t rows, size_t width,
+                                               uint64_t *out) {
+    if (!ctx || !rows_in || !out || width == 0) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (rows == 0) return ZIGZ_OK;
+    uint32_t *d_rows;
+    CHK(stage_in(ctx, rows_in, rows * width, &d_rows));
+    void *d_o;
+    CHK(ws_get(ctx, WS_OUT32, rows * 4, &d_o));
+    launch_lasso_fingerprints(d_rows, rows, width, (uint32_t *)d_o, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return download_u64(ctx, (uint32_t *)d_o, rows, out);
+}
+
+extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, size_t table_rows, const uint64_t *queries,
+                                        size_t n_queries, size_t n_in, size_t n_out, size_t *nv_out, uint64_t *rounds,
+                                        uint64_t *point, uint64_t *final_eval, uint8_t query_commitment[32],
+                                        uint8_t table_commitment[32]) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_queries == 0) return ZIGZ_ERR_NO_QUERIES;  // :108-110
+    const size_t w = n_in + n_out;
+    if (!table || !queries || w == 0 || !nv_out || !final_eval || !query_commitment || !table_commitment)
+        return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(table_rows));  // Multilinear.init(table_evals), :124
+    if (n_queries > ((size_t)1 << 40)) return ZIGZ_ERR_TOO_MANY_QUERIES;
+    const size_t padded = ceil_pow2(n_queries);  // :131
+    // fingerprints of table rows and queries (K9)
+    void *d_fp;
+    CHK(ws_get(ctx, WS_LASSO, (table_rows + padded) * 4, &d_fp));
+    uint32_t *d_tev = (uint32_t *)d_fp, *d_qev = d_tev + table_rows;
+    uint32_t *d_rows;
+    CHK(stage_in(ctx, table, table_rows * w, &d_rows));
+    launch_lasso_fingerprints(d_rows, table_rows, w, d_tev, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    CHK(stage_in(ctx, queries, n_queries * w, &d_rows));
+    HIPCHK(ctx, hipMemsetAsync(d_qev, 0, padded * 4, ctx->stream));  // zero-pad, :139-142
+    launch_lasso_fingerprints(d_rows, n_queries, w, d_qev, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    *nv_out = log2_floor(padded);
+    if (padded == 1) return ZIGZ_ERR_NO_VARIABLES;  // SumcheckProver.prove on a 0-variable poly, :160
+    if (!rounds || !point) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(sumcheck_core(ctx, d_qev, padded, nullptr, nullptr, rounds, point, final_eval));
+    std::vector<uint32_t> hq(padded), ht(table_rows);
+    HIPCHK(ctx, hipMemcpyAsync(hq.data(), d_qev, padded * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipMemcpyAsync(ht.data(), d_tev, table_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    flat_commit(hq.data(), padded, query_commitment);
+    flat_commit(ht.data(), table_rows, table_commitment);
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64_t *table, size_t table_rows,
+                                                     const uint64_t *queries, size_t n_queries, size_t n_in,
+                                                     size_t n_out, const uint64_t *mapping, size_t n_mapping,
+                                                     size_t *nv_out, uint64_t *rounds, uint64_t *point,
+                                                     uint64_t *final_eval, uint8_t query_commitment[32],
+                                                     uint8_t table_commitment[32]) {
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_queries != n_mapping) return ZIGZ_ERR_MAPPING_LENGTH_MISMATCH;  // :185-187
+    const size_t w = n_in + n_out;
+    if (n_queries && (!table || !queries || !mapping)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    for (size_t j = 0; j < n_queries; j++) {  // O(Q*w) host-side equality scan of caller data, :190-201
+        if (mapping[j] >= table_rows) return ZIGZ_ERR_INVALID_MAPPING;
+        if (memcmp(queries + j * w, table + mapping[j] * w, w * sizeof(uint64_t)) != 0)
+            return ZIGZ_ERR_QUERY_TABLE_MISMATCH;
+    }
+    return zigz_lasso_prove(ctx, table, table_rows, queries, n_queries, n_in, n_out, nv_out, rounds, point, final_eval,
+                            query_commitment, table_commitment);
+}
+
+// ------------------------------------------------------------------ host transcript
+struct zigz_transcript {
+    Transcript t;
+};
+extern "C" zigz_transcript *zigz_transcript_new(void) { return new (std::nothrow) zigz_transcript(); }
+extern "C" void zigz_transcript_free(zigz_transcript *t) { delete t; }
+extern "C" void zigz_transcript_append_bytes(zigz_transcript *t, const uint8_t *data, size_t len) {
+    if (t && (data || !len)) t->t.append_bytes(data, len);
+}
+extern "C" void zigz_transcript_append_field(zigz_transcript *t, uint64_t v) {
+    if (t) t->t.append_field(v);
+}
+extern "C" void zigz_transcript_append_tagged_counter(zigz_transcript *t, const uint8_t *tag, size_t tag_len,
+                                                      uint64_t start, uint64_t count) {
+    if (t) t->t.append_tagged_counter(tag, tag_len, start, count);
+}
+extern "C" uint64_t zigz_transcript_challenge(zigz_transcript *t) { return t ? t->t.challenge() : 0; }
+extern "C" void zigz_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]) { sha3_256(data, len, out); }
+extern "C" void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]) { sha256(data, len, out); }

@@ -1,0 +1,40 @@
+// Host-side sequential hashing that stays on the CPU by construction:
+// the SHA3-256 Fiat-Shamir sponge (src/core/hash.zig:255-324), flat SHA3 commitments
+// (src/lookups/lasso_prover.zig:242-252) and the SHA-256 program binding (src/prover/prover.zig:98-100).
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zk {
+
+class Sha3_256 {
+  public:
+    Sha3_256() { reset(); }
+    void reset();
+    void update(const uint8_t *data, size_t len);
+    void update_le64(uint64_t v);
+    // finalises a COPY (the object stays usable), as hash.zig:305-306 does
+    void digest_copy(uint8_t out[32]) const;
+    void finalize(uint8_t out[32]);
+
+  private:
+    uint64_t st_[25];
+    size_t pos_;  // bytes absorbed into the current 136-byte block
+};
+
+// FiatShamirTranscript over BabyBear
+class Transcript {
+  public:
+    void append_bytes(const uint8_t *d, size_t n) { h_.update(d, n); }
+    void append_field(uint64_t canonical) { h_.update_le64(canonical); }
+    uint64_t challenge();  // hash.zig:301-316
+    void append_tagged_counter(const uint8_t *tag, size_t tag_len, uint64_t start, uint64_t count);
+
+  private:
+    Sha3_256 h_;
+};
+
+void sha3_256(const uint8_t *data, size_t len, uint8_t out[32]);
+void sha256(const uint8_t *data, size_t len, uint8_t out[32]);
+
+}  // namespace zk

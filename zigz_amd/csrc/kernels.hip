@@ -1,0 +1,373 @@
+// Hand-written gfx950 (CDNA4, wave64) kernels for the zigz hot path.  See kernels.hpp for the launch
+// interface and DESIGN.md for the per-kernel roofline accounting.
+//
+//  K1/K2  k_bind_vec / k_bind_small   MLE bind (+ fused next-round half sums)   HBM-bound, 6 B/output-pair
+//  K2/K3  k_half_sums_vec / _small    round-polynomial half sums                HBM-bound, 4 B/element
+//  K5     k_keccak_leaves             SHA3-256 leaf hashes                      int-VALU bound
+//  K6     k_keccak_level / _top       SHA3-256 level merges                     int-VALU bound
+//  K7     k_paths                     authentication-path gather               latency
+//  K9     k_lasso_fingerprints        XXH3-64 row fingerprints                  int-VALU bound
+#include "kernels.hpp"
+
+#include "field.hpp"
+#include "keccak.hpp"
+
+namespace zk {
+
+constexpr int TPB = 256;      // 4 waves per workgroup
+constexpr int UNROLL = 4;     // 16-byte chunks per thread per tile: 8 x 16 B loads in flight
+constexpr size_t VEC_MIN_HALF = 4096;  // vector path needs half % (4*TPB*UNROLL) == 0
+
+// ------------------------------------------------------------------ reductions
+__device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;
+}
+
+// Adds the block's (s0, s1) into sums[0], sums[1]: wave shuffle -> LDS -> one atomic pair per block.
+__device__ __forceinline__ void block_add2(unsigned long long s0, unsigned long long s1,
+                                           unsigned long long *sums) {
+    __shared__ unsigned long long lds[2][TPB / 64];
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) {
+        lds[0][wave] = s0;
+        lds[1][wave] = s1;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t0 = 0, t1 = 0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; w++) {
+            t0 += lds[0][w];
+            t1 += lds[1][w];
+        }
+        if (t0) atomicAdd(&sums[0], t0);
+        if (t1) atomicAdd(&sums[1], t1);
+    }
+}
+
+// ------------------------------------------------------------------ K1 (+K2): MLE bind
+// One tile = TPB*UNROLL uint4 chunks of outputs.  Loads are 16 B/lane, fully coalesced (1 KiB per
+// wave instruction); 2*UNROLL independent loads are issued before the first use.
+template <bool SUMS>
+__global__ __launch_bounds__(TPB) void k_bind_vec(const uint32_t *__restrict__ in, size_t in_stride,
+                                                  uint32_t *__restrict__ out, size_t out_stride, size_t half,
+                                                  uint32_t r_m_scalar, const uint32_t *__restrict__ d_r_m,
+                                                  unsigned long long *__restrict__ sums) {
+    const size_t col = blockIdx.y;
+    const uint32_t r_m = d_r_m ? d_r_m[col] : r_m_scalar;
+    const uint4 *lo = reinterpret_cast<const uint4 *>(in + col * in_stride);
+    const uint4 *hi = lo + half / 4;
+    uint4 *o = reinterpret_cast<uint4 *>(out + col * out_stride);
+    const size_t base = (size_t)blockIdx.x * (TPB * UNROLL) + threadIdx.x;
+
+    uint4 a[UNROLL], b[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        a[u] = lo[base + (size_t)u * TPB];
+        b[u] = hi[base + (size_t)u * TPB];
+    }
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        uint4 r;
+        r.x = bind1(a[u].x, b[u].x, r_m);
+        r.y = bind1(a[u].y, b[u].y, r_m);
+        r.z = bind1(a[u].z, b[u].z, r_m);
+        r.w = bind1(a[u].w, b[u].w, r_m);
+        o[base + (size_t)u * TPB] = r;
+        if (SUMS) acc += (unsigned long long)r.x + r.y + r.z + r.w;
+    }
+    if (SUMS) {
+        // a tile never straddles the middle of the output (tiles are 4096 outputs, half/2 % 4096 == 0
+        // on this path), so the whole block adds to one of the two sums.
+        const bool upper = (size_t)blockIdx.x * (TPB * UNROLL * 4) >= half / 2;
+        block_add2(upper ? 0 : acc, upper ? acc : 0, sums + 2 * col);
+    }
+}
+
+// Small tables (half < 8192 with sums / < 4096 without): one workgroup per column, scalar accesses.
+template <bool SUMS>
+__global__ __launch_bounds__(TPB) void k_bind_small(const uint32_t *__restrict__ in, size_t in_stride,
+                                                    uint32_t *__restrict__ out, size_t out_stride, size_t half,
+                                                    uint32_t r_m_scalar, const uint32_t *__restrict__ d_r_m,
+                                                    unsigned long long *__restrict__ sums) {
+    const size_t col = blockIdx.y;
+    const uint32_t r_m = d_r_m ? d_r_m[col] : r_m_scalar;
+    const uint32_t *p = in + col * in_stride;
+    uint32_t *o = out + col * out_stride;
+    unsigned long long s0 = 0, s1 = 0;
+    for (size_t i = threadIdx.x; i < half; i += TPB) {
+        uint32_t v = bind1(p[i], p[i + half], r_m);
+        o[i] = v;
+        if (SUMS) {
+            if (half == 1 || i < half / 2) s0 += v;
+            else s1 += v;
+        }
+    }
+    if (SUMS) block_add2(s0, s1, sums + 2 * col);
+}
+
+void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s) {
+    if (half == 0 || ncols == 0) return;
+    const bool vec = half >= (d_sums ? 2 * VEC_MIN_HALF : VEC_MIN_HALF) && (in_stride % 4 == 0) &&
+                     (out_stride % 4 == 0);
+    if (vec) {
+        dim3 grid((unsigned)(half / (4 * TPB * UNROLL)), (unsigned)ncols);
+        if (d_sums)
+            hipLaunchKernelGGL(k_bind_vec<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
+                               r_m, d_r_m, d_sums);
+        else
+            hipLaunchKernelGGL(k_bind_vec<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
+                               r_m, d_r_m, d_sums);
+    } else {
+        dim3 grid(1, (unsigned)ncols);
+        if (d_sums)
+            hipLaunchKernelGGL(k_bind_small<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
+                               r_m, d_r_m, d_sums);
+        else
+            hipLaunchKernelGGL(k_bind_small<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride,
+                               half, r_m, d_r_m, d_sums);
+    }
+}
+
+// ------------------------------------------------------------------ K2/K3: half sums
+__global__ __launch_bounds__(TPB) void k_half_sums_vec(const uint32_t *__restrict__ in, size_t in_stride, size_t n,
+                                                       unsigned long long *__restrict__ sums) {
+    const size_t col = blockIdx.y;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride);
+    const size_t base = (size_t)blockIdx.x * (TPB * UNROLL) + threadIdx.x;
+    uint4 a[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) a[u] = p[base + (size_t)u * TPB];
+    unsigned long long acc = 0;
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) acc += (unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w;
+    const bool upper = (size_t)blockIdx.x * (TPB * UNROLL * 4) >= n / 2;
+    block_add2(upper ? 0 : acc, upper ? acc : 0, sums + 2 * col);
+}
+
+__global__ __launch_bounds__(TPB) void k_half_sums_small(const uint32_t *__restrict__ in, size_t in_stride, size_t n,
+                                                         unsigned long long *__restrict__ sums) {
+    const size_t col = blockIdx.y;
+    const uint32_t *p = in + col * in_stride;
+    unsigned long long s0 = 0, s1 = 0;
+    for (size_t i = threadIdx.x; i < n; i += TPB) {
+        if (n == 1 || i < n / 2) s0 += p[i];
+        else s1 += p[i];
+    }
+    block_add2(s0, s1, sums + 2 * col);
+}
+
+void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols, unsigned long long *d_sums,
+                      hipStream_t s) {
+    if (n == 0 || ncols == 0) return;
+    if (n >= 2 * (size_t)(4 * TPB * UNROLL) && in_stride % 4 == 0) {
+        dim3 grid((unsigned)(n / (4 * TPB * UNROLL)), (unsigned)ncols);
+        hipLaunchKernelGGL(k_half_sums_vec, grid, dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
+    } else {
+        hipLaunchKernelGGL(k_half_sums_small, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
+    }
+}
+
+// ------------------------------------------------------------------ layout conversion at the boundary
+__global__ __launch_bounds__(TPB) void k_narrow_u64(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    size_t n, uint32_t *flag) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * TPB;
+    uint32_t bad = 0;
+    for (; i < n; i += step) {
+        uint64_t v = in[i];
+        bad |= (v >= (uint64_t)P) ? 1u : 0u;
+        out[i] = (uint32_t)v;
+    }
+    if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
+__global__ __launch_bounds__(TPB) void k_reduce_u64(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
+                                                    size_t n) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * TPB;
+    for (; i < n; i += step) out[i] = (uint32_t)(in[i] % (uint64_t)P);
+}
+
+__global__ __launch_bounds__(TPB) void k_widen_u32(const uint32_t *__restrict__ in, uint64_t *__restrict__ out,
+                                                   size_t n) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * TPB;
+    for (; i < n; i += step) out[i] = in[i];
+}
+
+static unsigned stream_grid(size_t n) {
+    size_t b = (n + TPB - 1) / TPB;
+    return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));
+}
+
+void launch_narrow_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, uint32_t *d_flag, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_narrow_u64, dim3(stream_grid(n)), dim3(TPB), 0, s, d_in, d_out, n, d_flag);
+}
+void launch_reduce_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_reduce_u64, dim3(stream_grid(n)), dim3(TPB), 0, s, d_in, d_out, n);
+}
+void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_widen_u32, dim3(stream_grid(n)), dim3(TPB), 0, s, d_in, d_out, n);
+}
+
+// ------------------------------------------------------------------ K5/K6: Keccak Merkle
+__device__ __forceinline__ void store_digest(uint8_t *tree, size_t node, const Digest &d) {
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(tree + node * 32);
+    q[0] = make_ulonglong2(d.w[0], d.w[1]);
+    q[1] = make_ulonglong2(d.w[2], d.w[3]);
+}
+__device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(tree + node * 32);
+    ulonglong2 x = q[0], y = q[1];
+    return Digest{{x.x, x.y, y.x, y.y}};
+}
+
+__global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
+                                                       size_t n_values, size_t npad, uint8_t *__restrict__ tree,
+                                                       size_t tree_stride_nodes) {
+    const size_t col = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= npad) return;
+    const uint64_t v = i < n_values ? vals[col * val_stride + i] : 0;  // pad with hashLeaf(0), merkle_tree.zig:302-306
+    store_digest(tree + col * tree_stride_nodes * 32, i, sha3_leaf(v));
+}
+
+__global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
+                                                      size_t in_off, size_t out_off, size_t n_out) {
+    const size_t col = blockIdx.y;
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_out) return;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
+    store_digest(t, out_off + i, sha3_node(l, r));
+}
+
+// Finishes a tree from a level of at most 2*TPB nodes up to the root in ONE launch (one workgroup
+// per column; levels hand over through global memory + workgroup barrier on the same CU).
+__global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
+                                                    unsigned first_level /*level of the input nodes*/,
+                                                    unsigned height) {
+    const size_t col = blockIdx.y;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    for (unsigned l = first_level; l < height; l++) {
+        const size_t n_out = npad >> (l + 1);
+        const size_t in_off = 2 * npad - 2 * (npad >> l), out_off = 2 * npad - 2 * (npad >> (l + 1));
+        if (threadIdx.x < n_out) {
+            Digest a = load_digest(t, in_off + 2 * threadIdx.x), b = load_digest(t, in_off + 2 * threadIdx.x + 1);
+            store_digest(t, out_off + threadIdx.x, sha3_node(a, b));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
+void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                          size_t tree_stride_nodes, size_t ncols, hipStream_t s) {
+    dim3 grid((unsigned)((npad + TPB - 1) / TPB), (unsigned)ncols);
+    hipLaunchKernelGGL(k_keccak_leaves, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                       tree_stride_nodes);
+}
+
+void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
+                         size_t ncols, hipStream_t s) {
+    dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
+    hipLaunchKernelGGL(k_keccak_level, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+}
+
+void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
+                       size_t ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_keccak_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad,
+                       first_level, height);
+}
+
+// ------------------------------------------------------------------ K7: authentication paths
+__global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
+                                              unsigned height, const uint32_t *__restrict__ vals, size_t val_stride,
+                                              const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
+                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf) {
+    const size_t col = blockIdx.x;
+    const size_t index = idx[col];
+    const unsigned l = threadIdx.x;
+    if (l == 0) leaf[col] = vals[col * val_stride + index];
+    if (l >= height) return;
+    const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
+    const uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const size_t off = 2 * npad - 2 * (npad >> l);
+    Digest d = load_digest(t, off + (ci ^ 1));
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
+    q[0] = make_ulonglong2(d.w[0], d.w[1]);
+    q[1] = make_ulonglong2(d.w[2], d.w[3]);
+    dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
+}
+
+void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
+                  const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs,
+                  uint32_t *d_leaf, size_t ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, height, d_vals,
+                       val_stride, d_idx, d_sib, d_dirs, d_leaf);
+}
+
+__global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t node,
+                               uint8_t *__restrict__ out, size_t ncols) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= ncols) return;
+    Digest d = load_digest(tree + c * tree_stride_nodes * 32, node);
+    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + c * 32);
+    q[0] = make_ulonglong2(d.w[0], d.w[1]);
+    q[1] = make_ulonglong2(d.w[2], d.w[3]);
+}
+void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
+                         hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_nodes, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, d_tree, tree_stride_nodes, node,
+                       d_out, ncols);
+}
+
+__global__ void k_gather_first(const uint32_t *__restrict__ in, size_t stride, uint32_t *__restrict__ out,
+                               size_t ncols) {
+    size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncols) out[c] = in[c * stride];
+}
+void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_gather_first, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, d_in, stride, d_out, ncols);
+}
+
+// ------------------------------------------------------------------ K9: Lasso fingerprints
+// XXH3-64 (seed 0) of exactly 8 input bytes = the published 4..8-byte branch (XXH3_len_4to8_64b):
+// std.hash.XxHash3.hash(0, asBytes(&h)) in src/lookups/lasso_prover.zig:213.
+__device__ __forceinline__ uint64_t xxh3_64_of_u64(uint64_t h) {
+    const uint64_t bitflip = 0x1cad21f72c81017cull ^ 0xdb979083e96dd4deull;  // kSecret[8..16) ^ kSecret[16..24)
+    uint64_t in64 = (h >> 32) + (h << 32);  // input2 + (input1 << 32)
+    uint64_t k = in64 ^ bitflip;
+    k ^= rotl64(k, 49) ^ rotl64(k, 24);
+    k *= 0x9FB21C651E98DF25ull;
+    k ^= (k >> 35) + 8;
+    k *= 0x9FB21C651E98DF25ull;
+    return k ^ (k >> 28);
+}
+
+__global__ __launch_bounds__(TPB) void k_lasso_fingerprints(const uint32_t *__restrict__ rows, size_t n_rows,
+                                                            size_t width, uint32_t *__restrict__ out) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n_rows) return;
+    uint64_t h = 0;
+    for (size_t f = 0; f < width; f++) {
+        h ^= rows[i * width + f];
+        h = xxh3_64_of_u64(h);
+    }
+    out[i] = (uint32_t)(h % (uint64_t)P);
+}
+
+void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s) {
+    if (rows)
+        hipLaunchKernelGGL(k_lasso_fingerprints, dim3((unsigned)((rows + TPB - 1) / TPB)), dim3(TPB), 0, s, d_rows,
+                           rows, width, d_out);
+}
+
+}  // namespace zk

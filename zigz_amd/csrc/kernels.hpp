@@ -1,0 +1,53 @@
+// Launch interface of the gfx950 kernels (kernels.hip).  All pointers are device pointers; tables
+// are packed u32 canonical BabyBear elements; every launch is asynchronous on `stream`.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace zk {
+
+// Merkle tree of one column kept in HBM: levels bottom-up, level l (N>>l nodes of 32 B) starts at
+// node offset 2N - 2*(N>>l); root at node 2N-2.  Column stride = 2N nodes.
+inline size_t tree_level_offset(size_t npad, unsigned level) { return 2 * npad - 2 * (npad >> level); }
+inline size_t tree_nodes(size_t npad) { return 2 * npad; }
+
+// u64 host image (already on device) -> packed u32; flag[0] |= 1 when some value >= p.
+void launch_narrow_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, uint32_t *d_flag, hipStream_t s);
+// d_out[i] = d_in[i] mod p  (F.init on raw 64-bit words, src/core/field.zig:36-38)
+void launch_reduce_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, hipStream_t s);
+void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream_t s);
+
+// K1 (+K2 fused): batched MLE bind.  For column c in [0,ncols):
+//   out[c*out_stride + i] = in[c*in_stride + i] + r_c * (in[c*in_stride + i + half] - in[...+ i]),  i < half
+// r_c (Montgomery form) = d_r_m ? d_r_m[c] : r_m.  If d_sums: sums[2c] += sum of out[0..half/2),
+// sums[2c+1] += sum of out[half/2..half)  (exact u64 sums; must be zeroed by the caller).
+void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s);
+// K2/K3: sums[2c] += sum in[0..n/2), sums[2c+1] += sum in[n/2..n)   (n >= 2); n == 1: sums[2c] += in[0]
+void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols,
+                      unsigned long long *d_sums, hipStream_t s);
+
+// K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
+void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
+                          uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s);
+// K6: one level.  out node i = SHA3(in node 2i || in node 2i+1), i < n_out  (node offsets per column)
+void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
+                         size_t ncols, hipStream_t s);
+// K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
+void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
+                       size_t ncols, hipStream_t s);
+// K7: authentication paths.  For column c: index d_idx[c]; siblings -> d_sib[c][l][32], dirs -> d_dirs[c][l],
+// leaf value -> d_leaf[c].
+void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
+                  const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib,
+                  uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s);
+// copies node `node` of every column's tree into d_out[c][32]
+void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
+                         hipStream_t s);
+// gather element 0 of each column of a strided table
+void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s);
+// K9: Lasso fingerprints (src/lookups/lasso_prover.zig:208-239): rows x width canonical u32 -> u32
+void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s);
+
+}  // namespace zk
