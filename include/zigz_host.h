@@ -1,0 +1,69 @@
+/*
+ * zigz_host.h -- C face of libzigz_host.so, the C++ mirror of the Zig host (zigz_amd/csrc/host/).
+ *
+ * NOT the drop-in boundary (that is zigz_hip.h): this exists so that tests, bench.py and
+ * __graft_entry__ can drive the host mirror -- Prover.prove / Verifier.verify / BinarySerializer /
+ * VMState / WitnessGenerator / SumcheckProver / LassoProver with the reference's semantics -- from
+ * Python through ctypes.  Status codes: zigz_status values (zigz_hip.h) plus the host-only codes
+ * 19..31 (VM and serializer errors, same numbering as the oracle).  zigzh_last_error() returns the
+ * Zig-style error name of the last failure on the calling thread.
+ */
+#ifndef ZIGZ_HOST_H
+#define ZIGZ_HOST_H
+#include "zigz_hip.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct zigzh_trace zigzh_trace; /* an executed program: packed trace rows + public IO */
+
+const char *zigzh_last_error(void);
+void zigzh_free(void *p);
+
+/* Prover(F).prove(program, entry_pc, initial_regs, max_steps, null, input) + BinarySerializer.serialize
+ * src/prover/prover.zig:73-226, src/prover/serialization.zig:70-97 */
+int zigzh_prove(zigz_ctx *ctx, const uint8_t *program, size_t program_len, uint64_t entry_pc,
+                const uint64_t *initial_regs, size_t n_initial_regs, int has_initial_regs, size_t max_steps,
+                const uint64_t *input, size_t n_input, uint8_t **proof_out, size_t *proof_len, size_t *num_steps);
+/* BinarySerializer.deserialize + Verifier.verify   src/verifier/verifier.zig:49-91; result = VerificationResult */
+int zigzh_verify(const uint8_t *proof, size_t proof_len, const uint8_t *program, size_t program_len, int *result);
+/* deserialize then serialize again (round-trip, tests/integration_tests.zig:90-127) */
+int zigzh_reserialize(const uint8_t *proof, size_t proof_len, uint8_t **out, size_t *out_len);
+
+/* [1/6] of Prover.prove: run the VM exactly as prover.zig:117-142 does */
+int zigzh_execute(const uint8_t *program, size_t program_len, uint64_t entry_pc, const uint64_t *initial_regs,
+                  size_t n_initial_regs, int has_initial_regs, size_t max_steps, const uint64_t *input, size_t n_input,
+                  zigzh_trace **out);
+void zigzh_trace_free(zigzh_trace *t);
+size_t zigzh_trace_num_steps(const zigzh_trace *t);
+size_t zigzh_trace_num_vars(const zigzh_trace *t);
+size_t zigzh_trace_num_lookups(const zigzh_trace *t);
+const uint64_t *zigzh_trace_rows(const zigzh_trace *t); /* [num_steps][43] raw u64 */
+/* WitnessGenerator.generate -> 43 columns of 2^nv canonical u64, column-major   witness.zig:29-61 */
+int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out);
+/* builds the 43 witness columns directly in HBM (packed u32, column stride `stride` elements) */
+int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride);
+/* steps [4/6]..[6/6] + packagePublicIO for an executed trace; d_cols == NULL: host witness is generated and
+ * uploaded; otherwise the resident columns are used.  want_bytes: also serialize ("ZIGZ" v1). */
+int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int want_bytes,
+                      uint8_t **proof_out, size_t *proof_len);
+
+/* VMState.init + run(max_steps)   src/vm/state.zig:72-93,172-184 (VM known-answer tests) */
+int zigzh_vm_run(const uint8_t *program, size_t program_len, uint64_t entry_pc, size_t max_steps,
+                 uint64_t final_regs[32], uint64_t *final_pc, size_t *steps);
+
+/* Multilinear.init + SumcheckProver.prove + SumcheckProof.toBytes through the C++ mirror classes */
+int zigzh_sumcheck_prove_bytes(zigz_ctx *ctx, const uint64_t *evals, size_t n, uint8_t *out /*(3v+2)*8*/, size_t *out_len);
+/* build{Add,Xor,And}Table(bits) + LassoProver.prove / proveWithMapping (mapping may be NULL)
+ * queries: n_queries rows of 3 fields.  out: sumcheck toBytes, then the two 32-byte commitments */
+int zigzh_lasso_prove_table(zigz_ctx *ctx, int kind, size_t bits, const uint64_t *queries, size_t n_queries,
+                            const uint64_t *mapping, size_t n_mapping, uint8_t *sumcheck_bytes, size_t *sumcheck_len,
+                            uint8_t query_commitment[32], uint8_t table_commitment[32], size_t *num_lookups);
+/* Multilinear + CommitmentScheme.commit/open/verify through the mirror classes; returns verify() result in *ok */
+int zigzh_commit_open_verify(zigz_ctx *ctx, const uint64_t *evals, size_t n, const uint64_t *point, size_t npoint,
+                             uint8_t root[32], uint64_t *value, uint64_t *index, int *ok);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,69 @@
+"""Hand-assembled RV64IM test programs (synthetic traces for the BASELINE configs)."""
+import struct
+
+
+def _I(op, rd, f3, rs1, imm): return ((imm & 0xfff) << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op
+def _R(op, rd, f3, rs1, rs2, f7): return (f7 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op
+def _S(f3, rs1, rs2, imm): return (((imm >> 5) & 0x7f) << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | ((imm & 31) << 7) | 0x23
+def _U(op, rd, imm20): return ((imm20 & 0xfffff) << 12) | (rd << 7) | op
+
+
+def _B(f3, rs1, rs2, off):
+    o = off & 0x1fff
+    return ((((o >> 12) & 1) << 31) | (((o >> 5) & 0x3f) << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) |
+            (((o >> 1) & 0xf) << 8) | (((o >> 11) & 1) << 7) | 0x63)
+
+
+def _pack(words): return b"".join(struct.pack("<I", w) for w in words)
+
+
+def _li(rd, value):
+    """LUI+ADDI load of a 32-bit positive constant (value < 2^31)."""
+    hi = (value + 0x800) >> 12
+    lo = value - (hi << 12)
+    return [_U(0x37, rd, hi), _I(0x13, rd, 0, rd, lo)]
+
+
+def add_xor_loop(iterations):
+    """ADDI x1,x0,1; loop: ADD x2,x2,x1; XOR x3,x3,x2; ADDI x4,x4,1; BNE x4,x5,loop.
+    num_steps = 3 + 4*iterations (2 LI words + ADDI + 4/iter), every step is a lookup step except LUI."""
+    w = _li(5, iterations) + [_I(0x13, 1, 0, 0, 1)]
+    w += [_R(0x33, 2, 0, 2, 1, 0), _R(0x33, 3, 4, 3, 2, 0), _I(0x13, 4, 0, 4, 1), _B(1, 4, 5, -12)]
+    return _pack(w)
+
+
+def mixed_loop(iterations):
+    """RV64IM mix -- ADD/XOR/MUL/DIVU/REM, SD/LD, ADDIW, branch. 12 steps per iteration."""
+    w = _li(5, iterations) + [_I(0x13, 1, 0, 0, 3), _I(0x13, 6, 0, 0, 7), _I(0x13, 8, 0, 0, 0x100)]
+    body = [
+        _R(0x33, 2, 0, 2, 1, 0),      # ADD  x2,x2,x1
+        _R(0x33, 3, 4, 3, 2, 0),      # XOR  x3,x3,x2
+        _R(0x33, 7, 0, 2, 6, 1),      # MUL  x7,x2,x6
+        _R(0x33, 9, 5, 7, 1, 1),      # DIVU x9,x7,x1
+        _R(0x33, 10, 6, 7, 6, 1),     # REM  x10,x7,x6
+        _S(3, 8, 7, 0),               # SD   x7,0(x8)
+        _I(0x03, 11, 3, 8, 0),        # LD   x11,0(x8)
+        _I(0x1b, 12, 0, 11, 5),       # ADDIW x12,x11,5
+        _R(0x3b, 13, 0, 12, 3, 0),    # ADDW x13,x12,x3
+        _I(0x13, 1, 0, 1, 2),         # ADDI x1,x1,2
+        _I(0x13, 4, 0, 4, 1),         # ADDI x4,x4,1
+    ]
+    w += body + [_B(1, 4, 5, -4 * len(body))]
+    return _pack(w)
+
+
+def fibonacci(n):
+    """examples/fibonacci_guest semantics -- ECALL read n; loop; 2x ECALL commit; EBREAK.
+    Returns (program, input_tape).  num_steps = 6 + 5*n + 6."""
+    w = [
+        _I(0x13, 17, 0, 0, 2), 0x00000073,       # a7=2; ECALL read -> a0
+        _I(0x13, 5, 0, 10, 0),                   # t0 = n
+        _I(0x13, 6, 0, 0, 0), _I(0x13, 7, 0, 0, 1), _I(0x13, 28, 0, 0, 0),  # a=0, b=1, i=0
+        _R(0x33, 29, 0, 6, 7, 0),                # loop: t4 = a+b
+        _I(0x13, 6, 0, 7, 0), _I(0x13, 7, 0, 29, 0),   # a=b; b=t4
+        _I(0x13, 28, 0, 28, 1), _B(1, 28, 5, -16),     # i++; BNE i,n,loop
+        _I(0x13, 17, 0, 0, 1), _I(0x13, 10, 0, 6, 0), 0x00000073,  # a7=1; a0=a; ECALL commit
+        _I(0x13, 10, 0, 28, 0), 0x00000073,      # a0=i; ECALL commit
+        0x00100073,                              # EBREAK
+    ]
+    return _pack(w), [n]

@@ -1,0 +1,153 @@
+"""GPU end-to-end tests (-m gpu): Prover.prove through the C++ host mirror + HIP backend must emit
+proofs byte-identical to the oracle's (and to the committed golden proofs); Verifier.verify accepts."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+import programs
+
+pytestmark = pytest.mark.gpu
+P = O.P_BB
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import zigz_amd
+    c = zigz_amd.Context(0)
+    yield c
+    c.close()
+
+
+def ints(xs):
+    return None if xs is None else [int(x) for x in xs]
+
+
+@pytest.mark.parametrize("i", range(len(G["prove"])))
+def test_prove_golden_bytes(ctx, i):
+    from zigz_amd import host
+    e = G["prove"][i]
+    prog = bytes.fromhex(e["program"])
+    proof, ns = host.prove(ctx, prog, e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"]))
+    assert ns == e["num_steps"] and len(proof) == e["proof_len"]
+    assert hashlib.sha3_256(proof).hexdigest() == e["proof_sha3"]
+    if "proof" in e:
+        assert proof.hex() == e["proof"]
+    oproof, _ = O.prove(P, prog, e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"]))
+    assert proof == oproof
+    assert host.verify(proof, prog) == "Accept" and O.verify(P, proof, prog) == (0, 0)
+    # same proof from device-resident witness columns
+    t = host.Trace(prog, e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"]))
+    N = 1 << t.num_vars
+    stride = max(N, 4)
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        t.witness_to_device(ctx, d, stride)
+        assert t.prove(ctx, d, stride) == proof
+        assert t.prove(ctx) == proof
+    finally:
+        ctx.dev_free(d)
+
+
+def test_prove_errors(ctx):
+    import zigz_amd
+    from zigz_amd import host
+    with pytest.raises(zigz_amd.ZigzError) as e:
+        host.prove(ctx, b"\0\0\0\0")
+    assert e.value.name == "EmptyTrace"
+    with pytest.raises(zigz_amd.ZigzError) as e:  # CSRRW: UnimplementedSYSTEM propagates out of prove
+        host.prove(ctx, (0x00001073).to_bytes(4, "little"))
+    assert e.value.name == "UnimplementedSYSTEM"
+
+
+@pytest.mark.parametrize("maker,arg", [("fibonacci", 50), ("add_xor_loop", 300), ("mixed_loop", 200), ("fibonacci", 1500)])
+def test_prove_programs_vs_oracle(ctx, maker, arg):
+    from zigz_amd import host
+    r = getattr(programs, maker)(arg)
+    prog, inp = r if isinstance(r, tuple) else (r, None)
+    proof, ns = host.prove(ctx, prog, 0x1000, None, 1 << 20, inp)
+    oproof, ons = O.prove(P, prog, 0x1000, None, 1 << 20, inp)
+    assert ns == ons and proof == oproof
+    assert host.verify(proof, prog) == "Accept"
+
+
+def test_prove_config2_fibonacci_2_16_bit_exact(ctx):
+    """BASELINE config 2: fibonacci proved end-to-end at a 2^16 trace, byte-identical to the CPU oracle
+    (literal reference algorithm: naive eval twice per column, recompute-on-open Merkle)."""
+    from zigz_amd import host
+    n = (65536 - 12) // 5  # num_steps = 12 + 5n <= 2^16 < 2*num_steps
+    prog, inp = programs.fibonacci(n)
+    proof, ns = host.prove(ctx, prog, 0x1000, None, 1 << 20, inp)
+    assert 32768 < ns <= 65536
+    oproof, ons = O.prove(P, prog, 0x1000, None, 1 << 20, inp)
+    assert ons == ns and hashlib.sha3_256(proof).digest() == hashlib.sha3_256(oproof).digest() and proof == oproof
+    assert host.verify(proof, prog) == "Accept"
+
+
+def test_prove_2_20_properties(ctx):
+    """BASELINE config 3 (synthetic RV64I ADD/XOR loop, 2^20 trace): the literal oracle would need minutes, so
+    check size-independent properties: both verifiers accept; roots/values/paths agree with the oracle's
+    keep-levels commit on the same witness; transcript-derived points match; proof size formula."""
+    from zigz_amd import host
+    iters = ((1 << 20) - 3) // 4
+    prog = programs.add_xor_loop(iters)
+    t = host.Trace(prog, 0x1000, None, 1 << 21)
+    assert t.num_vars == 20 and (1 << 19) < t.num_steps <= (1 << 20)
+    proof = t.prove(ctx)
+    assert len(proof) == O.proof_size(20, 0, 0, t.num_lookups)
+    assert host.verify(proof, prog) == "Accept" and O.verify(P, proof, prog) == (0, 0)
+    # oracle: same transcript prefix, then generateCommitments (keep-levels variant, equal to the literal one)
+    cols = t.witness()
+    tr = O.Transcript()
+    tr.append_bytes(hashlib.sha256(prog).digest()); tr.append_field(0x1000 % P)
+    tr.append_bytes(b"SUMCHECK_BEGIN"); tr.append_field(t.num_steps % P); tr.append_field(20)
+    cpoint = []
+    for _ in range(20):
+        for _ in range(4):
+            tr.append_field(0)
+        cpoint.append(tr.challenge(P))
+    tr.append_bytes(b"LASSO_BEGIN")
+    O.lib.orc_tr_append_bytes  # (loop below is the literal schedule)
+    for i in range(t.num_lookups):
+        tr.append_bytes(b"LASSO_TABLE"); tr.append_field(i % P)
+    exp = O.generate_commitments(P, tr, cols, fast=True)
+    off = 32 + 324 + (40 * 20 + 8) + (4 + 24 * t.num_lookups)
+    for c in range(43):
+        rec = proof[off + c * (68 + 41 * 20): off + (c + 1) * (68 + 41 * 20)]
+        assert rec[:32] == exp["roots"][c].tobytes()
+        pts = np.frombuffer(rec[32:32 + 160], dtype="<u8")
+        assert np.array_equal(pts, exp["points"][c])
+        val, val2, idx, leaf = (int(x) for x in np.frombuffer(rec[192:224], dtype="<u8"))
+        assert val == val2 == int(exp["values"][c]) and idx == int(exp["indices"][c]) and leaf == int(exp["leaves"][c])
+        assert rec[228:228 + 640] == exp["siblings"][c].tobytes() and rec[868:888] == exp["dirs"][c].tobytes()
+
+
+def test_mirror_classes(ctx):
+    """SumcheckProver / LassoProver / CommitmentScheme through the C++ mirror classes."""
+    from zigz_amd import host
+    for nv in (1, 4, 12):
+        ev = O.splitmix64_field(31 + nv, 1 << nv)
+        r, pt, fe = O.sumcheck_prove(P, ev)
+        assert host.sumcheck_prove_bytes(ctx, ev) == O.sumcheck_to_bytes(r, pt, fe)
+    ev12 = [(i + 1) % P for i in range(1 << 12)]  # BASELINE config 1 input
+    r, pt, fe = O.sumcheck_prove(P, ev12)
+    assert host.sumcheck_prove_bytes(ctx, ev12) == O.sumcheck_to_bytes(r, pt, fe)
+    for e in G["lasso"]:
+        if e["p"] != str(P):
+            continue
+        q = np.array([[int(x) for x in r] for r in e["queries"]], dtype=np.uint64)
+        sb, qc, tc, nl = host.lasso_prove_table(ctx, e["kind"], e["bits"], q)
+        exp = O.sumcheck_to_bytes([int(x) for x in e["rounds"]], [int(x) for x in e["point"]], int(e["final_eval"]))
+        assert sb == exp and qc.hex() == e["query_commit"] and tc.hex() == e["table_commit"] and nl == len(q)
+    # mapping index 14 for (3,2)->1 in the 2-bit XOR table plus a second query (lasso_prover.zig:352-382)
+    sb, qc, tc, nl = host.lasso_prove_table(ctx, 1, 2, [[3, 2, 1], [0, 0, 0]], mapping=[14, 0])
+    assert nl == 2
+    ev = O.splitmix64_field(9, 64)
+    pt = O.splitmix64_field(10, 6)
+    root, val, idx, ok = host.commit_open_verify(ctx, ev, pt)
+    assert ok and root == O.merkle_build(ev)[0] and val == O.mle_eval(P, ev, pt) and idx == int(pt[0]) % 64

@@ -1,0 +1,140 @@
+"""CPU-only tests of the C++ host mirror's sequential parts (no GPU needed): RV64IM VM against the
+reference's own known answers, witness columns, ZIGZ v1 (de)serializer, Verifier, host transcript --
+checked against the golden fixtures and the oracle."""
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from zigz_amd import ZigzError, Transcript, host, sha256, sha3_256
+
+P = O.P_BB
+HERE = os.path.dirname(os.path.abspath(__file__))
+G = json.load(open(os.path.join(HERE, "golden", "golden.json")))
+VM_KATS = json.load(open(os.path.join(HERE, "golden", "vm_kats.json")))
+
+
+def ints(xs):
+    return None if xs is None else [int(x) for x in xs]
+
+
+@pytest.mark.parametrize("i", range(len(VM_KATS)))
+def test_vm_reference_kats(i):
+    k = VM_KATS[i]
+    limit = k["run_limit"] if k["run_limit"] is not None else k["n_step_calls"]
+    rc, regs, pc, steps = host.vm_run(bytes(k["program"]), k["entry_pc"], limit)
+    assert rc in (0, 30)
+    for r, v in k["expected_regs"].items():
+        assert regs[int(r)] == int(v), (k["name"], r)
+    if k["expected_pc"] is not None:
+        assert pc == int(k["expected_pc"])
+    orc = O.vm_run_kat(bytes(k["program"]), k["entry_pc"], limit)
+    assert (rc, regs, pc, steps) == orc
+
+
+@pytest.mark.parametrize("i", range(len(G["prove"])))
+def test_trace_and_witness_golden(i):
+    e = G["prove"][i]
+    prog = bytes.fromhex(e["program"])
+    t = host.Trace(prog, e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"]))
+    assert (t.num_steps, t.num_vars, t.num_lookups) == (e["num_steps"], e["nv"], e["L"])
+    cols, nv, ns = O.witness_from_program(P, prog, e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"]))
+    w = t.witness()
+    assert np.array_equal(w, cols)
+    if "witness" in e:
+        assert [[str(v) for v in c] for c in w] == e["witness"]
+    rows = t.rows()
+    assert rows.shape == (ns, 43) and np.array_equal(rows[:, :] % np.uint64(P), w[:, :ns].T)
+
+
+def test_vm_random_programs_vs_oracle():
+    """Random straight-line RV64IM programs (ALU/ALU-imm/*W/M/load/store/LUI/AUIPC): final registers and
+    witness must equal the oracle's, including sign/shift/division corner cases."""
+    rng = np.random.default_rng(42)
+    ops_r = [(0x33, f3, f7) for f3 in range(8) for f7 in (0, 0x20, 1)] + [(0x3b, f3, f7) for f3, f7 in
+             ((0, 0), (0, 0x20), (1, 0), (5, 0), (5, 0x20), (0, 1), (4, 1), (5, 1), (6, 1), (7, 1))]
+    for trial in range(30):
+        words = []
+        for r in range(1, 8):  # seed registers with interesting values via LUI/ADDI/SLLI
+            words.append((int(rng.integers(0, 1 << 20)) << 12) | (r << 7) | 0x37)
+            words.append((int(rng.integers(0, 1 << 12)) << 20) | (r << 15) | (r << 7) | 0x13)
+            if rng.integers(0, 2):
+                words.append((int(rng.integers(0, 64)) << 20) | (r << 15) | (1 << 12) | (r << 7) | 0x13)
+        for _ in range(60):
+            kind = int(rng.integers(0, 5))
+            rd, rs1, rs2 = (int(x) for x in rng.integers(0, 8, 3))
+            if kind == 0:
+                op, f3, f7 = ops_r[int(rng.integers(0, len(ops_r)))]
+                if op == 0x33 and f7 == 0x20 and f3 not in (0, 5):
+                    f7 = 0
+                words.append((f7 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op)
+            elif kind == 1:
+                f3 = int(rng.integers(0, 8))
+                imm = int(rng.integers(0, 1 << 12))
+                if f3 == 1:
+                    imm &= 63
+                if f3 == 5:
+                    imm = (imm & 63) | (0x400 if rng.integers(0, 2) else 0)
+                words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x13)
+            elif kind == 2:
+                f3 = [0, 1, 5][int(rng.integers(0, 3))]
+                imm = int(rng.integers(0, 1 << 12)) if f3 == 0 else (int(rng.integers(0, 32)) | (0x400 if (f3 == 5 and rng.integers(0, 2)) else 0))
+                words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x1b)
+            elif kind == 3:  # store then load back with random widths at small addresses off x0
+                f3s = int(rng.integers(0, 4)); off = int(rng.integers(0, 64))
+                words.append(((off >> 5) << 25) | (rs2 << 20) | (0 << 15) | (f3s << 12) | ((off & 31) << 7) | 0x23)
+                f3l = int(rng.integers(0, 7))
+                words.append((off << 20) | (0 << 15) | (f3l << 12) | (rd << 7) | 0x03)
+            else:
+                words.append((int(rng.integers(0, 1 << 20)) << 12) | (rd << 7) | (0x17 if rng.integers(0, 2) else 0x37))
+        prog = b"".join(int(w).to_bytes(4, "little") for w in words)
+        a = host.vm_run(prog, 0x1000, 10000)
+        b = O.vm_run_kat(prog, 0x1000, 10000)
+        assert a == b, trial
+        t = host.Trace(prog, 0x1000)
+        cols, nv, ns = O.witness_from_program(P, prog, 0x1000)
+        assert np.array_equal(t.witness(), cols)
+
+
+@pytest.mark.parametrize("i", [i for i, e in enumerate(G["prove"]) if "proof" in e])
+def test_verifier_and_serializer_golden(i):
+    e = G["prove"][i]
+    prog, proof = bytes.fromhex(e["program"]), bytes.fromhex(e["proof"])
+    assert host.verify(proof, prog) == "Accept"          # integration_tests.zig:55-84
+    assert host.reserialize(proof) == proof              # integration_tests.zig:90-127
+    with pytest.raises(ZigzError) as err:                # integration_tests.zig:133-165
+        host.verify(proof, prog + b"\x13\0\0\0")
+    assert err.value.name == "ProgramHashMismatch"
+    nv, L = e["nv"], e["L"]
+    n_in = 0 if e["initial_regs"] is None else len(e["initial_regs"])
+    n_out = int.from_bytes(proof[32 + 32 + 16 + 4 + 8 * n_in + 4 + 256 + 8:][:4], "little")
+    off = 32 + (324 + 8 * n_in + 8 * n_out) + (40 * nv + 8) + (4 + 24 * L)
+    t = bytearray(proof); t[off] ^= 1                    # tampered commitment (integration_tests.zig:251-290)
+    assert host.verify(bytes(t), prog) == "RejectInvalidCommitment"
+    t = bytearray(proof); t[off + 32 + 8 * nv] ^= 1      # tampered claim (integration_tests.zig:292-329)
+    assert host.verify(bytes(t), prog) == "RejectInvalidCommitment"
+    assert O.verify(P, bytes(t), prog) == (0, 3)
+    for bad, name in ((b"ZIGY" + proof[4:], "InvalidMagicNumber"), (proof[:4] + b"\2\0\0\0" + proof[8:], "UnsupportedVersion"),
+                      (proof[:8] + (17).to_bytes(8, "little") + proof[16:], "FieldMismatch"), (proof[:-5], None)):
+        with pytest.raises(ZigzError) as err:
+            host.verify(bad, prog)
+        if name:
+            assert err.value.name == name
+
+
+def test_host_hashes_and_transcript():
+    rng = np.random.default_rng(1)
+    for n in (0, 1, 8, 55, 56, 64, 135, 136, 137, 500):
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert sha3_256(m) == O.sha3_256(m) and sha256(m) == O.sha256(m)
+    a, b = Transcript(), O.Transcript()
+    for t in (a, b):
+        t.append_bytes(b"POLY_COMMITMENTS"); t.append_field(P - 1); t.append_bytes(b"x" * 200)
+    a.append_tagged_counter(b"LASSO_TABLE", 0, 300)
+    for i in range(300):
+        b.append_bytes(b"LASSO_TABLE"); b.append_field(i)
+    assert [a.challenge() for _ in range(4)] == [b.challenge(P) for _ in range(4)]
+    t = Transcript(); t.append_field(3); t.append_field(4)
+    assert [str(t.challenge()), str(t.challenge())] == G["transcript_kat"]["challenges_babybear"]

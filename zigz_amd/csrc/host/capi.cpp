@@ -1,0 +1,217 @@
+// extern "C" face of the host mirror (include/zigz_host.h) for ctypes callers.
+#include <cstdlib>
+#include <cstring>
+#include <memory>
+
+#include "zigz_host.h"
+#include "zigz_host.hpp"
+
+using namespace zigz;
+
+static thread_local std::string g_err;
+
+template <class Fn>
+static int guard(Fn &&fn) {
+    try {
+        fn();
+        return 0;
+    } catch (const Error &e) {
+        g_err = e.what();
+        return e.code;
+    } catch (const std::bad_alloc &) {
+        g_err = "error.OutOfMemory";
+        return ZIGZ_ERR_OUT_OF_MEMORY;
+    } catch (const std::exception &e) {
+        g_err = e.what();
+        return ZIGZ_ERR_INVALID_ARGUMENT;
+    }
+}
+
+static uint8_t *dup_bytes(const std::vector<uint8_t> &v) {
+    uint8_t *p = (uint8_t *)malloc(v.size() ? v.size() : 1);
+    if (!p) throw std::bad_alloc();
+    memcpy(p, v.data(), v.size());
+    return p;
+}
+
+extern "C" const char *zigzh_last_error(void) { return g_err.c_str(); }
+extern "C" void zigzh_free(void *p) { free(p); }
+
+struct zigzh_trace {
+    PublicIO io;
+    ExecutionTrace trace;
+    size_t num_lookups = 0, num_vars = 0;
+    std::optional<std::vector<uint64_t>> initial_regs;
+};
+
+extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_t entry_pc, const uint64_t *initial_regs,
+                             size_t n_initial_regs, int has_initial_regs, size_t max_steps, const uint64_t *input,
+                             size_t n_input, zigzh_trace **out) {
+    return guard([&] {
+        std::vector<uint8_t> prog(program, program + program_len);
+        std::vector<uint64_t> in(input, input + (input ? n_input : 0));
+        auto t = std::make_unique<zigzh_trace>();
+        zigz_sha256(prog.data(), prog.size(), t->io.program_hash.data());
+        t->io.initial_pc = entry_pc;
+        if (has_initial_regs) t->initial_regs = std::vector<uint64_t>(initial_regs, initial_regs + n_initial_regs);
+        VMState vm(prog, entry_pc, input ? &in : nullptr);
+        if (t->initial_regs)
+            for (size_t i = 0; i < t->initial_regs->size() && i < 32; i++) vm.writeReg((unsigned)i, (*t->initial_regs)[i]);
+        size_t step_count = 0;
+        while (!vm.halted && step_count < max_steps) {  // prover.zig:132-142
+            vm.step();
+            if (vm.invalid_instruction) break;
+            step_count++;
+        }
+        t->trace = std::move(vm.trace);
+        const size_t ns = t->trace.stepCount();
+        for (uint8_t f : t->trace.is_lookup) t->num_lookups += f;
+        while (((size_t)1 << t->num_vars) < ns) t->num_vars++;
+        t->io.final_pc = vm.pc;
+        std::vector<uint64_t> fr(32);
+        for (unsigned r = 0; r < 32; r++) fr[r] = vm.readReg(r);
+        t->io.final_regs = fr;
+        t->io.num_steps = ns;
+        if (!vm.output_tape.empty()) t->io.outputs = vm.output_tape;
+        t->io.initial_regs = t->initial_regs;
+        *out = t.release();
+    });
+}
+extern "C" void zigzh_trace_free(zigzh_trace *t) { delete t; }
+extern "C" size_t zigzh_trace_num_steps(const zigzh_trace *t) { return t->trace.stepCount(); }
+extern "C" size_t zigzh_trace_num_vars(const zigzh_trace *t) { return t->num_vars; }
+extern "C" size_t zigzh_trace_num_lookups(const zigzh_trace *t) { return t->num_lookups; }
+extern "C" const uint64_t *zigzh_trace_rows(const zigzh_trace *t) { return t->trace.rows.data(); }
+
+extern "C" int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out) {
+    return guard([&] {
+        Witness w = WitnessGenerator::generate(t->trace);
+        memcpy(cols_out, w.columns.data(), w.columns.size() * sizeof(uint64_t));
+    });
+}
+
+extern "C" int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride) {
+    return guard([&] {
+        Witness w = WitnessGenerator::generate(t->trace);
+        const size_t N = (size_t)1 << w.num_vars;
+        if (stride < N) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "stride < 2^num_vars");
+        for (size_t c = 0; c < ROW_WORDS; c++) check(ctx, zigz_dev_upload_u64(ctx, w.column(c), N, d_cols + c * stride));
+    });
+}
+
+extern "C" int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int want_bytes,
+                                 uint8_t **proof_out, size_t *proof_len) {
+    return guard([&] {
+        if (t->trace.stepCount() == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+        Prover prover(ctx, 0);
+        Proof proof;
+        const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
+        if (d_cols) {
+            proof = prover.proveWitness(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir);
+        } else {
+            Witness w = WitnessGenerator::generate(t->trace);
+            proof = prover.proveWitness(t->io, t->num_lookups, &w, nullptr, 0, w.num_vars, ir);
+        }
+        if (want_bytes) {
+            std::vector<uint8_t> b = BinarySerializer::serialize(proof);
+            *proof_out = dup_bytes(b);
+            *proof_len = b.size();
+        }
+    });
+}
+
+extern "C" int zigzh_prove(zigz_ctx *ctx, const uint8_t *program, size_t program_len, uint64_t entry_pc,
+                           const uint64_t *initial_regs, size_t n_initial_regs, int has_initial_regs, size_t max_steps,
+                           const uint64_t *input, size_t n_input, uint8_t **proof_out, size_t *proof_len, size_t *num_steps) {
+    return guard([&] {
+        std::vector<uint8_t> prog(program, program + program_len);
+        std::vector<uint64_t> regs, in;
+        if (has_initial_regs) regs.assign(initial_regs, initial_regs + n_initial_regs);
+        if (input) in.assign(input, input + n_input);
+        Prover prover(ctx, 0);  // main.cmdProve: Prover(F).init(allocator, 0), src/main.zig:148
+        Proof proof = prover.prove(prog, entry_pc, has_initial_regs ? &regs : nullptr, max_steps, nullptr, input ? &in : nullptr);
+        std::vector<uint8_t> b = BinarySerializer::serialize(proof);
+        *proof_out = dup_bytes(b);
+        *proof_len = b.size();
+        if (num_steps) *num_steps = proof.public_io.num_steps;
+    });
+}
+
+extern "C" int zigzh_verify(const uint8_t *proof, size_t proof_len, const uint8_t *program, size_t program_len, int *result) {
+    return guard([&] {
+        Proof p = BinarySerializer::deserialize(proof, proof_len);
+        Verifier v;
+        *result = (int)v.verify(p, std::vector<uint8_t>(program, program + program_len));
+    });
+}
+
+extern "C" int zigzh_reserialize(const uint8_t *proof, size_t proof_len, uint8_t **out, size_t *out_len) {
+    return guard([&] {
+        Proof p = BinarySerializer::deserialize(proof, proof_len);
+        std::vector<uint8_t> b = BinarySerializer::serialize(p);
+        *out = dup_bytes(b);
+        *out_len = b.size();
+    });
+}
+
+extern "C" int zigzh_vm_run(const uint8_t *program, size_t program_len, uint64_t entry_pc, size_t max_steps,
+                            uint64_t final_regs[32], uint64_t *final_pc, size_t *steps) {
+    std::unique_ptr<VMState> vm;
+    int rc = guard([&] {
+        vm.reset(new VMState(std::vector<uint8_t>(program, program + program_len), entry_pc, nullptr));
+        vm->run(max_steps);
+    });
+    if (vm) {
+        for (unsigned r = 0; r < 32; r++) final_regs[r] = vm->readReg(r);
+        *final_pc = vm->pc;
+        *steps = vm->trace.stepCount();
+    }
+    return rc;
+}
+
+extern "C" int zigzh_sumcheck_prove_bytes(zigz_ctx *ctx, const uint64_t *evals, size_t n, uint8_t *out, size_t *out_len) {
+    return guard([&] {
+        Multilinear poly = Multilinear::init(ctx, std::vector<F>(evals, evals + n));
+        if (poly.num_vars == 0) throw Error(ZIGZ_ERR_NO_VARIABLES, "error.NoVariables");  // sumcheck_prover.zig:30-32
+        SumcheckProof p = SumcheckProver::prove(poly);
+        std::vector<uint8_t> b = p.toBytes();
+        memcpy(out, b.data(), b.size());
+        *out_len = b.size();
+    });
+}
+
+extern "C" int zigzh_lasso_prove_table(zigz_ctx *ctx, int kind, size_t bits, const uint64_t *queries, size_t n_queries,
+                                       const uint64_t *mapping, size_t n_mapping, uint8_t *sumcheck_bytes,
+                                       size_t *sumcheck_len, uint8_t query_commitment[32], uint8_t table_commitment[32],
+                                       size_t *num_lookups) {
+    return guard([&] {
+        DenseTable table = kind == 0 ? buildAddTable(bits) : kind == 1 ? buildXorTable(bits) : buildAndTable(bits);
+        std::vector<LookupQuery> qs(n_queries);
+        for (size_t j = 0; j < n_queries; j++) {
+            qs[j].inputs = {queries[3 * j], queries[3 * j + 1]};
+            qs[j].expected_outputs = {queries[3 * j + 2]};
+        }
+        LassoProofFull p;
+        if (mapping) p = LassoProver::proveWithMapping(ctx, table, qs, std::vector<size_t>(mapping, mapping + n_mapping));
+        else p = LassoProver::prove(ctx, table, qs);
+        std::vector<uint8_t> b = p.sumcheck_proof.toBytes();
+        memcpy(sumcheck_bytes, b.data(), b.size());
+        *sumcheck_len = b.size();
+        memcpy(query_commitment, p.query_commitment.data(), 32);
+        memcpy(table_commitment, p.table_commitment.data(), 32);
+        *num_lookups = p.num_lookups;
+    });
+}
+
+extern "C" int zigzh_commit_open_verify(zigz_ctx *ctx, const uint64_t *evals, size_t n, const uint64_t *point, size_t npoint,
+                                        uint8_t root[32], uint64_t *value, uint64_t *index, int *ok) {
+    return guard([&] {
+        Multilinear poly = Multilinear::init(ctx, std::vector<F>(evals, evals + n));
+        auto c = CommitmentScheme::commit(poly);
+        memcpy(root, c.commitment.data(), 32);
+        PolyOpeningProof pr = CommitmentScheme::open(poly, c.tree, std::vector<F>(point, point + npoint));
+        *value = pr.value;
+        *index = pr.merkle_proof.index;
+        *ok = CommitmentScheme::verify(c.commitment, c.num_vars, pr) ? 1 : 0;
+    });
+}

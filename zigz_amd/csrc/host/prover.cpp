@@ -1,0 +1,415 @@
+// WitnessGenerator, Proof, Prover, BinarySerializer, Verifier: the host orchestration of
+// src/prover/prover.zig with its exact Fiat-Shamir schedule.  The 43-column
+// Merkle/eval/open work runs on the GPU through the zigz_commit_* job of the C ABI and overlaps the
+// sequential O(L) transcript absorption of the Lasso placeholders.
+#include <cstdio>
+#include <cstring>
+#include <memory>
+
+#include "zigz_host.hpp"
+
+namespace zigz {
+
+static size_t log2_int_ceil(size_t n) {  // std.math.log2_int_ceil
+    size_t l = 0;
+    while (((size_t)1 << l) < n) l++;
+    return l;
+}
+
+// ---------------------------------------------------------------- witness (witness.zig:29-270)
+Witness WitnessGenerator::generate(const ExecutionTrace &trace) {
+    Witness w;
+    const size_t ns = trace.stepCount();
+    w.num_steps = ns;
+    w.num_vars = ns == 0 ? 0 : log2_int_ceil(ns);
+    const size_t N = (size_t)1 << w.num_vars;
+    w.columns.assign(ROW_WORDS * N, 0);
+    if (ns == 0) return w;
+    for (size_t c = 0; c < ROW_WORDS; c++) {
+        F *col = w.columns.data() + c * N;
+        for (size_t i = 0; i < ns; i++) col[i] = finit(trace.row(i)[c]);
+        if (c <= 32) {  // pc and registers repeat the last value (:80-87,116-123); the rest pads with 0
+            const F last = col[ns - 1];
+            for (size_t i = ns; i < N; i++) col[i] = last;
+        }
+    }
+    return w;
+}
+
+// ---------------------------------------------------------------- Proof (proof.zig)
+Proof Proof::init(size_t num_steps) {  // :224-261
+    Proof p;
+    const size_t nv = log2_int_ceil(num_steps);
+    p.constraint_proof.num_vars = nv;
+    p.constraint_proof.num_coeffs = 4;  // degree 3
+    p.constraint_proof.round_polynomials.assign(nv * 4, 0);
+    p.constraint_proof.final_point.assign(nv, 0);
+    p.witness_commitments.resize(ZIGZ_NUM_COLUMNS);
+    for (auto &o : p.witness_commitments) o.point.assign(nv, 0);
+    p.metadata.num_steps = num_steps;
+    p.metadata.num_vars = nv;
+    return p;
+}
+
+LassoProof Proof::lookupAt(size_t i) const {
+    if (i >= lookup_placeholders) return lookup_proofs.at(i - lookup_placeholders);
+    LassoProof l;  // prover.zig:302-349
+    l.table_id = (uint32_t)i;
+    l.num_lookups = 1;
+    l.multiset_proof.num_vars = 0;
+    l.multiset_proof.num_coeffs = 3;
+    l.multiset_proof.final_eval = 0;
+    return l;
+}
+
+size_t Proof::estimateSize() const {  // :279-312
+    size_t size = 32 + 8 + 8 + 8;
+    if (public_io.initial_regs) size += public_io.initial_regs->size() * 8;
+    if (public_io.final_regs) size += public_io.final_regs->size() * 8;
+    size += metadata.num_vars * 4 * 8 + metadata.num_vars * 8 + 8;
+    for (size_t i = 0; i < lookupCount(); i++) size += 4 + 8 + lookupAt(i).multiset_proof.num_vars * 3 * 8;
+    size += witness_commitments.size() * 32 + witness_commitments.size() * 20 * 32;
+    return size;
+}
+
+// ---------------------------------------------------------------- Prover
+void Prover::bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs) {
+    transcript_.reset();                                   // prover.zig:91
+    transcript_.appendBytes(program_hash.data(), 32);      // :98-100
+    transcript_.appendFieldElement(finit(entry_pc));       // :103
+    if (initial_regs)
+        for (uint64_t r : *initial_regs) transcript_.appendFieldElement(finit(r));  // :106-110
+}
+
+void Prover::generateSumcheckProof(Proof &proof, size_t num_steps, size_t num_vars) {  // :229-289
+    transcript_.appendBytes("SUMCHECK_BEGIN");
+    transcript_.appendFieldElement(finit(num_steps));
+    transcript_.appendFieldElement(finit(num_vars));
+    proof.constraint_proof.final_eval = 0;
+    for (size_t round = 0; round < num_vars; round++) {
+        for (int k = 0; k < 4; k++) {
+            proof.constraint_proof.round_polynomials[round * 4 + k] = 0;  // zero polynomial, :267-272
+            transcript_.appendFieldElement(0);
+        }
+        proof.constraint_proof.final_point[round] = transcript_.challenge();
+    }
+}
+
+void Prover::generateLassoProofs(Proof &proof, size_t num_lookups) {  // :292-363
+    transcript_.appendBytes("LASSO_BEGIN");
+    // per lookup constraint i: appendBytes("LASSO_TABLE"); appendFieldElement(F.init(i))  (:311-312)
+    transcript_.appendTaggedCounter("LASSO_TABLE", 0, num_lookups);
+    proof.lookup_placeholders = num_lookups;  // placeholder proofs; the rng fill loops run zero times
+}
+
+void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) {  // :366-467
+    const size_t NC = ZIGZ_NUM_COLUMNS;
+    std::vector<uint8_t> roots(NC * 32);
+    check(ctx_, zigz_commit_roots(job, roots.data()));                 // PHASE 1 results
+    transcript_.appendBytes("POLY_COMMITMENTS");                       // PHASE 2, :413-416
+    for (size_t c = 0; c < NC; c++) {
+        memcpy(proof.witness_commitments[c].commitment.data(), roots.data() + 32 * c, 32);
+        transcript_.appendBytes(roots.data() + 32 * c, 32);
+    }
+    std::vector<F> points(NC * nv + 1);                                // PHASE 3, :420-424
+    for (size_t c = 0; c < NC; c++)
+        for (size_t j = 0; j < nv; j++) points[c * nv + j] = transcript_.challenge();
+    std::vector<F> values(NC), indices(NC), leaves(NC);
+    std::vector<uint8_t> sib(NC * nv * 32 + 1), dirs(NC * nv + 1);
+    check(ctx_, zigz_commit_open_all(job, points.data(), values.data(), indices.data(), leaves.data(), sib.data(),
+                                     dirs.data()));                    // :427-431
+    for (size_t c = 0; c < NC; c++) {
+        CommitmentOpening &o = proof.witness_commitments[c];
+        o.point.assign(points.begin() + c * nv, points.begin() + (c + 1) * nv);
+        o.value = values[c];
+        o.proof.point = o.point;
+        o.proof.value = values[c];
+        o.proof.merkle_proof.index = indices[c];
+        o.proof.merkle_proof.value = leaves[c];
+        o.proof.merkle_proof.path.siblings.resize(nv);
+        o.proof.merkle_proof.path.directions.resize(nv);
+        for (size_t l = 0; l < nv; l++) {
+            memcpy(o.proof.merkle_proof.path.siblings[l].data(), sib.data() + (c * nv + l) * 32, 32);
+            o.proof.merkle_proof.path.directions[l] = dirs[c * nv + l];
+        }
+    }
+    transcript_.appendBytes("OPENING_CLAIMS");                         // PHASE 4, :463-466
+    for (size_t c = 0; c < NC; c++) transcript_.appendFieldElement(proof.witness_commitments[c].value);
+}
+
+Proof Prover::proveWitness(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                           size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs) {
+    // transcript binding of the public inputs (prover.zig:91-110)
+    bindPublicInputs(io.program_hash, io.initial_pc, initial_regs);
+    const size_t num_steps = io.num_steps;
+    if (num_steps == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+    Proof proof = Proof::init(num_steps);
+    if (proof.metadata.num_vars != num_vars) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "witness num_vars != log2_int_ceil(num_steps)");
+    // [6/6 phase 1] Merkle builds do not depend on the transcript: start them first, asynchronously on
+    // the GPU, so they run underneath the sequential host absorption of steps 4 and 5.
+    zigz_commit_job *job = nullptr;
+    if (witness)
+        check(ctx_, zigz_commit_begin(ctx_, witness->columns.data(), ZIGZ_NUM_COLUMNS, (size_t)1 << num_vars, num_vars, &job));
+    else
+        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols, ZIGZ_NUM_COLUMNS, d_col_stride, num_vars, &job));
+    try {
+        generateSumcheckProof(proof, num_steps, num_vars);  // [4/6]
+        generateLassoProofs(proof, num_lookups);            // [5/6]
+        generateCommitments(proof, job, num_vars);          // [6/6]
+    } catch (...) {
+        zigz_commit_end(job);
+        throw;
+    }
+    zigz_commit_end(job);
+    proof.public_io = io;  // packagePublicIO, :514-559
+    if (initial_regs) proof.public_io.initial_regs = *initial_regs;
+    else proof.public_io.initial_regs.reset();
+    return proof;
+}
+
+Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs,
+                    size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input) {
+    if (verbose) fprintf(stderr, "\n=== zkVM Prover ===\nProgram size: %zu bytes\nEntry PC: 0x%llx\n", program.size(),
+                         (unsigned long long)entry_pc);
+    PublicIO io;
+    zigz_sha256(program.data(), program.size(), io.program_hash.data());
+    io.initial_pc = entry_pc;
+    // [1/6] execute (prover.zig:117-149)
+    std::unique_ptr<VMState> vm(segments ? new VMState(*segments, entry_pc, input) : new VMState(program, entry_pc, input));
+    if (initial_regs)
+        for (size_t i = 0; i < initial_regs->size() && i < 32; i++) vm->writeReg((unsigned)i, (*initial_regs)[i]);
+    size_t step_count = 0;
+    while (!vm->halted && step_count < max_steps) {
+        vm->step();
+        if (vm->invalid_instruction) break;  // "Program halted at step N": normal termination
+        step_count++;
+    }
+    const size_t num_steps = vm->trace.stepCount();
+    if (num_steps == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+    // [2/6] witness (prover.zig:156-162)
+    Witness witness = WitnessGenerator::generate(vm->trace);
+    // [3/6] constraint system: only the number of lookup constraints is observable (builder.zig:253-267)
+    size_t L = 0;
+    for (uint8_t f : vm->trace.is_lookup) L += f;
+    io.final_pc = vm->pc;
+    std::vector<uint64_t> fr(32);
+    for (unsigned r = 0; r < 32; r++) fr[r] = vm->readReg(r);
+    io.final_regs = fr;
+    io.num_steps = num_steps;
+    if (!vm->output_tape.empty()) io.outputs = vm->output_tape;
+    return proveWitness(io, L, &witness, nullptr, 0, witness.num_vars, initial_regs);
+}
+
+// ---------------------------------------------------------------- BinarySerializer (serialization.zig)
+namespace {
+struct W {
+    std::vector<uint8_t> &b;
+    size_t pos = 0;
+    void bytes(const void *d, size_t n) { memcpy(b.data() + pos, d, n); pos += n; }
+    void u8(uint8_t v) { b[pos++] = v; }
+    void u32(uint32_t v) { bytes(&v, 4); }
+    void u64(uint64_t v) { bytes(&v, 8); }
+};
+struct R {
+    const uint8_t *b;
+    size_t len, pos = 0;
+    const uint8_t *bytes(size_t n) {
+        if (len - pos < n) throw Error(ERR_INVALID_DATA, "error.EndOfStream");
+        const uint8_t *q = b + pos;
+        pos += n;
+        return q;
+    }
+    uint32_t u32() { uint32_t v; memcpy(&v, bytes(4), 4); return v; }
+    uint64_t u64() { uint64_t v; memcpy(&v, bytes(8), 8); return v; }
+};
+size_t sumcheck_size(const ProverSumcheckProof &s) { return (s.round_polynomials.size() + s.final_point.size() + 1) * 8; }
+}  // namespace
+
+size_t BinarySerializer::exactSize(const Proof &p) {
+    size_t size = 32;  // header
+    size += 32 + 8 + 8 + 4 + 4 + 8 + 4;
+    if (p.public_io.initial_regs) size += p.public_io.initial_regs->size() * 8;
+    if (p.public_io.final_regs) size += p.public_io.final_regs->size() * 8;
+    if (p.public_io.outputs) size += p.public_io.outputs->size() * 8;
+    size += sumcheck_size(p.constraint_proof);
+    size += 4 + p.lookup_placeholders * 24;
+    for (auto &l : p.lookup_proofs) size += 16 + sumcheck_size(l.multiset_proof);
+    for (auto &o : p.witness_commitments)
+        size += 32 + o.point.size() * 8 + 8 + (8 + 8 + 8 + 4 + o.proof.merkle_proof.path.siblings.size() * 33);
+    return size;
+}
+
+static void write_sumcheck(W &w, const ProverSumcheckProof &s) {  // writeConstraintProof, :296-311
+    for (F c : s.round_polynomials) w.u64(c);
+    for (F c : s.final_point) w.u64(c);
+    w.u64(s.final_eval);
+}
+
+std::vector<uint8_t> BinarySerializer::serialize(const Proof &p) {
+    // The reference sizes a fixed buffer from an estimate that under-counts; this
+    // writes the same layout into an exact-size buffer.
+    std::vector<uint8_t> buf(exactSize(p));
+    W w{buf};
+    w.bytes("ZIGZ", 4);  // writeHeader, :175-182
+    w.u32(1);
+    w.u64(p.metadata.field_modulus);
+    w.u64(p.metadata.num_steps);
+    w.u32((uint32_t)p.metadata.num_vars);
+    w.u32(0);
+    w.bytes(p.public_io.program_hash.data(), 32);  // writePublicIO, :209-245
+    w.u64(p.public_io.initial_pc);
+    w.u64(p.public_io.final_pc);
+    auto regs = [&](const std::optional<std::vector<uint64_t>> &r) {
+        if (r) { w.u32((uint32_t)r->size()); for (uint64_t v : *r) w.u64(v); }
+        else w.u32(0);
+    };
+    regs(p.public_io.initial_regs);
+    regs(p.public_io.final_regs);
+    w.u64(p.public_io.num_steps);
+    regs(p.public_io.outputs);
+    write_sumcheck(w, p.constraint_proof);
+    w.u32((uint32_t)p.lookupCount());  // writeLassoProofs, :333-344
+    for (size_t i = 0; i < p.lookup_placeholders; i++) { w.u32((uint32_t)i); w.u64(1); w.u32(0); w.u64(0); }
+    for (auto &l : p.lookup_proofs) {
+        w.u32(l.table_id); w.u64(l.num_lookups); w.u32((uint32_t)l.multiset_proof.num_vars);
+        write_sumcheck(w, l.multiset_proof);
+    }
+    for (auto &o : p.witness_commitments) {  // writeWitnessCommitments + writeMerkleProof, :374-429
+        w.bytes(o.commitment.data(), 32);
+        for (F c : o.point) w.u64(c);
+        w.u64(o.value);
+        w.u64(o.proof.value);
+        w.u64(o.proof.merkle_proof.index);
+        w.u64(o.proof.merkle_proof.value);
+        w.u32((uint32_t)o.proof.merkle_proof.path.siblings.size());
+        for (auto &s : o.proof.merkle_proof.path.siblings) w.bytes(s.data(), 32);
+        for (uint8_t d : o.proof.merkle_proof.path.directions) w.u8(d ? 1 : 0);
+    }
+    if (w.pos != buf.size()) throw Error(ZIGZ_ERR_PROTOCOL_ERROR, "serializer size mismatch");
+    return buf;
+}
+
+Proof BinarySerializer::deserialize(const uint8_t *data, size_t len) {  // :100-131
+    R r{data, len};
+    if (memcmp(r.bytes(4), "ZIGZ", 4) != 0) throw Error(ERR_INVALID_MAGIC, "error.InvalidMagicNumber");
+    if (r.u32() != 1) throw Error(ERR_UNSUPPORTED_VERSION, "error.UnsupportedVersion");
+    ProofMetadata md;
+    md.field_modulus = r.u64();
+    md.num_steps = (size_t)r.u64();
+    md.num_vars = r.u32();
+    (void)r.u32();
+    if (md.field_modulus != BABYBEAR) throw Error(ERR_FIELD_MISMATCH, "error.FieldMismatch");
+    if (md.num_steps == 0) throw Error(ERR_INVALID_DATA, "error.InvalidData");
+    Proof p = Proof::init(md.num_steps);
+    p.metadata = md;
+    memcpy(p.public_io.program_hash.data(), r.bytes(32), 32);  // readPublicIO, :247-294
+    p.public_io.initial_pc = r.u64();
+    p.public_io.final_pc = r.u64();
+    auto regs = [&](std::optional<std::vector<uint64_t>> &out) {
+        uint32_t n = r.u32();
+        if (n > 0) {
+            if ((r.len - r.pos) / 8 < n) throw Error(ERR_INVALID_DATA, "error.EndOfStream");
+            std::vector<uint64_t> v(n);
+            for (auto &x : v) x = r.u64();
+            out = std::move(v);
+        } else out.reset();
+    };
+    regs(p.public_io.initial_regs);
+    regs(p.public_io.final_regs);
+    p.public_io.num_steps = (size_t)r.u64();
+    regs(p.public_io.outputs);
+    auto read_sumcheck = [&](ProverSumcheckProof &s) {  // readConstraintProof, :313-331
+        for (auto &c : s.round_polynomials) c = finit(r.u64());
+        for (auto &c : s.final_point) c = finit(r.u64());
+        s.final_eval = finit(r.u64());
+    };
+    read_sumcheck(p.constraint_proof);
+    uint32_t n_lasso = r.u32();  // readLassoProofs, :346-372
+    bool placeholders_only = true;
+    for (uint32_t i = 0; i < n_lasso; i++) {
+        LassoProof l;
+        l.table_id = r.u32();
+        l.num_lookups = (size_t)r.u64();
+        uint32_t nv = r.u32();
+        if ((r.len - r.pos) / 8 < (size_t)nv * 4) throw Error(ERR_INVALID_DATA, "error.EndOfStream");
+        l.multiset_proof.num_vars = nv;
+        l.multiset_proof.num_coeffs = 3;
+        l.multiset_proof.round_polynomials.assign((size_t)nv * 3, 0);
+        l.multiset_proof.final_point.assign(nv, 0);
+        read_sumcheck(l.multiset_proof);
+        const bool is_placeholder = l.table_id == i && l.num_lookups == 1 && nv == 0 && l.multiset_proof.final_eval == 0;
+        if (placeholders_only && is_placeholder) p.lookup_placeholders++;
+        else { placeholders_only = false; p.lookup_proofs.push_back(std::move(l)); }
+    }
+    for (auto &o : p.witness_commitments) {  // readWitnessCommitments + readMerkleProof, :389-477
+        memcpy(o.commitment.data(), r.bytes(32), 32);
+        for (auto &c : o.point) c = finit(r.u64());
+        o.value = finit(r.u64());
+        o.proof.value = finit(r.u64());
+        o.proof.merkle_proof.index = (size_t)r.u64();
+        o.proof.merkle_proof.value = finit(r.u64());
+        uint32_t plen = r.u32();
+        if ((r.len - r.pos) / 33 < plen) throw Error(ERR_INVALID_DATA, "error.EndOfStream");
+        o.proof.merkle_proof.path.siblings.resize(plen);
+        o.proof.merkle_proof.path.directions.resize(plen);
+        for (auto &s : o.proof.merkle_proof.path.siblings) memcpy(s.data(), r.bytes(32), 32);
+        for (auto &d : o.proof.merkle_proof.path.directions) d = *r.bytes(1) != 0;
+        o.proof.point = o.point;
+    }
+    return p;
+}
+
+// ---------------------------------------------------------------- Verifier (verifier.zig)
+static inline F vadd(F a, F b) { F s = a + b; return s >= BABYBEAR ? s - BABYBEAR : s; }
+static inline F vmul(F a, F b) { return (F)(((unsigned __int128)a * b) % BABYBEAR); }
+
+VerificationResult Verifier::verifySumcheckProof(const ProverSumcheckProof &p) {  // :182-238
+    transcript_.appendBytes("SUMCHECK_BEGIN");
+    transcript_.appendFieldElement(finit(p.num_vars));
+    const F claimed_sum = p.final_eval;
+    const size_t nc = p.num_coeffs;
+    for (size_t round = 0; round < p.num_vars; round++) {
+        const F *c = p.round_polynomials.data() + round * nc;
+        F g1 = 0;
+        for (size_t k = 0; k < nc; k++) g1 = vadd(g1, c[k]);
+        if (round == 0 && vadd(c[0], g1) != claimed_sum) return VerificationResult::RejectInvalidSumcheck;
+        const F ch = transcript_.challenge();
+        F ev = 0, pw = 1;
+        for (size_t k = 0; k < nc; k++) { ev = vadd(ev, vmul(c[k], pw)); pw = vmul(pw, ch); }
+        transcript_.appendFieldElement(ev);
+    }
+    return VerificationResult::Accept;
+}
+
+VerificationResult Verifier::verify(const Proof &proof, const std::vector<uint8_t> &program) {  // :49-91
+    transcript_.reset();
+    Hash ph;
+    zigz_sha256(program.data(), program.size(), ph.data());  // bindPublicInputs, :95-122
+    if (ph != proof.public_io.program_hash) throw Error(ERR_PROGRAM_HASH_MISMATCH, "error.ProgramHashMismatch");
+    transcript_.appendBytes(ph.data(), 32);
+    transcript_.appendFieldElement(finit(proof.public_io.initial_pc));
+    if (proof.public_io.initial_regs)
+        for (uint64_t r : *proof.public_io.initial_regs) transcript_.appendFieldElement(finit(r));
+    transcript_.appendBytes("POLY_COMMITMENTS");  // bindPolynomialCommitments, :126-137
+    for (auto &o : proof.witness_commitments) transcript_.appendBytes(o.commitment.data(), 32);
+    for (auto &o : proof.witness_commitments)      // deriveAndBindOpeningClaims, :146-179
+        for (size_t j = 0; j < o.point.size(); j++) (void)transcript_.challenge();
+    transcript_.appendBytes("OPENING_CLAIMS");
+    for (auto &o : proof.witness_commitments) transcript_.appendFieldElement(o.value);
+    if (verifySumcheckProof(proof.constraint_proof) != VerificationResult::Accept)  // PHASE 4
+        return VerificationResult::RejectInvalidSumcheck;
+    for (size_t i = 0; i < proof.lookupCount(); i++) {  // PHASE 5, verifyLassoProof :241-267
+        LassoProof l = proof.lookupAt(i);
+        transcript_.appendBytes("LASSO_BEGIN");
+        transcript_.appendBytes("LASSO_TABLE");
+        transcript_.appendFieldElement(finit(l.table_id));
+        if (verifySumcheckProof(l.multiset_proof) != VerificationResult::Accept) return VerificationResult::RejectInvalidLookup;
+    }
+    for (auto &o : proof.witness_commitments) {  // PHASE 6, verifyOpening :270-294
+        if (o.value != o.proof.value) return VerificationResult::RejectInvalidCommitment;
+        if (!CommitmentScheme::verify(o.commitment, o.point.size(), o.proof)) return VerificationResult::RejectInvalidCommitment;
+    }
+    return VerificationResult::Accept;
+}
+
+}  // namespace zigz

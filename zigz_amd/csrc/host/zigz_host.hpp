@@ -1,0 +1,287 @@
+// C++ mirror of the Zig host side of zigz, written ABOVE the C ABI of include/zigz_hip.h.
+//
+// The reference host is Zig (absent from this toolchain), so the host side that a Zig maintainer
+// would keep is restated here in C++ with the reference's names, argument meaning and error
+// behaviour: Multilinear, SumcheckProver, SimpleMerkleTree, CommitmentScheme, LassoProver,
+// VMState/ExecutionTrace, WitnessGenerator, Prover, BinarySerializer, Verifier.  Every field or hash
+// operation on the data path goes through libzigz_hip.so (zigz_* calls); this layer holds only the
+// sequential host logic (VM, transcript schedule, proof packaging).
+#pragma once
+#include <array>
+#include <cstdint>
+#include <optional>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "zigz_hip.h"
+
+namespace zigz {
+
+constexpr uint64_t BABYBEAR = ZIGZ_BABYBEAR_P;  // src/core/field_presets.zig:19
+using F = uint64_t;                             // canonical value of Field(u64, BabyBear)
+using Hash = std::array<uint8_t, 32>;           // src/commitments/merkle_tree.zig:25
+
+// Zig error unions -> one exception type carrying the status code / Zig error name
+struct Error : std::runtime_error {
+    int code;
+    Error(int c, const std::string &what) : std::runtime_error(what), code(c) {}
+};
+// host-only error codes (continue the zigz_status numbering; shared with oracle numbering)
+enum : int {
+    ERR_UNIMPLEMENTED_INSTRUCTION = 19, ERR_UNIMPLEMENTED_SYSTEM = 20, ERR_INVALID_OP32 = 21,
+    ERR_INVALID_LOAD_FUNCT3 = 22, ERR_INVALID_STORE_FUNCT3 = 23, ERR_INVALID_BRANCH_FUNCT3 = 24,
+    ERR_PROGRAM_HASH_MISMATCH = 25, ERR_INVALID_MAGIC = 26, ERR_UNSUPPORTED_VERSION = 27,
+    ERR_FIELD_MISMATCH = 28, ERR_INVALID_DATA = 29, ERR_MAX_STEPS_EXCEEDED = 30, ERR_VM_HALTED = 31
+};
+void check(zigz_ctx *ctx, zigz_status s);  // throws Error on s != ZIGZ_OK
+
+inline F finit(uint64_t v) { return v % BABYBEAR; }  // F.init, src/core/field.zig:36-38
+
+// ---------------------------------------------------------------- FiatShamirTranscript (src/core/hash.zig:255-324)
+class FiatShamirTranscript {
+  public:
+    FiatShamirTranscript();
+    ~FiatShamirTranscript();
+    FiatShamirTranscript(const FiatShamirTranscript &) = delete;
+    FiatShamirTranscript &operator=(const FiatShamirTranscript &) = delete;
+    void reset();  // = FiatShamirTranscript.init()
+    void appendFieldElement(F e);
+    void appendFieldElements(const std::vector<F> &es);
+    void appendBytes(const void *data, size_t len);
+    void appendBytes(const char *s);
+    void appendTaggedCounter(const char *tag, uint64_t start, uint64_t count);
+    F challenge();
+
+  private:
+    zigz_transcript *t_;
+};
+
+// ---------------------------------------------------------------- Multilinear(F) (src/poly/multilinear.zig)
+struct Multilinear {
+    std::vector<F> evaluations;
+    size_t num_vars = 0;
+    zigz_ctx *ctx = nullptr;
+
+    static Multilinear init(zigz_ctx *ctx, const std::vector<F> &evals);  // :36-54
+    F eval(const std::vector<F> &point) const;                            // :110-144
+    Multilinear partialEval(F r) const;                                   // :154-180
+    F sumOverHypercube() const;                                           // :188-194
+    std::vector<F> roundPolynomial() const;                               // :205-232
+};
+
+// ---------------------------------------------------------------- sumcheck (src/proofs/)
+struct SumcheckProof {  // sumcheck_protocol.zig:24-109
+    std::vector<std::array<F, 2>> round_polynomials;
+    std::vector<F> final_point;
+    F final_eval = 0;
+    size_t num_vars = 0;
+    std::vector<uint8_t> toBytes() const;  // :76-107
+};
+F evalUnivariateCoeffs(const F *coeffs, size_t n, F x);  // :113-123 (host scalar Horner)
+struct SumcheckProver {                                  // sumcheck_prover.zig
+    static SumcheckProof prove(const Multilinear &poly);                                  // :26-91
+    static SumcheckProof proveInteractive(const Multilinear &poly, const std::vector<F> &challenges);  // :97-144
+};
+
+// ---------------------------------------------------------------- Merkle + commitments
+struct MerklePath {  // merkle_tree.zig:39-60
+    std::vector<Hash> siblings;
+    std::vector<uint8_t> directions;  // 0 = left, 1 = right
+};
+struct MerkleOpening {  // merkle_tree.zig:63-75 OpeningProof(F)
+    size_t index = 0;
+    F value = 0;
+    MerklePath path;
+};
+class SimpleMerkleTree {  // merkle_tree.zig:273-401, HashFn = SHA3Hasher
+  public:
+    static SimpleMerkleTree build(zigz_ctx *ctx, const std::vector<F> &values);
+    SimpleMerkleTree(SimpleMerkleTree &&o) noexcept;
+    SimpleMerkleTree &operator=(SimpleMerkleTree &&o) noexcept;
+    ~SimpleMerkleTree();
+    Hash getRoot() const { return root_hash; }
+    MerkleOpening open(size_t index) const;
+    static bool verify(const Hash &root, const MerkleOpening &proof);  // :362-373 (host SHA3, verifier side)
+    Hash root_hash{};
+    size_t height = 0;
+    zigz_merkle *handle() const { return t_; }
+
+  private:
+    SimpleMerkleTree() = default;
+    zigz_ctx *ctx_ = nullptr;
+    zigz_merkle *t_ = nullptr;
+};
+struct PolyOpeningProof {  // polynomial_commit.zig:42-55 OpeningProof(F)
+    std::vector<F> point;
+    F value = 0;
+    MerkleOpening merkle_proof;
+};
+struct CommitmentScheme {  // polynomial_commit.zig:58-185 (CommitmentSchemeSHA3)
+    struct Commit { Hash commitment; size_t num_vars; SimpleMerkleTree tree; };
+    static Commit commit(const Multilinear &poly);
+    static PolyOpeningProof open(const Multilinear &poly, const SimpleMerkleTree &tree, const std::vector<F> &point);
+    static bool verify(const Hash &commitment, size_t num_vars, const PolyOpeningProof &proof);
+};
+
+// ---------------------------------------------------------------- Lasso (src/lookups/)
+struct TableEntry { std::vector<F> inputs, outputs; };  // table_builder.zig:14-35
+struct DenseTable {                                      // table_builder.zig:38-84
+    std::vector<TableEntry> entries;
+    size_t num_inputs = 0, num_outputs = 0;
+};
+DenseTable buildAddTable(size_t bits);  // table_builder.zig:126-153
+DenseTable buildXorTable(size_t bits);  // :156-183
+DenseTable buildAndTable(size_t bits);  // :186-213
+struct LookupQuery { std::vector<F> inputs, expected_outputs; };  // lasso_prover.zig:65-86
+struct LassoProofFull {                                            // lasso_prover.zig:27-62
+    SumcheckProof sumcheck_proof;
+    Hash query_commitment{}, table_commitment{};
+    size_t num_lookups = 0;
+};
+struct LassoProver {
+    static LassoProofFull prove(zigz_ctx *ctx, const DenseTable &table, const std::vector<LookupQuery> &queries);  // :103-173
+    static LassoProofFull proveWithMapping(zigz_ctx *ctx, const DenseTable &table, const std::vector<LookupQuery> &queries,
+                                           const std::vector<size_t> &mapping);  // :179-205
+};
+
+// ---------------------------------------------------------------- VM (src/vm/, src/isa/)
+struct Instruction {  // rv64i.zig:111-151
+    uint8_t opcode = 0, rd = 0, funct3 = 0, rs1 = 0, rs2 = 0, funct7 = 0;
+    int64_t imm = 0;
+    static bool decode(uint32_t word, Instruction &out);  // false = error.InvalidInstruction
+};
+bool hasLookupTable(const Instruction &inst);  // getTableMetadata(inst) != null, instruction_table.zig:243-274
+struct Segment { uint64_t vaddr; std::vector<uint8_t> data; };  // src/elf.zig:8-11
+
+// One recorded step, already in witness-row order (prover.zig:376-390): the 43 raw 64-bit words whose
+// `mod p` are the witness cells of that step (witness.zig:76,112,164-170,237-239).
+constexpr size_t ROW_WORDS = 43;
+struct ExecutionTrace {  // trace.zig:16-70 (steps kept as packed rows instead of Step structs)
+    std::vector<uint64_t> rows;     // [num_steps][43] raw u64
+    std::vector<uint8_t> is_lookup; // per step
+    size_t stepCount() const { return is_lookup.size(); }
+    const uint64_t *row(size_t i) const { return rows.data() + i * ROW_WORDS; }
+};
+class VMState {  // state.zig:35-598
+  public:
+    VMState(const std::vector<uint8_t> &program, uint64_t start_pc, const std::vector<uint64_t> *input);
+    VMState(const std::vector<Segment> &segments, uint64_t entry_pc, const std::vector<uint64_t> *input);
+    ~VMState();
+    void step();                  // throws Error (InvalidInstruction is reported via `invalid_instruction`)
+    void run(size_t max_steps);   // state.zig:172-184
+    uint64_t readReg(unsigned r) const { return r ? regs_[r] : 0; }
+    void writeReg(unsigned r, uint64_t v) { if (r) regs_[r] = v; }
+    uint64_t pc = 0;
+    bool halted = false;
+    bool invalid_instruction = false;  // set when step() hit error.InvalidInstruction
+    ExecutionTrace trace;
+    std::vector<uint64_t> output_tape;
+    size_t step_count = 0;
+
+  private:
+    struct Mem;
+    Mem *mem_;
+    uint64_t regs_[32] = {0};
+    std::vector<uint64_t> input_tape_;
+    size_t input_pos_ = 0;
+    uint64_t execute(const Instruction &in, uint64_t *mem_row /*[3]: addr,value,is_read*/);
+};
+
+// ---------------------------------------------------------------- witness (src/constraints/witness.zig)
+struct Witness {  // :274-313; the 43 columns in prover order, column-major
+    size_t num_vars = 0, num_steps = 0;
+    std::vector<F> columns;  // [43][2^num_vars] canonical
+    const F *column(size_t c) const { return columns.data() + (c << num_vars); }
+    size_t size() const { return columns.size(); }
+};
+struct WitnessGenerator {
+    static Witness generate(const ExecutionTrace &trace);  // :29-61
+};
+
+// ---------------------------------------------------------------- proof structures (src/prover/proof.zig)
+struct PublicIO {  // :18-50
+    Hash program_hash{};
+    uint64_t initial_pc = 0;
+    std::optional<std::vector<uint64_t>> initial_regs;
+    uint64_t final_pc = 0;
+    std::optional<std::vector<uint64_t>> final_regs;
+    size_t num_steps = 0;
+    std::optional<std::vector<uint64_t>> outputs;
+};
+struct ProverSumcheckProof {  // :53-99 (degree known from the coefficient count)
+    size_t num_vars = 0;
+    size_t num_coeffs = 0;             // degree + 1
+    std::vector<F> round_polynomials;  // [num_vars][num_coeffs]
+    std::vector<F> final_point;
+    F final_eval = 0;
+};
+struct LassoProof {  // :102-144
+    uint32_t table_id = 0;
+    size_t num_lookups = 0;
+    ProverSumcheckProof multiset_proof;
+};
+struct CommitmentOpening {  // :147-191
+    Hash commitment{};
+    std::vector<F> point;
+    F value = 0;
+    PolyOpeningProof proof;
+};
+struct ProofMetadata { size_t num_steps = 0, num_vars = 0; uint64_t field_modulus = BABYBEAR; uint32_t version = 1; };  // :317-329
+struct Proof {  // :194-314
+    PublicIO public_io;
+    ProverSumcheckProof constraint_proof;
+    // Prover.prove emits one identical placeholder per lookup step (prover.zig:302-322: table_id = i,
+    // num_lookups = 1, 0 variables, final_eval = 0).  They are kept as a count instead of 2^20 heap
+    // objects; lookup_proofs holds only entries that are NOT of that form (deserialised foreign data).
+    // Logical list = placeholders [0, lookup_placeholders) followed by lookup_proofs.
+    size_t lookup_placeholders = 0;
+    std::vector<LassoProof> lookup_proofs;
+    size_t lookupCount() const { return lookup_placeholders + lookup_proofs.size(); }
+    LassoProof lookupAt(size_t i) const;
+    std::vector<CommitmentOpening> witness_commitments;  // 43
+    ProofMetadata metadata;
+    static Proof init(size_t num_steps);  // :224-261
+    size_t estimateSize() const;          // :279-312
+};
+enum class VerificationResult { Accept = 0, RejectInvalidSumcheck, RejectInvalidLookup, RejectInvalidCommitment, RejectInvalidPublicIO };  // :335-341
+
+// ---------------------------------------------------------------- Prover / serializer / verifier
+class Prover {  // src/prover/prover.zig
+  public:
+    Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
+    // prove(program, entry_pc, initial_regs, max_steps, segments, input), :73-226
+    Proof prove(const std::vector<uint8_t> &program, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs,
+                size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input);
+    // Steps [4/6]-[6/6] + packagePublicIO on an existing witness (the data-parallel part): the columns
+    // may be host canonical u64 (`witness`) or already resident in HBM as packed u32 (`d_cols`).
+    Proof proveWitness(const PublicIO &io_template, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                       size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs);
+    bool verbose = false;  // the reference prints progress banners unconditionally (prover.zig:82-85); off by default here
+
+  private:
+    void bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs);  // :91-110
+    void generateSumcheckProof(Proof &proof, size_t num_steps, size_t num_vars);                                     // :229-289
+    void generateLassoProofs(Proof &proof, size_t num_lookups);                                                      // :292-363
+    void generateCommitments(Proof &proof, zigz_commit_job *job, size_t num_vars);                                   // :366-467
+    zigz_ctx *ctx_;
+    uint64_t seed_;
+    FiatShamirTranscript transcript_;
+};
+
+struct BinarySerializer {  // src/prover/serialization.zig
+    static std::vector<uint8_t> serialize(const Proof &proof);             // :70-97 with an exact-size buffer
+    static Proof deserialize(const uint8_t *data, size_t len);             // :100-131
+    static size_t exactSize(const Proof &proof);
+};
+
+class Verifier {  // src/verifier/verifier.zig:26-300 (host-only: 43*v SHA3 merges)
+  public:
+    VerificationResult verify(const Proof &proof, const std::vector<uint8_t> &program);  // :49-91
+
+  private:
+    FiatShamirTranscript transcript_;
+    VerificationResult verifySumcheckProof(const ProverSumcheckProof &p);  // :182-238
+};
+
+}  // namespace zigz

@@ -1,0 +1,182 @@
+"""ctypes face of libzigz_host.so (include/zigz_host.h): the C++ mirror of the Zig host --
+Prover.prove / Verifier.verify / BinarySerializer / VMState / WitnessGenerator -- on top of the C ABI.
+Host-only entry points (VM, witness, verifier, serializer) run without a GPU; everything that proves
+needs a Context (gfx950)."""
+import ctypes as C
+import os
+
+import numpy as np
+
+from . import errors
+from ._ffi import u8p, u64p, vp
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "lib", "libzigz_host.so")
+if not os.path.exists(LIB_PATH):
+    raise ImportError(f"{LIB_PATH} is missing: build it with `python -m zigz_amd.build`")
+lib = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+
+szp = C.POINTER(C.c_size_t)
+SIGNATURES = {
+    "zigzh_last_error": (C.c_char_p, []),
+    "zigzh_free": (None, [vp]),
+    "zigzh_prove": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_uint64, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p,
+                              C.c_size_t, C.POINTER(u8p), szp, szp]),
+    "zigzh_verify": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
+    "zigzh_reserialize": (C.c_int, [C.c_char_p, C.c_size_t, C.POINTER(u8p), szp]),
+    "zigzh_execute": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p,
+                                C.c_size_t, C.POINTER(vp)]),
+    "zigzh_trace_free": (None, [vp]),
+    "zigzh_trace_num_steps": (C.c_size_t, [vp]),
+    "zigzh_trace_num_vars": (C.c_size_t, [vp]),
+    "zigzh_trace_num_lookups": (C.c_size_t, [vp]),
+    "zigzh_trace_rows": (u64p, [vp]),
+    "zigzh_trace_witness": (C.c_int, [vp, u64p]),
+    "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
+    "zigzh_vm_run": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, szp]),
+    "zigzh_sumcheck_prove_bytes": (C.c_int, [vp, u64p, C.c_size_t, u8p, szp]),
+    "zigzh_lasso_prove_table": (C.c_int, [vp, C.c_int, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u8p, szp, u8p,
+                                          u8p, szp]),
+    "zigzh_commit_open_verify": (C.c_int, [vp, u64p, C.c_size_t, u64p, C.c_size_t, u8p, u64p, u64p, C.POINTER(C.c_int)]),
+}
+for _n, (_r, _a) in SIGNATURES.items():
+    _f = getattr(lib, _n)
+    _f.restype = _r
+    _f.argtypes = _a
+
+HOST_ERROR_NAMES = {19: "UnimplementedInstruction", 20: "UnimplementedSYSTEM", 21: "InvalidOP32", 22: "InvalidLoadFunct3",
+                    23: "InvalidStoreFunct3", 24: "InvalidBranchFunct3", 25: "ProgramHashMismatch", 26: "InvalidMagicNumber",
+                    27: "UnsupportedVersion", 28: "FieldMismatch", 29: "InvalidData", 30: "MaxStepsExceeded", 31: "VMHalted"}
+VERIFICATION_RESULTS = ["Accept", "RejectInvalidSumcheck", "RejectInvalidLookup", "RejectInvalidCommitment",
+                        "RejectInvalidPublicIO"]
+
+
+def _check(rc):
+    if rc != 0:
+        msg = lib.zigzh_last_error().decode(errors="replace")
+        name = msg.split(":")[0].replace("error.", "") if msg.startswith("error.") else HOST_ERROR_NAMES.get(rc, "Error")
+        raise errors.ZigzError(rc, name, msg)
+
+
+def _u64(a):
+    a = np.ascontiguousarray(a if a is not None else [], dtype=np.uint64)
+    if a.size == 0:
+        a = np.zeros(1, dtype=np.uint64)
+    return a, a.ctypes.data_as(u64p)
+
+
+def _take(ptr, n):
+    try:
+        return C.string_at(ptr, n.value)
+    finally:
+        lib.zigzh_free(ptr)
+
+
+def prove(ctx, program, entry_pc=0x1000, initial_regs=None, max_steps=1 << 20, inputs=None):
+    """Prover(F).prove(...) then BinarySerializer.serialize -> (proof bytes, num_steps)."""
+    ir, irp = _u64(initial_regs)
+    inp, inpp = _u64(inputs)
+    out, n, ns = u8p(), C.c_size_t(), C.c_size_t()
+    _check(lib.zigzh_prove(ctx.h, bytes(program), len(program), entry_pc, irp,
+                           0 if initial_regs is None else len(initial_regs), 0 if initial_regs is None else 1, max_steps,
+                           inpp if inputs is not None else None, 0 if inputs is None else len(inputs),
+                           C.byref(out), C.byref(n), C.byref(ns)))
+    return _take(out, n), ns.value
+
+
+def verify(proof, program):
+    """BinarySerializer.deserialize + Verifier.verify -> VerificationResult name (host only)."""
+    res = C.c_int(-1)
+    _check(lib.zigzh_verify(bytes(proof), len(proof), bytes(program), len(program), C.byref(res)))
+    return VERIFICATION_RESULTS[res.value]
+
+
+def reserialize(proof):
+    out, n = u8p(), C.c_size_t()
+    _check(lib.zigzh_reserialize(bytes(proof), len(proof), C.byref(out), C.byref(n)))
+    return _take(out, n)
+
+
+class Trace:
+    """An executed program ([1/6] of Prover.prove): packed trace rows + public IO."""
+
+    def __init__(self, program, entry_pc=0x1000, initial_regs=None, max_steps=1 << 20, inputs=None):
+        ir, irp = _u64(initial_regs)
+        inp, inpp = _u64(inputs)
+        h = vp()
+        _check(lib.zigzh_execute(bytes(program), len(program), entry_pc, irp,
+                                 0 if initial_regs is None else len(initial_regs), 0 if initial_regs is None else 1,
+                                 max_steps, inpp if inputs is not None else None, 0 if inputs is None else len(inputs),
+                                 C.byref(h)))
+        self.h = h
+        self.num_steps = lib.zigzh_trace_num_steps(h)
+        self.num_vars = lib.zigzh_trace_num_vars(h)
+        self.num_lookups = lib.zigzh_trace_num_lookups(h)
+
+    def __del__(self):
+        if getattr(self, "h", None):
+            lib.zigzh_trace_free(self.h)
+            self.h = None
+
+    def rows(self):
+        p = lib.zigzh_trace_rows(self.h)
+        return np.ctypeslib.as_array(p, shape=(self.num_steps, 43)).copy()
+
+    def witness(self):
+        """WitnessGenerator.generate: [43, 2^nv] canonical uint64 (host)."""
+        cols = np.zeros((43, 1 << self.num_vars), dtype=np.uint64)
+        _check(lib.zigzh_trace_witness(self.h, cols.ctypes.data_as(u64p)))
+        return cols
+
+    def witness_to_device(self, ctx, d_cols, stride):
+        _check(lib.zigzh_trace_witness_dev(self.h, ctx.h, vp(d_cols), stride))
+
+    def prove(self, ctx, d_cols=None, stride=0, want_bytes=True):
+        out, n = u8p(), C.c_size_t()
+        _check(lib.zigzh_prove_trace(self.h, ctx.h, vp(d_cols) if d_cols else None, stride, 1 if want_bytes else 0,
+                                     C.byref(out), C.byref(n)))
+        return _take(out, n) if want_bytes else None
+
+
+def vm_run(program, entry_pc, max_steps):
+    """VMState.init + run(max_steps) -> (status, regs[32], pc, steps) (host only)."""
+    regs = np.zeros(32, dtype=np.uint64)
+    pc, steps = C.c_uint64(), C.c_size_t()
+    rc = lib.zigzh_vm_run(bytes(program), len(program), entry_pc, max_steps, regs.ctypes.data_as(u64p), C.byref(pc),
+                          C.byref(steps))
+    return rc, [int(x) for x in regs], pc.value, steps.value
+
+
+def sumcheck_prove_bytes(ctx, evals):
+    a, ap = _u64(evals)
+    n = len(evals)
+    nv = max(n.bit_length() - 1, 0)
+    out = np.zeros((3 * nv + 2) * 8, dtype=np.uint8)
+    ln = C.c_size_t()
+    _check(lib.zigzh_sumcheck_prove_bytes(ctx.h, ap, n, out.ctypes.data_as(u8p), C.byref(ln)))
+    return out[: ln.value].tobytes()
+
+
+def lasso_prove_table(ctx, kind, bits, queries, mapping=None):
+    q, qp = _u64(np.asarray(queries, dtype=np.uint64).reshape(-1))
+    nq = len(queries)
+    m, mp = _u64(mapping)
+    out = np.zeros(4096, dtype=np.uint8)
+    ln, nl = C.c_size_t(), C.c_size_t()
+    qc = np.zeros(32, dtype=np.uint8)
+    tc = np.zeros(32, dtype=np.uint8)
+    _check(lib.zigzh_lasso_prove_table(ctx.h, kind, bits, qp, nq, mp if mapping is not None else None,
+                                       0 if mapping is None else len(mapping), out.ctypes.data_as(u8p), C.byref(ln),
+                                       qc.ctypes.data_as(u8p), tc.ctypes.data_as(u8p), C.byref(nl)))
+    return out[: ln.value].tobytes(), qc.tobytes(), tc.tobytes(), nl.value
+
+
+def commit_open_verify(ctx, evals, point):
+    a, ap = _u64(evals)
+    q, qp = _u64(point)
+    root = np.zeros(32, dtype=np.uint8)
+    val, idx, ok = C.c_uint64(), C.c_uint64(), C.c_int()
+    _check(lib.zigzh_commit_open_verify(ctx.h, ap, len(evals), qp, len(point), root.ctypes.data_as(u8p), C.byref(val),
+                                        C.byref(idx), C.byref(ok)))
+    return root.tobytes(), val.value, idx.value, bool(ok.value)
