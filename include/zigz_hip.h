@@ -203,9 +203,14 @@ typedef struct zigz_kernel_stats {
     double merkle_build_us;   /* all Keccak leaf + level launches of the last commit_begin */
     double eval_us;           /* all MLE fold / eval launches of the last commit_open_all */
     double path_us;           /* path gather */
-    double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch */
+    double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch, or all binds of the last sumcheck */
     uint64_t bind_launches;
     uint64_t keccak_permutations;
+    /* vector-path MLE bind launches (kernel k_bind_vec) of the last eval / sumcheck / bind call, each timed
+     * with its own HIP event pair: total device time, launch count, algorithmic bytes (6 B per table element) */
+    double bind_vec_us;
+    uint64_t bind_vec_launches;
+    uint64_t bind_vec_bytes;
 } zigz_kernel_stats;
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);

@@ -72,35 +72,50 @@ static const uint64_t KECCAK_RC[24] = {
     0x000000008000808bull, 0x800000000000008bull, 0x8000000000008089ull, 0x8000000000008003ull,
     0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800aull, 0x800000008000000aull,
     0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
-static const int KECCAK_ROT[24] = {1, 3, 6, 10, 15, 21, 28, 36, 45, 55, 2, 14,
-                                   27, 41, 56, 8, 25, 43, 62, 18, 39, 61, 20, 44};
-static const int KECCAK_PIL[24] = {10, 7, 11, 17, 18, 3, 5, 16, 8, 21, 24, 4,
-                                   15, 23, 19, 13, 12, 2, 20, 14, 22, 9, 6, 1};
-
 static inline uint64_t rotl64(uint64_t x, int n) { return (x << n) | (x >> (64 - n)); }
 
+static void le64(uint64_t v, uint8_t out[8]) {
+    for (int b = 0; b < 8; b++) out[b] = (uint8_t)(v >> (8 * b));
+}
+static uint64_t rd64(const uint8_t *in) {
+    uint64_t v = 0;
+    for (int b = 0; b < 8; b++) v |= (uint64_t)in[b] << (8 * b);
+    return v;
+}
+static uint32_t rd32(const uint8_t *in) {
+    return (uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24);
+}
+
+
+
+/* One round with theta, rho+pi and chi fully unrolled (lanes st[x + 5y]); rotation offsets and the pi
+ * lane permutation are the FIPS 202 tables written out: b[y + 5((2x+3y)%5)] = rot(a[x+5y], r[x][y]). */
+#define TH(i) (st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20])
+#define RP(dst, src, rot) b[dst] = rotl64(st[src] ^ d[(src) % 5], rot)
+#define CH(y) do { \
+        st[y] = b[y] ^ (~b[y + 1] & b[y + 2]); st[y + 1] = b[y + 1] ^ (~b[y + 2] & b[y + 3]); \
+        st[y + 2] = b[y + 2] ^ (~b[y + 3] & b[y + 4]); st[y + 3] = b[y + 3] ^ (~b[y + 4] & b[y]); \
+        st[y + 4] = b[y + 4] ^ (~b[y] & b[y + 1]); } while (0)
+
 static void keccak_f1600(uint64_t st[25]) {
+    uint64_t b[25], c[5], d[5];
     for (int round = 0; round < 24; round++) {
-        uint64_t bc[5], t;
-        for (int i = 0; i < 5; i++) bc[i] = st[i] ^ st[i + 5] ^ st[i + 10] ^ st[i + 15] ^ st[i + 20];
-        for (int i = 0; i < 5; i++) {
-            t = bc[(i + 4) % 5] ^ rotl64(bc[(i + 1) % 5], 1);
-            for (int j = 0; j < 25; j += 5) st[j + i] ^= t;
-        }
-        t = st[1];
-        for (int i = 0; i < 24; i++) {
-            int j = KECCAK_PIL[i];
-            uint64_t b = st[j];
-            st[j] = rotl64(t, KECCAK_ROT[i]);
-            t = b;
-        }
-        for (int j = 0; j < 25; j += 5) {
-            for (int i = 0; i < 5; i++) bc[i] = st[j + i];
-            for (int i = 0; i < 5; i++) st[j + i] ^= (~bc[(i + 1) % 5]) & bc[(i + 2) % 5];
-        }
+        c[0] = TH(0); c[1] = TH(1); c[2] = TH(2); c[3] = TH(3); c[4] = TH(4);
+        d[0] = c[4] ^ rotl64(c[1], 1); d[1] = c[0] ^ rotl64(c[2], 1); d[2] = c[1] ^ rotl64(c[3], 1);
+        d[3] = c[2] ^ rotl64(c[4], 1); d[4] = c[3] ^ rotl64(c[0], 1);
+        b[0] = st[0] ^ d[0];
+        RP(10, 1, 1);  RP(20, 2, 62); RP(5, 3, 28);  RP(15, 4, 27);
+        RP(16, 5, 36); RP(1, 6, 44);  RP(11, 7, 6);  RP(21, 8, 55); RP(6, 9, 20);
+        RP(7, 10, 3);  RP(17, 11, 10); RP(2, 12, 43); RP(12, 13, 25); RP(22, 14, 39);
+        RP(23, 15, 41); RP(8, 16, 45); RP(18, 17, 15); RP(3, 18, 21); RP(13, 19, 8);
+        RP(14, 20, 18); RP(24, 21, 2); RP(9, 22, 61); RP(19, 23, 56); RP(4, 24, 14);
+        CH(0); CH(5); CH(10); CH(15); CH(20);
         st[0] ^= KECCAK_RC[round];
     }
 }
+#undef TH
+#undef RP
+#undef CH
 
 #define SHA3_RATE 136 /* SHA3-256: r = 1088 bits */
 
@@ -136,32 +151,24 @@ void orc_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]) {
     sha3_final(&c, out);
 }
 
-static void le64(uint64_t v, uint8_t out[8]) {
-    for (int b = 0; b < 8; b++) out[b] = (uint8_t)(v >> (8 * b));
-}
-static uint64_t rd64(const uint8_t *in) {
-    uint64_t v = 0;
-    for (int b = 0; b < 8; b++) v |= (uint64_t)in[b] << (8 * b);
-    return v;
-}
-static uint32_t rd32(const uint8_t *in) {
-    return (uint32_t)in[0] | ((uint32_t)in[1] << 8) | ((uint32_t)in[2] << 16) | ((uint32_t)in[3] << 24);
-}
-
 /* hashFieldElementSHA3, hash.zig:135-147: SHA3-256 over the 8 LE bytes of the canonical value */
 void orc_hash_leaf(uint64_t value, uint8_t out[32]) {
-    uint8_t b[8];
-    le64(value, b);
-    orc_sha3_256(b, 8, out);
+    uint64_t st[25] = {0};
+    st[0] = value;                    /* 8 message bytes, little endian */
+    st[1] = 0x06;                     /* SHA3 domain/pad byte at offset 8 */
+    st[16] = 0x8000000000000000ull;   /* final pad bit at byte 135 */
+    keccak_f1600(st);
+    for (int i = 0; i < 4; i++) le64(st[i], out + 8 * i);
 }
 
 /* mergeHashesSHA3, hash.zig:187-195 */
 void orc_hash_internal(const uint8_t l[32], const uint8_t r[32], uint8_t out[32]) {
-    sha3_ctx c;
-    sha3_init(&c);
-    sha3_update(&c, l, 32);
-    sha3_update(&c, r, 32);
-    sha3_final(&c, out);
+    uint64_t st[25] = {0};
+    for (int i = 0; i < 4; i++) { st[i] = rd64(l + 8 * i); st[4 + i] = rd64(r + 8 * i); }
+    st[8] = 0x06;
+    st[16] = 0x8000000000000000ull;
+    keccak_f1600(st);
+    for (int i = 0; i < 4; i++) le64(st[i], out + 8 * i);
 }
 
 /* ======================================================================== */
@@ -1122,6 +1129,20 @@ int orc_generate_commitments(uint64_t p, orc_transcript *t, const uint64_t *cols
     tr_append_str(t, "OPENING_CLAIMS"); /* phase 4, :463-466 */
     for (int c = 0; c < 43; c++) orc_tr_append_field(t, values[c]);
     return ORC_OK;
+}
+
+int orc_commit_column_literal(uint64_t p, const uint64_t *col, size_t nv, const uint64_t *point, uint8_t root[32],
+                              uint64_t *value, uint64_t *index, uint8_t *siblings, uint8_t *dirs, uint64_t *leaf) {
+    size_t N = (size_t)1 << nv;
+    int rc = orc_merkle_build(col, N, root, NULL); /* prover.zig:406 */
+    if (rc) return rc;
+    uint64_t v1 = 0, v2 = 0;
+    rc = orc_mle_eval(p, col, N, point, nv, &v1); /* prover.zig:427 */
+    if (rc) return rc;
+    rc = orc_commit_open(p, col, N, point, nv, &v2, index, siblings, dirs, leaf); /* prover.zig:431 */
+    if (rc) return rc;
+    *value = v1;
+    return v1 == v2 ? ORC_OK : ORC_ERR_PROTOCOL_ERROR;
 }
 
 /* eval by MSB-first folds with the point reversed: exact field arithmetic => the value of :110-144 */

@@ -197,6 +197,12 @@ int orc_prove(uint64_t p, const uint8_t *program, size_t program_len, uint64_t e
 int orc_generate_commitments(uint64_t p, orc_transcript *t, const uint64_t *cols, size_t nv,
                              uint8_t *roots, uint64_t *points, uint64_t *values, uint64_t *indices,
                              uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);
+/* The per-column work of generateCommitments exactly as the reference does it (prover.zig:405-431):
+ * Scheme.commit (Merkle build) + poly.eval(point) + Scheme.open (eval AGAIN + recompute-on-open path).
+ * Used by bench.py's cpu_baseline leg on a bounded sample of columns. */
+int orc_commit_column_literal(uint64_t p, const uint64_t *col, size_t nv, const uint64_t *point,
+                              uint8_t root[32], uint64_t *value, uint64_t *index, uint8_t *siblings,
+                              uint8_t *dirs, uint64_t *leaf);
 /* Same outputs, but with fold-based eval and keep-levels Merkle (for timing comparisons / big sizes). */
 int orc_generate_commitments_fast(uint64_t p, orc_transcript *t, const uint64_t *cols, size_t nv,
                              uint8_t *roots, uint64_t *points, uint64_t *values, uint64_t *indices,

@@ -85,6 +85,7 @@ _sig("orc_prove", C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, C.c_uint64, u64p,
      u64p, C.c_size_t, C.POINTER(u8p), szp, szp)
 _sig("orc_generate_commitments", C.c_int, C.c_uint64, C.c_void_p, u64p, C.c_size_t, u8p, u64p, u64p, u64p, u64p, u8p, u8p)
 _sig("orc_generate_commitments_fast", C.c_int, C.c_uint64, C.c_void_p, u64p, C.c_size_t, u8p, u64p, u64p, u64p, u64p, u8p, u8p)
+_sig("orc_commit_column_literal", C.c_int, C.c_uint64, u64p, C.c_size_t, u64p, u8p, u64p, u64p, u8p, u8p, u64p)
 _sig("orc_verify", C.c_int, C.c_uint64, C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int))
 _sig("orc_proof_size", C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t)
 _sig("orc_free", None, C.c_void_p)
@@ -364,6 +365,19 @@ def generate_commitments(p, tr, cols, fast=False):
     return dict(roots=roots[: NCOL * 32].reshape(NCOL, 32), points=points[: NCOL * nv].reshape(NCOL, nv),
                 values=values[:NCOL], indices=indices[:NCOL], leaves=leaves[:NCOL],
                 siblings=sib[: NCOL * nv * 32].reshape(NCOL, nv, 32), dirs=dirs[: NCOL * nv].reshape(NCOL, nv))
+
+
+def commit_column_literal(p, col, point):
+    """Literal per-column reference work (commit + eval + open with its second eval and level rebuild)."""
+    a, ap = _u64(col)
+    nv = len(point)
+    q, qp = _u64(point) if nv else _out_u64(1)
+    root, rp = _out_u8(32)
+    sib, sp = _out_u8(32 * nv)
+    dirs, dp = _out_u8(nv)
+    val, idx, leaf = C.c_uint64(), C.c_uint64(), C.c_uint64()
+    _chk(lib.orc_commit_column_literal(p, ap, nv, qp, rp, C.byref(val), C.byref(idx), sp, dp, C.byref(leaf)))
+    return root.tobytes(), val.value, idx.value, sib[: 32 * nv].tobytes(), dirs[:nv].tobytes(), leaf.value
 
 
 def verify(p, proof, program):

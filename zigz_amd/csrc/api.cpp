@@ -33,6 +33,9 @@ struct zigz_ctx {
     uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
     bool timing;
     hipEvent_t ev[6];
+    hipEvent_t pool[2 * 64];  // per-launch event pairs for k_bind_vec timing
+    int pool_used;
+    uint64_t pool_bytes;
     zigz_kernel_stats stats;
     zigz_commit_job *active_job;
 };
@@ -151,6 +154,8 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
+    for (int i = 0; st == ZIGZ_OK && i < 128; i++)
+        if (fail(hipEventCreate(&ctx->pool[i]))) st = ZIGZ_ERR_HIP;
     if (st != ZIGZ_OK) {
         zigz_ctx_destroy(ctx);
         return st;
@@ -171,6 +176,8 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
+    for (int i = 0; i < 128; i++)
+        if (ctx->pool[i]) (void)hipEventDestroy(ctx->pool[i]);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -315,15 +322,50 @@ static zigz_status timed_end(zigz_ctx *ctx, int ev, double *us_out) {
     return ZIGZ_OK;
 }
 
+// launch_bind with a private HIP event pair around every vector-path launch (timing mode only)
+static zigz_status bind_launch(zigz_ctx *ctx, const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride,
+                               size_t half, size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums) {
+    const bool rec = ctx->timing && ctx->pool_used < 64 && bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride);
+    if (rec) HIPCHK(ctx, hipEventRecord(ctx->pool[2 * ctx->pool_used], ctx->stream));
+    launch_bind(d_in, in_stride, d_out, out_stride, half, ncols, r_m, d_r_m, d_sums, ctx->stream);
+    if (rec) {
+        HIPCHK(ctx, hipEventRecord(ctx->pool[2 * ctx->pool_used + 1], ctx->stream));
+        ctx->pool_used++;
+        ctx->pool_bytes += (uint64_t)ncols * half * 2 * 6;  // table of 2*half u32: read 8*half B, write 4*half B
+    }
+    return ZIGZ_OK;
+}
+static void bind_pool_reset(zigz_ctx *ctx) {
+    ctx->pool_used = 0;
+    ctx->pool_bytes = 0;
+}
+// call after the stream has been synchronised past the last recorded launch
+static zigz_status bind_pool_collect(zigz_ctx *ctx) {
+    if (!ctx->timing) return ZIGZ_OK;
+    double us = 0;
+    for (int i = 0; i < ctx->pool_used; i++) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventSynchronize(ctx->pool[2 * i + 1]));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pool[2 * i], ctx->pool[2 * i + 1]));
+        us += (double)ms * 1000.0;
+    }
+    ctx->stats.bind_vec_us = us;
+    ctx->stats.bind_vec_launches = (uint64_t)ctx->pool_used;
+    ctx->stats.bind_vec_bytes = ctx->pool_bytes;
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out) {
     if (!ctx || !d_in || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
     if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+    bind_pool_reset(ctx);
     CHK(timed_begin(ctx, 0));
-    launch_bind(d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, nullptr, ctx->stream);
+    CHK(bind_launch(ctx, d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, nullptr));
     HIPCHK(ctx, hipGetLastError());
     CHK(timed_end(ctx, 0, &ctx->stats.bind_us));
+    CHK(bind_pool_collect(ctx));
     ctx->stats.bind_launches = 1;
     return ZIGZ_OK;
 }
@@ -335,10 +377,12 @@ extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_i
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
     if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 16, ctx->stream));
+    bind_pool_reset(ctx);
     CHK(timed_begin(ctx, 0));
-    launch_bind(d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, ctx->d_sums, ctx->stream);
+    CHK(bind_launch(ctx, d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, ctx->d_sums));
     HIPCHK(ctx, hipGetLastError());
     CHK(timed_end(ctx, 0, &ctx->stats.bind_us));
+    CHK(bind_pool_collect(ctx));
     ctx->stats.bind_launches = 1;
     uint64_t s[2];
     CHK(read_u64(ctx, ctx->d_sums, 2, s));
@@ -375,14 +419,14 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
     const size_t a_elems = ncols * (N / 2), b_elems = ncols * (N / 4 ? N / 4 : 1);
     CHK(ws_get(ctx, WS_FOLD, (a_elems + b_elems) * 4, &fold));
     uint32_t *bufA = (uint32_t *)fold, *bufB = bufA + a_elems;
+    bind_pool_reset(ctx);
     const uint32_t *src = d_cols;
     size_t src_stride = col_stride, len = N;
     for (size_t k = 0; k < nv; k++) {
         uint32_t *dst = (k % 2 == 0) ? bufA : bufB;
         size_t half = len / 2;
         size_t dst_stride = half < 4 ? 4 : half;  // keep 16-byte alignment of every column
-        launch_bind(src, src_stride, dst, dst_stride, half, ncols, 0, (const uint32_t *)d_rt + k * ncols, nullptr,
-                    ctx->stream);
+        CHK(bind_launch(ctx, src, src_stride, dst, dst_stride, half, ncols, 0, (const uint32_t *)d_rt + k * ncols, nullptr));
         src = dst;
         src_stride = dst_stride;
         len = half;
@@ -427,6 +471,7 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
     uint64_t s[2];
     CHK(read_u64(ctx, ctx->d_sums, 2, s));
     Transcript tr;  // fresh transcript per sumcheck, sumcheck_protocol.zig:161
+    bind_pool_reset(ctx);
     const uint32_t *cur = d_in;
     size_t len = n;
     double bind_us = 0;
@@ -449,7 +494,7 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
         const bool last = (len == 2);
         unsigned long long *d_s = last ? nullptr : ctx->d_sums + 2 * (round + 1);
         if (ctx->timing) CHK(timed_begin(ctx, 0));
-        launch_bind(cur, len, dst, len / 2, len / 2, 1, host_to_mont(ch), nullptr, d_s, ctx->stream);
+        CHK(bind_launch(ctx, cur, len, dst, len / 2, len / 2, 1, host_to_mont(ch), nullptr, d_s));
         HIPCHK(ctx, hipGetLastError());
         if (ctx->timing) {
             double us = 0;
@@ -468,6 +513,7 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
     if (ctx->timing) {
         ctx->stats.bind_us = bind_us;
         ctx->stats.bind_launches = nv;
+        CHK(bind_pool_collect(ctx));
     }
     return ZIGZ_OK;
 }
@@ -810,6 +856,7 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
     CHK(open_paths(ctx, job->d_tree, job->N, (unsigned)nv, job->d_cols, job->col_stride, idx.data(), ncols, siblings,
                    dirs, leaves));
     for (size_t c = 0; c < ncols; c++) values[c] = hv[c];
+    CHK(bind_pool_collect(ctx));
     job->state = 2;
     return ZIGZ_OK;
 }

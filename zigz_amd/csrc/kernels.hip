@@ -111,11 +111,14 @@ __global__ __launch_bounds__(TPB) void k_bind_small(const uint32_t *__restrict__
     if (SUMS) block_add2(s0, s1, sums + 2 * col);
 }
 
+bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride) {
+    return half >= (with_sums ? 2 * VEC_MIN_HALF : VEC_MIN_HALF) && (in_stride % 4 == 0) && (out_stride % 4 == 0);
+}
+
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
                  size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s) {
     if (half == 0 || ncols == 0) return;
-    const bool vec = half >= (d_sums ? 2 * VEC_MIN_HALF : VEC_MIN_HALF) && (in_stride % 4 == 0) &&
-                     (out_stride % 4 == 0);
+    const bool vec = bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride);
     if (vec) {
         dim3 grid((unsigned)(half / (4 * TPB * UNROLL)), (unsigned)ncols);
         if (d_sums)
