@@ -101,18 +101,21 @@ def main():
 
     proof = None
     for _ in range(args.warmup):
-        proof = trace.prove(ctx, d_cols, N, want_bytes=True)
+        proof = trace.prove(ctx, d_cols, N, want_bytes="borrow")
     ctx.enable_timing(True)
     bind_us = bind_bytes = bind_launches = 0
     merkle_us = eval_us = 0.0
     perms = 0
+    phases = {}
     sync_all()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        proof = trace.prove(ctx, d_cols, N, want_bytes=True)
+        proof = trace.prove(ctx, d_cols, N, want_bytes="borrow")
         st = ctx.stats()
         bind_us += st["bind_vec_us"]; bind_bytes += st["bind_vec_bytes"]; bind_launches += st["bind_vec_launches"]
         merkle_us += st["merkle_build_us"]; eval_us += st["eval_us"]; perms += st["keccak_permutations"]
+        for k, v in host.last_timings().items():
+            phases[k] = phases.get(k, 0.0) + v
     sync_all()
     dt = time.perf_counter() - t0
     if torch is not None:
@@ -126,6 +129,7 @@ def main():
         total_steps = float(trace.num_steps)
 
     if rank == 0:
+        proof = proof.tobytes()
         assert host.verify(proof, prog) == "Accept"
         ach = (bind_bytes / 1e9) / (bind_us / 1e6) if bind_us > 0 else 0.0
         traffic = None
@@ -155,6 +159,7 @@ def main():
                          "algorithmic_bytes_per_launch": bind_bytes / max(bind_launches, 1)},
             "kernels": {"merkle_build_ms_per_step": merkle_us / args.steps / 1e3,
                         "eval_ms_per_step": eval_us / args.steps / 1e3,
+                        "host_phase_ms_per_step": {k: v / args.steps * 1e3 for k, v in phases.items()},
                         "keccak_gperm_per_s": (perms / 1e9) / (merkle_us / 1e6) if merkle_us else 0.0,
                         "keccak_frac_of_int_valu_peak": ((perms * KECCAK_OPS) / (merkle_us / 1e6)) / VALU_PEAK_OPS if merkle_us else 0.0},
         }

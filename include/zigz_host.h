@@ -19,6 +19,9 @@ typedef struct zigzh_trace zigzh_trace; /* an executed program: packed trace row
 
 const char *zigzh_last_error(void);
 void zigzh_free(void *p);
+/* wall-clock seconds of the phases of the last zigzh_prove_trace on this thread: commit_begin, sumcheck transcript,
+ * lasso transcript, wait for roots, roots+challenges, open_all, packaging, serialize */
+void zigzh_last_timings(double out[8]);
 
 /* Prover(F).prove(program, entry_pc, initial_regs, max_steps, null, input) + BinarySerializer.serialize
  * src/prover/prover.zig:73-226, src/prover/serialization.zig:70-97 */
@@ -44,7 +47,10 @@ int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out);
 /* builds the 43 witness columns directly in HBM (packed u32, column stride `stride` elements) */
 int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride);
 /* steps [4/6]..[6/6] + packagePublicIO for an executed trace; d_cols == NULL: host witness is generated and
- * uploaded; otherwise the resident columns are used.  want_bytes: also serialize ("ZIGZ" v1). */
+ * uploaded; otherwise the resident columns are used.  want_bytes: 0 = proof struct only; 1 = also serialize ("ZIGZ"
+ * v1) into a malloc'd buffer the caller frees with zigzh_free; 2 = serialize with the early sections written on a
+ * helper thread underneath the transcript, into a thread-local buffer the caller BORROWS (valid until the next
+ * call on this thread; do not free). */
 int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int want_bytes,
                       uint8_t **proof_out, size_t *proof_len);
 

@@ -50,6 +50,8 @@ def test_prove_golden_bytes(ctx, i):
         t.witness_to_device(ctx, d, stride)
         assert t.prove(ctx, d, stride) == proof
         assert t.prove(ctx) == proof
+        assert t.prove(ctx, d, stride, want_bytes="borrow").tobytes() == proof  # overlapped serialisation path
+        assert t.prove(ctx, want_bytes="borrow").tobytes() == proof
     finally:
         ctx.dev_free(d)
 

@@ -138,3 +138,24 @@ def test_host_hashes_and_transcript():
     assert [a.challenge() for _ in range(4)] == [b.challenge(P) for _ in range(4)]
     t = Transcript(); t.append_field(3); t.append_field(4)
     assert [str(t.challenge()), str(t.challenge())] == G["transcript_kat"]["challenges_babybear"]
+
+
+def test_host_keccak_dispatch_matches_portable_code():
+    """The AVX-512 single-state Keccak-f[1600] used by the host sponge (when the CPU has it) must equal the
+    portable implementation and the oracle's on random states."""
+    from zigz_amd._ffi import lib, u64p
+    rng = np.random.default_rng(5)
+    assert lib.zigz_host_keccak_impl() in (b"avx512f", b"bmi2", b"scalar")
+    for _ in range(200):
+        st = rng.integers(0, 2**64, 25, dtype=np.uint64)
+        outs = []
+        for which in (0, 1, 2, 3):  # picked, scalar, bmi2, avx512f (unsupported ones fall back to the picked one)
+            a = st.copy()
+            lib.zigz_host_keccak_permute(a.ctypes.data_as(u64p), which)
+            outs.append(a)
+        assert all(np.array_equal(outs[0], o) for o in outs[1:])
+    # one-block SHA3 through the dispatched permutation == hashlib
+    import hashlib
+    for n in (0, 8, 64, 135):
+        m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
+        assert sha3_256(m) == hashlib.sha3_256(m).digest()

@@ -53,6 +53,8 @@ def build_hip(force=False):
         ("kernels.hip", [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
         ("api.cpp", [hipcc, "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
         ("host_hash.cpp", ["g++", "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
+        ("host_keccak_avx512.cpp", ["g++", "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
+        ("host_keccak_bmi.cpp", ["g++", "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
     ]
     for src, cmd in units:
         s = os.path.join(CSRC, src)
@@ -75,7 +77,7 @@ def build_host(force=False):
         return None
     so = os.path.join(LIB, "libzigz_host.so")
     if force or _newer(so, srcs + _headers() + [os.path.join(LIB, "libzigz_hip.so")]):
-        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-shared", f"-I{INC}", f"-I{CSRC}", "-o", so] + srcs +
+        _run(["g++", "-O3", "-std=c++17", "-fPIC", "-pthread", "-shared", f"-I{INC}", f"-I{CSRC}", "-o", so] + srcs +
              [f"-L{LIB}", "-lzigz_hip", "-Wl,-rpath,$ORIGIN"])
     return so
 

@@ -966,3 +966,5 @@ extern "C" void zigz_transcript_append_tagged_counter(zigz_transcript *t, const 
 extern "C" uint64_t zigz_transcript_challenge(zigz_transcript *t) { return t ? t->t.challenge() : 0; }
 extern "C" void zigz_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]) { sha3_256(data, len, out); }
 extern "C" void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]) { sha256(data, len, out); }
+extern "C" const char *zigz_host_keccak_impl(void) { return host_keccak_impl(); }
+extern "C" void zigz_host_keccak_permute(uint64_t state[25], int which) { host_keccak_permute(state, which); }

@@ -1,4 +1,5 @@
 // extern "C" face of the host mirror (include/zigz_host.h) for ctypes callers.
+#include <chrono>
 #include <cstdlib>
 #include <cstring>
 #include <memory>
@@ -9,6 +10,8 @@
 using namespace zigz;
 
 static thread_local std::string g_err;
+static thread_local double g_timings[8] = {0};
+static thread_local std::vector<uint8_t> g_proof;  // borrowed-proof buffer of zigzh_prove_trace(want_bytes = 2)
 
 template <class Fn>
 static int guard(Fn &&fn) {
@@ -36,6 +39,7 @@ static uint8_t *dup_bytes(const std::vector<uint8_t> &v) {
 
 extern "C" const char *zigzh_last_error(void) { return g_err.c_str(); }
 extern "C" void zigzh_free(void *p) { free(p); }
+extern "C" void zigzh_last_timings(double out[8]) { memcpy(out, g_timings, sizeof(g_timings)); }
 
 struct zigzh_trace {
     PublicIO io;
@@ -106,16 +110,31 @@ extern "C" int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint
         Prover prover(ctx, 0);
         Proof proof;
         const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
+        if (want_bytes == 2) {  // overlapped serialisation into a reusable thread-local buffer (borrowed by the caller)
+            if (d_cols) {
+                prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
+            } else {
+                Witness w = WitnessGenerator::generate(t->trace);
+                prover.proveWitnessToBytes(t->io, t->num_lookups, &w, nullptr, 0, w.num_vars, ir, g_proof);
+            }
+            memcpy(g_timings, prover.timings, sizeof(g_timings));
+            *proof_out = g_proof.data();
+            *proof_len = g_proof.size();
+            return;
+        }
         if (d_cols) {
             proof = prover.proveWitness(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir);
         } else {
             Witness w = WitnessGenerator::generate(t->trace);
             proof = prover.proveWitness(t->io, t->num_lookups, &w, nullptr, 0, w.num_vars, ir);
         }
-        if (want_bytes) {
+        memcpy(g_timings, prover.timings, sizeof(g_timings));
+        if (want_bytes == 1) {
+            auto t0 = std::chrono::steady_clock::now();
             std::vector<uint8_t> b = BinarySerializer::serialize(proof);
             *proof_out = dup_bytes(b);
             *proof_len = b.size();
+            g_timings[7] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
         }
     });
 }

@@ -2,13 +2,19 @@
 // src/prover/prover.zig with its exact Fiat-Shamir schedule.  The 43-column
 // Merkle/eval/open work runs on the GPU through the zigz_commit_* job of the C ABI and overlaps the
 // sequential O(L) transcript absorption of the Lasso placeholders.
+#include <chrono>
 #include <cstdio>
 #include <cstring>
 #include <memory>
+#include <thread>
 
 #include "zigz_host.hpp"
 
 namespace zigz {
+
+static double now_s() {
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
 
 static size_t log2_int_ceil(size_t n) {  // std.math.log2_int_ceil
     size_t l = 0;
@@ -105,7 +111,10 @@ void Prover::generateLassoProofs(Proof &proof, size_t num_lookups) {  // :292-36
 void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) {  // :366-467
     const size_t NC = ZIGZ_NUM_COLUMNS;
     std::vector<uint8_t> roots(NC * 32);
+    double t0 = now_s();
     check(ctx_, zigz_commit_roots(job, roots.data()));                 // PHASE 1 results
+    timings[3] = now_s() - t0;
+    t0 = now_s();
     transcript_.appendBytes("POLY_COMMITMENTS");                       // PHASE 2, :413-416
     for (size_t c = 0; c < NC; c++) {
         memcpy(proof.witness_commitments[c].commitment.data(), roots.data() + 32 * c, 32);
@@ -116,8 +125,12 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
         for (size_t j = 0; j < nv; j++) points[c * nv + j] = transcript_.challenge();
     std::vector<F> values(NC), indices(NC), leaves(NC);
     std::vector<uint8_t> sib(NC * nv * 32 + 1), dirs(NC * nv + 1);
+    timings[4] = now_s() - t0;
+    t0 = now_s();
     check(ctx_, zigz_commit_open_all(job, points.data(), values.data(), indices.data(), leaves.data(), sib.data(),
                                      dirs.data()));                    // :427-431
+    timings[5] = now_s() - t0;
+    t0 = now_s();
     for (size_t c = 0; c < NC; c++) {
         CommitmentOpening &o = proof.witness_commitments[c];
         o.point.assign(points.begin() + c * nv, points.begin() + (c + 1) * nv);
@@ -135,10 +148,23 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
     }
     transcript_.appendBytes("OPENING_CLAIMS");                         // PHASE 4, :463-466
     for (size_t c = 0; c < NC; c++) transcript_.appendFieldElement(proof.witness_commitments[c].value);
+    timings[6] = now_s() - t0;
 }
 
 Proof Prover::proveWitness(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                            size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs) {
+    return proveWitnessImpl(io, num_lookups, witness, d_cols, d_col_stride, num_vars, initial_regs, nullptr);
+}
+
+void Prover::proveWitnessToBytes(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                                 size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
+                                 std::vector<uint8_t> &out) {
+    (void)proveWitnessImpl(io, num_lookups, witness, d_cols, d_col_stride, num_vars, initial_regs, &out);
+}
+
+Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                               size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
+                               std::vector<uint8_t> *bytes_out) {
     // transcript binding of the public inputs (prover.zig:91-110)
     bindPublicInputs(io.program_hash, io.initial_pc, initial_regs);
     const size_t num_steps = io.num_steps;
@@ -148,22 +174,46 @@ Proof Prover::proveWitness(const PublicIO &io, size_t num_lookups, const Witness
     // [6/6 phase 1] Merkle builds do not depend on the transcript: start them first, asynchronously on
     // the GPU, so they run underneath the sequential host absorption of steps 4 and 5.
     zigz_commit_job *job = nullptr;
+    double t0 = now_s();
     if (witness)
         check(ctx_, zigz_commit_begin(ctx_, witness->columns.data(), ZIGZ_NUM_COLUMNS, (size_t)1 << num_vars, num_vars, &job));
     else
         check(ctx_, zigz_commit_begin_dev(ctx_, d_cols, ZIGZ_NUM_COLUMNS, d_col_stride, num_vars, &job));
+    timings[0] = now_s() - t0;
+    // packagePublicIO (:514-559) only copies VM results; doing it here lets the serialiser start early
+    proof.public_io = io;
+    if (initial_regs) proof.public_io.initial_regs = *initial_regs;
+    else proof.public_io.initial_regs.reset();
+    std::thread writer;
     try {
+        t0 = now_s();
         generateSumcheckProof(proof, num_steps, num_vars);  // [4/6]
+        timings[1] = now_s() - t0;
+        proof.lookup_placeholders = num_lookups;
+        if (bytes_out) {
+            // everything up to the 43 openings is final now: write it while the transcript absorbs step 5
+            size_t total = BinarySerializer::prefixSize(proof) + ZIGZ_NUM_COLUMNS * (68 + 41 * num_vars);
+            if (bytes_out->size() != total) bytes_out->resize(total);
+            uint8_t *buf = bytes_out->data();
+            const Proof *pp = &proof;
+            writer = std::thread([pp, buf] { BinarySerializer::writePrefix(*pp, buf); });
+        }
+        t0 = now_s();
         generateLassoProofs(proof, num_lookups);            // [5/6]
+        timings[2] = now_s() - t0;
         generateCommitments(proof, job, num_vars);          // [6/6]
     } catch (...) {
+        if (writer.joinable()) writer.join();
         zigz_commit_end(job);
         throw;
     }
     zigz_commit_end(job);
-    proof.public_io = io;  // packagePublicIO, :514-559
-    if (initial_regs) proof.public_io.initial_regs = *initial_regs;
-    else proof.public_io.initial_regs.reset();
+    if (bytes_out) {
+        t0 = now_s();
+        writer.join();
+        BinarySerializer::writeCommitments(proof, bytes_out->data() + BinarySerializer::prefixSize(proof));
+        timings[7] = now_s() - t0;
+    }
     return proof;
 }
 
@@ -202,14 +252,6 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
 
 // ---------------------------------------------------------------- BinarySerializer (serialization.zig)
 namespace {
-struct W {
-    std::vector<uint8_t> &b;
-    size_t pos = 0;
-    void bytes(const void *d, size_t n) { memcpy(b.data() + pos, d, n); pos += n; }
-    void u8(uint8_t v) { b[pos++] = v; }
-    void u32(uint32_t v) { bytes(&v, 4); }
-    void u64(uint64_t v) { bytes(&v, 8); }
-};
 struct R {
     const uint8_t *b;
     size_t len, pos = 0;
@@ -225,7 +267,23 @@ struct R {
 size_t sumcheck_size(const ProverSumcheckProof &s) { return (s.round_polynomials.size() + s.final_point.size() + 1) * 8; }
 }  // namespace
 
-size_t BinarySerializer::exactSize(const Proof &p) {
+namespace {
+struct RawW {  // unchecked writer into a caller-sized buffer
+    uint8_t *b;
+    size_t pos = 0;
+    void bytes(const void *d, size_t n) { memcpy(b + pos, d, n); pos += n; }
+    void u8(uint8_t v) { b[pos++] = v; }
+    void u32(uint32_t v) { bytes(&v, 4); }
+    void u64(uint64_t v) { bytes(&v, 8); }
+};
+void write_sumcheck(RawW &w, const ProverSumcheckProof &s) {  // writeConstraintProof, :296-311
+    for (F c : s.round_polynomials) w.u64(c);
+    for (F c : s.final_point) w.u64(c);
+    w.u64(s.final_eval);
+}
+}  // namespace
+
+size_t BinarySerializer::prefixSize(const Proof &p) {
     size_t size = 32;  // header
     size += 32 + 8 + 8 + 4 + 4 + 8 + 4;
     if (p.public_io.initial_regs) size += p.public_io.initial_regs->size() * 8;
@@ -234,22 +292,18 @@ size_t BinarySerializer::exactSize(const Proof &p) {
     size += sumcheck_size(p.constraint_proof);
     size += 4 + p.lookup_placeholders * 24;
     for (auto &l : p.lookup_proofs) size += 16 + sumcheck_size(l.multiset_proof);
+    return size;
+}
+
+size_t BinarySerializer::exactSize(const Proof &p) {
+    size_t size = prefixSize(p);
     for (auto &o : p.witness_commitments)
         size += 32 + o.point.size() * 8 + 8 + (8 + 8 + 8 + 4 + o.proof.merkle_proof.path.siblings.size() * 33);
     return size;
 }
 
-static void write_sumcheck(W &w, const ProverSumcheckProof &s) {  // writeConstraintProof, :296-311
-    for (F c : s.round_polynomials) w.u64(c);
-    for (F c : s.final_point) w.u64(c);
-    w.u64(s.final_eval);
-}
-
-std::vector<uint8_t> BinarySerializer::serialize(const Proof &p) {
-    // The reference sizes a fixed buffer from an estimate that under-counts (SURVEY s0 fact 9); this
-    // writes the same layout into an exact-size buffer.
-    std::vector<uint8_t> buf(exactSize(p));
-    W w{buf};
+void BinarySerializer::writePrefix(const Proof &p, uint8_t *buf) {
+    RawW w{buf};
     w.bytes("ZIGZ", 4);  // writeHeader, :175-182
     w.u32(1);
     w.u64(p.metadata.field_modulus);
@@ -269,11 +323,26 @@ std::vector<uint8_t> BinarySerializer::serialize(const Proof &p) {
     regs(p.public_io.outputs);
     write_sumcheck(w, p.constraint_proof);
     w.u32((uint32_t)p.lookupCount());  // writeLassoProofs, :333-344
-    for (size_t i = 0; i < p.lookup_placeholders; i++) { w.u32((uint32_t)i); w.u64(1); w.u32(0); w.u64(0); }
+    {   // placeholders: u32 table_id = i, u64 num_lookups = 1, u32 num_vars = 0, u64 final_eval = 0
+        uint8_t *q = buf + w.pos;
+        uint8_t rec[24] = {0};
+        rec[4] = 1;
+        const size_t n = p.lookup_placeholders;
+        for (size_t i = 0; i < n; i++, q += 24) {
+            memcpy(q, rec, 24);
+            uint32_t id = (uint32_t)i;
+            memcpy(q, &id, 4);
+        }
+        w.pos += n * 24;
+    }
     for (auto &l : p.lookup_proofs) {
         w.u32(l.table_id); w.u64(l.num_lookups); w.u32((uint32_t)l.multiset_proof.num_vars);
         write_sumcheck(w, l.multiset_proof);
     }
+}
+
+void BinarySerializer::writeCommitments(const Proof &p, uint8_t *buf) {
+    RawW w{buf};
     for (auto &o : p.witness_commitments) {  // writeWitnessCommitments + writeMerkleProof, :374-429
         w.bytes(o.commitment.data(), 32);
         for (F c : o.point) w.u64(c);
@@ -282,10 +351,17 @@ std::vector<uint8_t> BinarySerializer::serialize(const Proof &p) {
         w.u64(o.proof.merkle_proof.index);
         w.u64(o.proof.merkle_proof.value);
         w.u32((uint32_t)o.proof.merkle_proof.path.siblings.size());
-        for (auto &s : o.proof.merkle_proof.path.siblings) w.bytes(s.data(), 32);
+        for (auto &sib : o.proof.merkle_proof.path.siblings) w.bytes(sib.data(), 32);
         for (uint8_t d : o.proof.merkle_proof.path.directions) w.u8(d ? 1 : 0);
     }
-    if (w.pos != buf.size()) throw Error(ZIGZ_ERR_PROTOCOL_ERROR, "serializer size mismatch");
+}
+
+std::vector<uint8_t> BinarySerializer::serialize(const Proof &p) {
+    // The reference sizes a fixed buffer from an estimate that under-counts (SURVEY s0 fact 9); this
+    // writes the same layout into an exact-size buffer.
+    std::vector<uint8_t> buf(exactSize(p));
+    writePrefix(p, buf.data());
+    writeCommitments(p, buf.data() + prefixSize(p));
     return buf;
 }
 

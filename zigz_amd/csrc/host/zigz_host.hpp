@@ -257,6 +257,14 @@ class Prover {  // src/prover/prover.zig
     // may be host canonical u64 (`witness`) or already resident in HBM as packed u32 (`d_cols`).
     Proof proveWitness(const PublicIO &io_template, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                        size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs);
+    // proveWitness + BinarySerializer.serialize with the serialisation of everything but the 43 openings
+    // overlapped (helper thread) with the sequential transcript; `out` is resized to the exact proof size.
+    void proveWitnessToBytes(const PublicIO &io_template, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                             size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
+                             std::vector<uint8_t> &out);
+    // wall-clock seconds of the phases of the last proveWitness: 0 commit_begin, 1 sumcheck transcript,
+    // 2 lasso transcript, 3 wait for roots, 4 absorb roots + challenges, 5 open_all, 6 packaging
+    double timings[8] = {0};
     bool verbose = false;  // the reference prints progress banners unconditionally (prover.zig:82-85); off by default here
 
   private:
@@ -264,6 +272,9 @@ class Prover {  // src/prover/prover.zig
     void generateSumcheckProof(Proof &proof, size_t num_steps, size_t num_vars);                                     // :229-289
     void generateLassoProofs(Proof &proof, size_t num_lookups);                                                      // :292-363
     void generateCommitments(Proof &proof, zigz_commit_job *job, size_t num_vars);                                   // :366-467
+    Proof proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
+                           size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
+                           std::vector<uint8_t> *bytes_out);
     zigz_ctx *ctx_;
     uint64_t seed_;
     FiatShamirTranscript transcript_;
@@ -273,6 +284,12 @@ struct BinarySerializer {  // src/prover/serialization.zig
     static std::vector<uint8_t> serialize(const Proof &proof);             // :70-97 with an exact-size buffer
     static Proof deserialize(const uint8_t *data, size_t len);             // :100-131
     static size_t exactSize(const Proof &proof);
+    // The same byte layout written in two independent parts, so the large part that is known early (header,
+    // public IO, constraint proof, Lasso placeholders) can be written on a helper thread while the main
+    // thread is still inside the transcript: [0, prefixSize) then [prefixSize, exactSize).
+    static size_t prefixSize(const Proof &proof);
+    static void writePrefix(const Proof &proof, uint8_t *buf);
+    static void writeCommitments(const Proof &proof, uint8_t *buf_at_prefix_end);
 };
 
 class Verifier {  // src/verifier/verifier.zig:26-300 (host-only: 43*v SHA3 merges)

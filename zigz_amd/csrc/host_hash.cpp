@@ -1,14 +1,69 @@
 #include "host_hash.hpp"
 
+#include <stdlib.h>
 #include <string.h>
+
+#include <chrono>
 
 #include "field.hpp"
 #include "keccak.hpp"  // host build: the same round macro as the device kernels
 
 namespace zk {
 
-static inline void permute(uint64_t st[25]) {
+void keccak_f1600_avx512(uint64_t st[25]);  // host_keccak_avx512.cpp
+bool cpu_has_avx512f();
+void keccak_f1600_bmi(uint64_t st[25]);     // host_keccak_bmi.cpp
+bool cpu_has_bmi2();
+
+static void permute_scalar(uint64_t st[25]) {
     for (int r = 0; r < 24; r++) ZK_KECCAK_ROUND(st, KECCAK_RC[r]);
+}
+
+// The sponge is the sequential critical path of a proof, and which single-state permutation is fastest
+// depends on the micro-architecture (the AVX-512 plane form wins on Intel server cores, the scalar/BMI
+// forms on Zen 5), so the choice is made once at load time by timing each supported variant (~1 ms).
+namespace {
+struct Variant { const char *name; void (*fn)(uint64_t *); };
+Variant pick_variant() {
+    Variant cands[3];
+    int n = 0;
+    cands[n++] = {"scalar", permute_scalar};
+    if (cpu_has_bmi2()) cands[n++] = {"bmi2", keccak_f1600_bmi};
+    if (cpu_has_avx512f()) cands[n++] = {"avx512f", keccak_f1600_avx512};
+    const char *force = getenv("ZIGZ_HOST_KECCAK");
+    if (force)
+        for (int i = 0; i < n; i++)
+            if (strcmp(force, cands[i].name) == 0) return cands[i];
+    int best = 0;
+    double best_t = 1e30;
+    for (int i = 0; i < n; i++) {
+        uint64_t st[25];
+        for (int k = 0; k < 25; k++) st[k] = 0x9E3779B97F4A7C15ull * (uint64_t)(k + 1);
+        for (int k = 0; k < 200; k++) cands[i].fn(st);  // warm up
+        double t = 1e30;
+        for (int rep = 0; rep < 3; rep++) {
+            auto t0 = std::chrono::steady_clock::now();
+            for (int k = 0; k < 1000; k++) cands[i].fn(st);
+            double dt = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            if (dt < t) t = dt;
+        }
+        volatile uint64_t sink = st[0];
+        (void)sink;
+        if (t < best_t) { best_t = t; best = i; }
+    }
+    return cands[best];
+}
+const Variant g_variant = pick_variant();
+}  // namespace
+
+static inline void permute(uint64_t st[25]) { g_variant.fn(st); }
+
+const char *host_keccak_impl() { return g_variant.name; }
+void host_keccak_permute(uint64_t st[25], int which) {
+    if (which == 1) permute_scalar(st);
+    else if (which == 2 && cpu_has_bmi2()) keccak_f1600_bmi(st);
+    else if (which == 3 && cpu_has_avx512f()) keccak_f1600_avx512(st);
+    else g_variant.fn(st);
 }
 
 void Sha3_256::reset() {
@@ -16,25 +71,33 @@ void Sha3_256::reset() {
     pos_ = 0;
 }
 
+static inline void xor_into(uint8_t *dst, const uint8_t *src, size_t n) {
+    size_t i = 0;
+    for (; i + 8 <= n; i += 8) {
+        uint64_t a, b;
+        memcpy(&a, dst + i, 8);
+        memcpy(&b, src + i, 8);
+        a ^= b;
+        memcpy(dst + i, &a, 8);
+    }
+    for (; i < n; i++) dst[i] ^= src[i];
+}
+
+// Absorb: XOR message bytes into the byte image of the state (little-endian host), block by block.
 void Sha3_256::update(const uint8_t *data, size_t len) {
     constexpr size_t RATE = 136;
-    // byte-wise until lane aligned
-    while (len && (pos_ & 7)) {
-        st_[pos_ >> 3] ^= (uint64_t)(*data++) << (8 * (pos_ & 7));
-        len--;
-        if (++pos_ == RATE) { permute(st_); pos_ = 0; }
-    }
-    while (len >= 8) {
-        uint64_t w;
-        memcpy(&w, data, 8);  // little-endian host
-        st_[pos_ >> 3] ^= w;
-        data += 8; len -= 8; pos_ += 8;
-        if (pos_ == RATE) { permute(st_); pos_ = 0; }
-    }
+    uint8_t *sb = reinterpret_cast<uint8_t *>(st_);
     while (len) {
-        st_[pos_ >> 3] ^= (uint64_t)(*data++) << (8 * (pos_ & 7));
-        len--;
-        if (++pos_ == RATE) { permute(st_); pos_ = 0; }
+        size_t n = RATE - pos_;
+        if (n > len) n = len;
+        xor_into(sb + pos_, data, n);
+        pos_ += n;
+        data += n;
+        len -= n;
+        if (pos_ == RATE) {
+            permute(st_);
+            pos_ = 0;
+        }
     }
 }
 
@@ -76,9 +139,26 @@ uint64_t Transcript::challenge() {
 }
 
 void Transcript::append_tagged_counter(const uint8_t *tag, size_t tag_len, uint64_t start, uint64_t count) {
-    for (uint64_t k = 0; k < count; k++) {
-        h_.update(tag, tag_len);
-        h_.update_le64((start + k) % (uint64_t)P);
+    // materialise the records (tag || LE64((start+k) mod p)) in chunks and absorb them in bulk
+    constexpr size_t CHUNK = 512;
+    const size_t rec = tag_len + 8;
+    if (rec > 256) {
+        for (uint64_t k = 0; k < count; k++) { h_.update(tag, tag_len); h_.update_le64((start + k) % (uint64_t)P); }
+        return;
+    }
+    uint8_t buf[CHUNK * 256 > 0 ? CHUNK * 64 : 1];
+    const size_t per = sizeof(buf) / rec;
+    uint64_t k = 0;
+    while (k < count) {
+        size_t m = count - k < per ? (size_t)(count - k) : per;
+        uint8_t *q = buf;
+        for (size_t j = 0; j < m; j++, q += rec) {
+            memcpy(q, tag, tag_len);
+            uint64_t v = (start + k + j) % (uint64_t)P;
+            memcpy(q + tag_len, &v, 8);
+        }
+        h_.update(buf, m * rec);
+        k += m;
     }
 }
 

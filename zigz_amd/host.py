@@ -20,6 +20,7 @@ szp = C.POINTER(C.c_size_t)
 SIGNATURES = {
     "zigzh_last_error": (C.c_char_p, []),
     "zigzh_free": (None, [vp]),
+    "zigzh_last_timings": (None, [C.POINTER(C.c_double)]),
     "zigzh_prove": (C.c_int, [vp, C.c_char_p, C.c_size_t, C.c_uint64, u64p, C.c_size_t, C.c_int, C.c_size_t, u64p,
                               C.c_size_t, C.POINTER(u8p), szp, szp]),
     "zigzh_verify": (C.c_int, [C.c_char_p, C.c_size_t, C.c_char_p, C.c_size_t, C.POINTER(C.c_int)]),
@@ -71,6 +72,17 @@ def _take(ptr, n):
         return C.string_at(ptr, n.value)
     finally:
         lib.zigzh_free(ptr)
+
+
+TIMING_NAMES = ["commit_begin", "sumcheck_transcript", "lasso_transcript", "wait_roots", "roots_challenges", "open_all",
+                "packaging", "serialize"]
+
+
+def last_timings():
+    """Per-phase wall-clock seconds of the last Trace.prove on this thread."""
+    a = (C.c_double * 8)()
+    lib.zigzh_last_timings(a)
+    return dict(zip(TIMING_NAMES, list(a)))
 
 
 def prove(ctx, program, entry_pc=0x1000, initial_regs=None, max_steps=1 << 20, inputs=None):
@@ -133,10 +145,27 @@ class Trace:
         _check(lib.zigzh_trace_witness_dev(self.h, ctx.h, vp(d_cols), stride))
 
     def prove(self, ctx, d_cols=None, stride=0, want_bytes=True):
+        """want_bytes: True -> proof bytes; False -> None (proof struct only);
+        "borrow" -> BorrowedProof (overlapped serialisation into a library-owned buffer, no copy)."""
         out, n = u8p(), C.c_size_t()
-        _check(lib.zigzh_prove_trace(self.h, ctx.h, vp(d_cols) if d_cols else None, stride, 1 if want_bytes else 0,
-                                     C.byref(out), C.byref(n)))
+        mode = 2 if want_bytes == "borrow" else (1 if want_bytes else 0)
+        _check(lib.zigzh_prove_trace(self.h, ctx.h, vp(d_cols) if d_cols else None, stride, mode, C.byref(out), C.byref(n)))
+        if mode == 2:
+            return BorrowedProof(out, n.value)
         return _take(out, n) if want_bytes else None
+
+
+class BorrowedProof:
+    """Proof bytes living in a library-owned buffer (valid until the next prove on this thread)."""
+
+    def __init__(self, ptr, n):
+        self.ptr, self.n = ptr, n
+
+    def __len__(self):
+        return self.n
+
+    def tobytes(self):
+        return C.string_at(self.ptr, self.n)
 
 
 def vm_run(program, entry_pc, max_steps):
