@@ -153,3 +153,32 @@ def test_mirror_classes(ctx):
     pt = O.splitmix64_field(10, 6)
     root, val, idx, ok = host.commit_open_verify(ctx, ev, pt)
     assert ok and root == O.merkle_build(ev)[0] and val == O.mle_eval(P, ev, pt) and idx == int(pt[0]) % 64
+
+
+def test_concurrent_proofs_on_one_gpu(ctx):
+    """Several proofs share one GPU (one host thread + one context/stream each, as bench.py --batch does):
+    every proof must still be byte-identical to the oracle's."""
+    import threading
+    import zigz_amd
+    from zigz_amd import host
+    jobs = [programs.fibonacci(40 + 7 * k) for k in range(4)] + [(programs.mixed_loop(30 + k), None) for k in range(2)]
+    expect = [O.prove(P, p, 0x1000, None, 1 << 20, i)[0] for p, i in jobs]
+    got = [None] * len(jobs)
+    errs = []
+
+    def work(k):
+        try:
+            c = zigz_amd.Context(0)
+            for _ in range(3):
+                t = host.Trace(jobs[k][0], 0x1000, None, 1 << 20, jobs[k][1])
+                got[k] = t.prove(c, want_bytes="borrow").tobytes()
+                assert got[k] == expect[k]
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    th = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    assert not errs, errs
+    assert got == expect

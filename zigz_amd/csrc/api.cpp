@@ -64,6 +64,16 @@ static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
         if (s_ != ZIGZ_OK) return s_;      \
     } while (0)
 
+// HIP's current device is per thread: make the context's device current for the calling thread (multi-GPU
+// ranks that see every device, helper threads, hosts that also drive torch on another device).
+#define ZIGZ_ENTER(ctx)                                                              \
+    do {                                                                             \
+        if (ctx) {                                                                   \
+            int d_ = -1;                                                             \
+            if (hipGetDevice(&d_) != hipSuccess || d_ != (ctx)->device) (void)hipSetDevice((ctx)->device); \
+        }                                                                            \
+    } while (0)
+
 static bool is_pow2(size_t n) { return n && !(n & (n - 1)); }
 static unsigned log2_floor(size_t n) { unsigned l = 0; while (n > 1) { n >>= 1; l++; } return l; }
 static size_t ceil_pow2(size_t n) { size_t v = 1; while (v < n) v <<= 1; return v; }
@@ -166,6 +176,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
 }
 
 extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->stream) (void)hipStreamSynchronize(ctx->stream);
@@ -185,6 +196,7 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
 extern "C" const char *zigz_last_error(const zigz_ctx *ctx) { return ctx ? ctx->err : "no context"; }
 
 extern "C" zigz_status zigz_ctx_set_stream(zigz_ctx *ctx, void *hip_stream) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -193,18 +205,21 @@ extern "C" zigz_status zigz_ctx_set_stream(zigz_ctx *ctx, void *hip_stream) {
 extern "C" void *zigz_ctx_get_stream(zigz_ctx *ctx) { return ctx ? (void *)ctx->stream : nullptr; }
 
 extern "C" zigz_status zigz_ctx_synchronize(zigz_ctx *ctx) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ZIGZ_OK;
 }
 
 extern "C" zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
     HIPCHK(ctx, hipSetDevice(ctx->device));
     HIPCHK(ctx, hipMalloc(d_out, bytes ? bytes : 16));
     return ZIGZ_OK;
 }
 extern "C" zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     HIPCHK(ctx, hipFree(d_ptr));
@@ -212,11 +227,13 @@ extern "C" zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr) {
 }
 
 extern "C" zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     ctx->timing = enable != 0;
     return ZIGZ_OK;
 }
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
     *out = ctx->stats;
     return ZIGZ_OK;
@@ -259,16 +276,19 @@ static zigz_status download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, u
 }
 
 extern "C" zigz_status zigz_dev_upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || (n && (!h_in || !d_out))) return ZIGZ_ERR_INVALID_ARGUMENT;
     return upload_u64(ctx, h_in, n, d_out, false);
 }
 extern "C" zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || (n && (!h_in || !d_out))) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(upload_u64(ctx, h_in, n, d_out, true));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ZIGZ_OK;
 }
 extern "C" zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || (n && (!h_out || !d_in))) return ZIGZ_ERR_INVALID_ARGUMENT;
     return download_u64(ctx, d_in, n, h_out);
 }
@@ -298,6 +318,7 @@ static zigz_status dev_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
 }
 
 extern "C" zigz_status zigz_dev_mle_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t half_sums[2]) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !half_sums) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     uint64_t s[2];
@@ -356,6 +377,7 @@ static zigz_status bind_pool_collect(zigz_ctx *ctx) {
 }
 
 extern "C" zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
@@ -372,6 +394,7 @@ extern "C" zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, si
 
 extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r,
                                               uint32_t *d_out, uint64_t half_sums[2]) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !d_out || !half_sums) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
@@ -439,6 +462,7 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
 
 extern "C" zigz_status zigz_dev_mle_eval(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *point,
                                          size_t point_len, uint64_t *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !out || (point_len && !point)) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (point_len != log2_floor(n)) return ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES;
@@ -521,6 +545,7 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
 extern "C" zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
                                                const uint64_t *fixed_challenges, uint64_t *rounds, uint64_t *point,
                                                uint64_t *final_eval) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
@@ -537,6 +562,7 @@ static zigz_status stage_in(zigz_ctx *ctx, const uint64_t *in, size_t n, uint32_
 }
 
 extern "C" zigz_status zigz_mle_bind(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t r, uint64_t *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
@@ -551,6 +577,7 @@ extern "C" zigz_status zigz_mle_bind(zigz_ctx *ctx, const uint64_t *in, size_t n
 }
 
 extern "C" zigz_status zigz_mle_round_poly(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t out[2]) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
@@ -566,6 +593,7 @@ extern "C" zigz_status zigz_mle_round_poly(zigz_ctx *ctx, const uint64_t *in, si
 }
 
 extern "C" zigz_status zigz_mle_sum(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (!in || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -579,6 +607,7 @@ extern "C" zigz_status zigz_mle_sum(zigz_ctx *ctx, const uint64_t *in, size_t n,
 
 extern "C" zigz_status zigz_mle_eval(zigz_ctx *ctx, const uint64_t *in, size_t n, const uint64_t *point,
                                      size_t point_len, uint64_t *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (point_len != log2_floor(n)) return ZIGZ_ERR_WRONG_NUMBER_OF_VARIABLES;
@@ -590,6 +619,7 @@ extern "C" zigz_status zigz_mle_eval(zigz_ctx *ctx, const uint64_t *in, size_t n
 
 extern "C" zigz_status zigz_sumcheck_prove(zigz_ctx *ctx, const uint64_t *in, size_t n, uint64_t *rounds,
                                            uint64_t *point, uint64_t *final_eval) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
@@ -602,6 +632,7 @@ extern "C" zigz_status zigz_sumcheck_prove(zigz_ctx *ctx, const uint64_t *in, si
 extern "C" zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint64_t *in, size_t n,
                                                        const uint64_t *challenges, size_t n_challenges,
                                                        uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES;
@@ -640,6 +671,7 @@ struct zigz_merkle {
 };
 
 extern "C" void zigz_merkle_destroy(zigz_ctx *ctx, zigz_merkle *t) {
+    ZIGZ_ENTER(ctx);
     if (!t) return;
     if (ctx) (void)hipStreamSynchronize(ctx->stream);
     if (t->d_vals) (void)hipFree(t->d_vals);
@@ -649,6 +681,7 @@ extern "C" void zigz_merkle_destroy(zigz_ctx *ctx, zigz_merkle *t) {
 
 extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values, size_t n, uint8_t root[32],
                                           size_t *height, zigz_merkle **out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n == 0) return ZIGZ_ERR_EMPTY_VALUES;                      // merkle_tree.zig:284
     if (n > ((size_t)1 << 40)) return ZIGZ_ERR_TOO_MANY_VALUES;    // merkle_tree.zig:287 (device-size cap)
@@ -710,6 +743,7 @@ static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad,
 
 extern "C" zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *t, size_t index, uint8_t *siblings,
                                         uint8_t *dirs, uint64_t *leaf_value) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !t || !leaf_value) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (index >= t->n_values) return ZIGZ_ERR_INDEX_OUT_OF_BOUNDS;  // merkle_tree.zig:325 (values.len)
     if (t->height && (!siblings || !dirs)) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -720,6 +754,7 @@ extern "C" zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *t, siz
 extern "C" zigz_status zigz_commit_open(zigz_ctx *ctx, const uint64_t *evals, size_t n, const zigz_merkle *tree,
                                         const uint64_t *point, size_t point_len, uint64_t *value, uint64_t *index,
                                         uint8_t *siblings, uint8_t *dirs, uint64_t *leaf_value) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !tree || !value || !index || !leaf_value) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(mle_check(n));
     if (point_len != log2_floor(n)) return ZIGZ_ERR_POINT_DIMENSION_MISMATCH;  // polynomial_commit.zig:92-94
@@ -794,6 +829,7 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
 
 extern "C" zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
                                              size_t nv, zigz_commit_job **out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !d_cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (col_stride < ((size_t)1 << nv)) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -802,6 +838,7 @@ extern "C" zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_co
 
 extern "C" zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols, size_t col_stride,
                                          size_t nv, zigz_commit_job **out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
     const size_t N = (size_t)1 << nv;
@@ -820,6 +857,7 @@ extern "C" zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, si
 }
 
 extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
+    if (job) ZIGZ_ENTER(job->ctx);
     if (!job || !roots) return ZIGZ_ERR_INVALID_ARGUMENT;
     zigz_ctx *ctx = job->ctx;
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
@@ -836,6 +874,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
 
 extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, uint64_t *values,
                                             uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs) {
+    if (job) ZIGZ_ENTER(job->ctx);
     if (!job || !values || !indices || !leaves) return ZIGZ_ERR_INVALID_ARGUMENT;
     zigz_ctx *ctx = job->ctx;
     if (job->state != 1) return ZIGZ_ERR_BAD_STATE;
@@ -862,6 +901,7 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
 }
 
 extern "C" void zigz_commit_end(zigz_commit_job *job) {
+    if (job) ZIGZ_ENTER(job->ctx);
     if (!job) return;
     zigz_ctx *ctx = job->ctx;
     (void)hipStreamSynchronize(ctx->stream);
@@ -879,6 +919,7 @@ static void flat_commit(const uint32_t *ev, size_t n, uint8_t out[32]) {  // com
 
 extern "C" zigz_status zigz_lasso_fingerprints(zigz_ctx *ctx, const uint64_t *rows_in, size_t rows, size_t width,
                                                uint64_t *out) {
+    ZIGZ_ENTER(ctx);
     if (!ctx || !rows_in || !out || width == 0) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (rows == 0) return ZIGZ_OK;
     uint32_t *d_rows;
@@ -894,6 +935,7 @@ extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, si
                                         size_t n_queries, size_t n_in, size_t n_out, size_t *nv_out, uint64_t *rounds,
                                         uint64_t *point, uint64_t *final_eval, uint8_t query_commitment[32],
                                         uint8_t table_commitment[32]) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_queries == 0) return ZIGZ_ERR_NO_QUERIES;  // :108-110
     const size_t w = n_in + n_out;
@@ -934,6 +976,7 @@ extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64
                                                      size_t *nv_out, uint64_t *rounds, uint64_t *point,
                                                      uint64_t *final_eval, uint8_t query_commitment[32],
                                                      uint8_t table_commitment[32]) {
+    ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_queries != n_mapping) return ZIGZ_ERR_MAPPING_LENGTH_MISMATCH;  // :185-187
     const size_t w = n_in + n_out;
