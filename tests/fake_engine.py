@@ -1,0 +1,69 @@
+"""Oracle-backed stand-ins for zigz_amd.shard's compute objects, so the N > 1 partition / exchange logic
+can be exercised with gloo on CPU (the product engines need a GPU).  Test infrastructure only."""
+import numpy as np
+
+import oracle_lib as O
+
+P = O.P_BB
+
+
+class _FakeJob:
+    def __init__(self, cols, nv):
+        self.cols = np.ascontiguousarray(cols, dtype=np.uint64)
+        self.nv = nv
+
+    def roots(self):
+        return np.stack([np.frombuffer(O.merkle_build(c)[0], dtype=np.uint8) for c in self.cols])
+
+    def open_all(self, points):
+        nc, nv = len(self.cols), self.nv
+        out = dict(values=np.zeros(nc, dtype=np.uint64), indices=np.zeros(nc, dtype=np.uint64),
+                   leaves=np.zeros(nc, dtype=np.uint64), siblings=np.zeros((nc, nv, 32), dtype=np.uint8),
+                   dirs=np.zeros((nc, nv), dtype=np.uint8))
+        for k in range(nc):
+            val, idx, sib, dirs, leaf = O.commit_open(P, self.cols[k], [int(x) for x in points[k]])
+            out["values"][k], out["indices"][k], out["leaves"][k] = val, idx, leaf
+            out["siblings"][k] = np.frombuffer(sib, dtype=np.uint8).reshape(nv, 32)
+            out["dirs"][k] = np.frombuffer(dirs, dtype=np.uint8)
+        return out
+
+    def end(self):
+        pass
+
+
+class FakeEngine:
+    def begin(self, local_cols, ncols, nv):
+        assert len(local_cols) == ncols
+        return _FakeJob(local_cols, nv)
+
+
+class FakeOps:
+    def upload(self, values):
+        return np.array(values, dtype=np.uint64)
+
+    def download(self, t, n):
+        return t[:n]
+
+    def half_sums(self, t, n):
+        h = max(n // 2, 1)
+        return [int(t[:h].sum(dtype=np.uint64) % np.uint64(P)), int(t[h:n].sum(dtype=np.uint64) % np.uint64(P)) if n > 1 else 0]
+
+    def bind(self, t, n, r):
+        return np.array(O.mle_partial_eval(P, t[:n], r), dtype=np.uint64)
+
+    def bind_sums(self, t, n, r):
+        o = self.bind(t, n, r)
+        return o, self.half_sums(o, n // 2)
+
+    def sumcheck_tail(self, t, n, tr):
+        rounds, point = [], []
+        cur = t[:n]
+        while n > 1:
+            c = O.mle_round_poly(P, cur)
+            rounds += c
+            tr.append_field(c[0]); tr.append_field(c[1])
+            ch = tr.challenge()
+            point.append(ch)
+            cur = self.bind(cur, n, ch)
+            n //= 2
+        return rounds, point, int(cur[0])

@@ -1,0 +1,66 @@
+"""-m gpu: the sharded paths of zigz_amd.shard on the real HIP engines, world_size 2 (both ranks on the one
+GPU of the test box, gloo for the tiny exchanges), against the unsharded oracle."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+
+pytestmark = pytest.mark.gpu
+P = O.P_BB
+torch = pytest.importorskip("torch")
+import torch.distributed as dist  # noqa: E402
+import torch.multiprocessing as mp  # noqa: E402
+
+
+def _worker(rank, world, port, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import zigz_amd
+    from zigz_amd import shard
+    ctx = zigz_amd.Context(0)
+    try:
+        nv = 11
+        cols = O.splitmix64_field(177, 43 * (1 << nv)).reshape(43, 1 << nv)
+        c0, c1 = shard.column_partition(43, world)[rank]
+        tr = zigz_amd.Transcript(); tr.append_bytes(b"prefix")
+        res = shard.generate_commitments_sharded(shard.GpuEngine(ctx), tr, cols[c0:c1], nv, dist)
+        res["next_challenge"] = tr.challenge()
+        table = O.splitmix64_field(188, 1 << 16)
+        ops = shard.GpuOps(ctx)
+        local = ops.upload(shard.interleave_rows(table, rank, world))
+        r, p, fe = shard.sumcheck_prove_row_sharded(ops, local, 1 << 16, dist, zigz_amd.Transcript)
+        ops.close()
+        q.put((rank, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()},
+               dict(rounds=r.tolist(), point=p.tolist(), fe=fe)))
+    finally:
+        ctx.close()
+        dist.destroy_process_group()
+
+
+def test_sharded_paths_world2_on_gpu():
+    world = 2
+    s = socket.socket(); s.bind(("127.0.0.1", 0)); port = s.getsockname()[1]; s.close()
+    mpc = mp.get_context("spawn")
+    q = mpc.Queue()
+    procs = [mpc.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    [p.start() for p in procs]
+    outs = [q.get(timeout=300) for _ in range(world)]
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    nv = 11
+    cols = O.splitmix64_field(177, 43 * (1 << nv)).reshape(43, 1 << nv)
+    tr = O.Transcript(); tr.append_bytes(b"prefix")
+    exp = O.generate_commitments(P, tr, cols, fast=True)
+    nxt = tr.challenge(P)
+    table = O.splitmix64_field(188, 1 << 16)
+    r, p, fe = O.sumcheck_prove(P, table)
+    for rank, got, sc in outs:
+        for k in ("roots", "points", "values", "indices", "leaves", "siblings", "dirs"):
+            assert np.array_equal(np.array(got[k], dtype=exp[k].dtype), exp[k]), (rank, k)
+        assert got["next_challenge"] == nxt
+        assert sc["rounds"] == [int(x) for x in r] and sc["point"] == [int(x) for x in p] and sc["fe"] == fe

@@ -1,0 +1,223 @@
+"""Sharding ONE proof over several GPUs (one process per GPU, torch.distributed; backend "nccl" = RCCL
+over xGMI on a node, "gloo" in the CPU tests).  SURVEY.md s8(e):
+
+* columns  -- `generate_commitments_sharded`: the 43 (Merkle tree, eval, opening) jobs of
+  Prover.generateCommitments (src/prover/prover.zig:366-467) are independent; rank r takes a contiguous
+  block of columns.  Exchange steps: one all-gather of the roots (43 x 32 B) before the transcript absorbs
+  them, one all-gather of the openings (value, index, leaf, v x 33 B) after.  Every rank runs the same
+  deterministic transcript, so challenges need no broadcast.
+* rows     -- `sumcheck_prove_row_sharded`: a single large table is owned interleaved (global index i lives
+  on rank i mod G), which keeps every MSB-bind pair (i, i + n/2) on one rank for the first v - log2(G)
+  rounds; each round costs ONE all-reduce(sum) of the two partial half sums (16 bytes), the last log2(G)
+  rounds run on the all-gathered G-element table.
+
+Messages are 16 B - a few KiB: latency-bound, far below xGMI link bandwidth.  The compute is delegated to an
+`ops` object (GpuOps below = libzigz_hip.so; the CPU tests inject an oracle-backed stand-in), so this file
+holds only the partitioning and exchange logic.
+"""
+import numpy as np
+
+P = 2013265921
+NUM_COLUMNS = 43
+
+
+def column_partition(ncols, world):
+    """Contiguous blocks, sizes differing by at most one: 43 over 8 -> 6,6,6,5,5,5,5,5."""
+    base, extra = divmod(ncols, world)
+    out, c = [], 0
+    for r in range(world):
+        n = base + (1 if r < extra else 0)
+        out.append((c, c + n))
+        c += n
+    return out
+
+
+def _dist_device(dist):
+    import torch
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+
+def _all_gather_bytes(dist, payload, nbytes_max):
+    """all-gather of one fixed-size byte buffer per rank -> list of numpy uint8 arrays."""
+    import torch
+    dev = _dist_device(dist)
+    buf = np.zeros(nbytes_max, dtype=np.uint8)
+    buf[: len(payload)] = np.frombuffer(payload, dtype=np.uint8)
+    t = torch.from_numpy(buf).to(dev)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [o.cpu().numpy() for o in outs]
+
+
+def _all_reduce_u64(dist, values):
+    import torch
+    dev = _dist_device(dist)
+    t = torch.tensor([int(v) for v in values], dtype=torch.int64, device=dev)  # sums < G * 2^31: no overflow
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return [int(v) for v in t.cpu().tolist()]
+
+
+def generate_commitments_sharded(engine, transcript, local_cols, nv, dist, ncols=NUM_COLUMNS):
+    """Column-sharded Prover.generateCommitments.  `local_cols`: this rank's block of columns (whatever the
+    engine's `begin` accepts: a [n_local, 2^nv] uint64 array, or a device handle).  `transcript`: a
+    FiatShamirTranscript-like object (append_bytes / append_field / challenge) in the state just before
+    "POLY_COMMITMENTS" -- identical on every rank.  Returns the full 43-column result on every rank."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    part = column_partition(ncols, world)
+    c0, c1 = part[rank]
+    nmax = max(b - a for a, b in part)
+    job = engine.begin(local_cols, c1 - c0, nv)
+    try:
+        roots_local = np.ascontiguousarray(job.roots(), dtype=np.uint8).reshape(-1)          # PHASE 1
+        gathered = _all_gather_bytes(dist, roots_local.tobytes(), nmax * 32)                    # exchange 1
+        roots = np.concatenate([gathered[r][: (part[r][1] - part[r][0]) * 32] for r in range(world)]).reshape(ncols, 32)
+        transcript.append_bytes(b"POLY_COMMITMENTS")                                            # PHASE 2
+        for c in range(ncols):
+            transcript.append_bytes(roots[c].tobytes())
+        points = np.array([[transcript.challenge() for _ in range(nv)] for _ in range(ncols)],
+                          dtype=np.uint64).reshape(ncols, nv)                                   # PHASE 3
+        o = job.open_all(points[c0:c1])
+    finally:
+        job.end()
+    rec = 24 + 33 * nv  # value, index, leaf (3 x u64) + siblings + dirs per column
+    payload = bytearray()
+    for k in range(c1 - c0):
+        payload += np.array([o["values"][k], o["indices"][k], o["leaves"][k]], dtype="<u8").tobytes()
+        payload += np.ascontiguousarray(o["siblings"][k], dtype=np.uint8).tobytes()
+        payload += np.ascontiguousarray(o["dirs"][k], dtype=np.uint8).tobytes()
+    gathered = _all_gather_bytes(dist, bytes(payload), nmax * rec)                              # exchange 2
+    values = np.zeros(ncols, dtype=np.uint64)
+    indices = np.zeros(ncols, dtype=np.uint64)
+    leaves = np.zeros(ncols, dtype=np.uint64)
+    siblings = np.zeros((ncols, nv, 32), dtype=np.uint8)
+    dirs = np.zeros((ncols, nv), dtype=np.uint8)
+    for r in range(world):
+        a, b = part[r]
+        for k in range(b - a):
+            chunk = gathered[r][k * rec:(k + 1) * rec]
+            values[a + k], indices[a + k], leaves[a + k] = np.frombuffer(chunk[:24].tobytes(), dtype="<u8")
+            siblings[a + k] = chunk[24:24 + 32 * nv].reshape(nv, 32)
+            dirs[a + k] = chunk[24 + 32 * nv:24 + 33 * nv]
+    transcript.append_bytes(b"OPENING_CLAIMS")                                                  # PHASE 4
+    for c in range(ncols):
+        transcript.append_field(int(values[c]))
+    return dict(roots=roots, points=points, values=values, indices=indices, leaves=leaves, siblings=siblings, dirs=dirs)
+
+
+def interleave_rows(table, rank, world):
+    """The slice of a global table owned by `rank` under interleaved ownership (index mod world)."""
+    return np.ascontiguousarray(np.asarray(table)[rank::world])
+
+
+def sumcheck_prove_row_sharded(ops, local_table, n_global, dist, transcript_factory):
+    """SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) over a table sharded by rows (interleaved).
+    `local_table`: ops-specific handle of this rank's n_global/G elements.  One all-reduce of 2 words per round.
+    Returns (rounds[2v], point[v], final_eval) on every rank -- identical to the unsharded proof."""
+    rank, world = dist.get_rank(), dist.get_world_size()
+    assert n_global & (n_global - 1) == 0 and world & (world - 1) == 0 and n_global >= 2 * world
+    nv = n_global.bit_length() - 1
+    lg = world.bit_length() - 1
+    tr = transcript_factory()  # fresh transcript per sumcheck (sumcheck_protocol.zig:161)
+    rounds, point = [], []
+    cur, n_local = local_table, n_global // world
+    s = _all_reduce_u64(dist, ops.half_sums(cur, n_local))
+    for _ in range(nv - lg):                       # rounds whose bind pairs are rank-local
+        s0, s1 = s[0] % P, s[1] % P
+        c0, c1 = s0, (s1 - s0) % P                 # roundPolynomial, multilinear.zig:228-229
+        rounds += [c0, c1]
+        tr.append_field(c0); tr.append_field(c1)
+        ch = tr.challenge()
+        point.append(ch)
+        if n_local > 1:
+            if n_local > 2:
+                cur, part = ops.bind_sums(cur, n_local, ch)
+                s = _all_reduce_u64(dist, part)
+            else:
+                cur = ops.bind(cur, n_local, ch)
+            n_local //= 2
+    # n_local == 1 now: global table of `world` elements, element g on rank g
+    mine = int(ops.download(cur, 1)[0])
+    tail = np.array(_all_gather_u64(dist, mine), dtype=np.uint64)
+    if lg:
+        t = ops.upload(tail)
+        r2, p2, fe = ops.sumcheck_tail(t, world, tr)
+        rounds += r2
+        point += p2
+    else:
+        fe = int(tail[0])
+    return np.array(rounds, dtype=np.uint64), np.array(point, dtype=np.uint64), int(fe)
+
+
+def _all_gather_u64(dist, value):
+    import torch
+    dev = _dist_device(dist)
+    t = torch.tensor([int(value)], dtype=torch.int64, device=dev)
+    outs = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(outs, t)
+    return [int(o.item()) for o in outs]
+
+
+class GpuEngine:
+    """Column engine on libzigz_hip.so: host uint64 columns or (device pointer, stride)."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def begin(self, local_cols, ncols, nv):
+        from .hip import CommitJob
+        if isinstance(local_cols, tuple):
+            d_ptr, stride = local_cols
+            return CommitJob(self.ctx, d_cols=d_ptr, ncols=ncols, nv=nv, col_stride=stride)
+        return CommitJob(self.ctx, cols=np.ascontiguousarray(local_cols, dtype=np.uint64))
+
+
+class GpuOps:
+    """Row-sharded sumcheck ops on libzigz_hip.so; tables are (device pointer, capacity) pairs."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+        self._bufs = []
+
+    def upload(self, values):
+        n = len(values)
+        d = self.ctx.dev_alloc(max(n, 4) * 4)
+        self._bufs.append(d)
+        self.ctx.upload(values, d)
+        return d
+
+    def download(self, d, n):
+        return self.ctx.download(d, n)
+
+    def half_sums(self, d, n):
+        return self.ctx.dev_mle_half_sums(d, n)
+
+    def bind_sums(self, d, n, r):
+        out = self.ctx.dev_alloc(max(n // 2, 4) * 4)
+        self._bufs.append(out)
+        return out, self.ctx.dev_mle_bind_sums(d, n, r, out)
+
+    def bind(self, d, n, r):
+        out = self.ctx.dev_alloc(max(n // 2, 4) * 4)
+        self._bufs.append(out)
+        self.ctx.dev_mle_bind(d, n, r, out)
+        return out
+
+    def sumcheck_tail(self, d, n, tr):
+        """Finish the last log2(G) rounds on the gathered table, continuing transcript `tr`."""
+        rounds, point = [], []
+        cur = d
+        while n > 1:
+            s = self.ctx.dev_mle_half_sums(cur, n)
+            c0, c1 = s[0] % P, (s[1] - s[0]) % P
+            rounds += [c0, c1]
+            tr.append_field(c0); tr.append_field(c1)
+            ch = tr.challenge()
+            point.append(ch)
+            cur = self.bind(cur, n, ch)
+            n //= 2
+        return rounds, point, int(self.ctx.download(cur, 1)[0])
+
+    def close(self):
+        for d in self._bufs:
+            self.ctx.dev_free(d)
+        self._bufs = []
