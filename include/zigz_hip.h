@@ -168,6 +168,12 @@ zigz_status zigz_lasso_fingerprints(zigz_ctx *ctx, const uint64_t *rows_in, size
  * F.init(u64) = x mod p over raw 64-bit trace words (src/constraints/witness.zig:76,112,164-170,237-239):
  * d_out[i] = h_in[i] mod p, packed u32, for building device-resident columns from raw trace data. */
 zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out);
+/* WitnessGenerator.generate on the device   src/constraints/witness.zig:29-270, column order prover.zig:376-390.
+ * h_rows: the execution trace as packed rows, [num_steps][43] raw 64-bit words in column order (pc, x0..x31,
+ * opcode, rd, rs1, rs2, funct3, funct7, imm as u64(bitcast i64), mem address, mem value, is_read).  Builds the 43
+ * padded columns of 2^nv packed-u32 cells (nv = log2_int_ceil(num_steps)) at d_cols + c*col_stride. */
+zigz_status zigz_dev_witness_from_rows(zigz_ctx *ctx, const uint64_t *h_rows, size_t num_steps, size_t nv,
+                                       uint32_t *d_cols, size_t col_stride);
 
 /* ---------------------------------------------------------------- device-resident MLE / sumcheck */
 zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out);

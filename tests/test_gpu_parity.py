@@ -336,3 +336,26 @@ def test_host_transcript_vs_oracle(ctx):
         b.append_bytes(b"LASSO_TABLE"); b.append_field(i)
     for _ in range(5):
         assert a.challenge() == b.challenge(P)
+
+
+# ---------------------------------------------------------------- A0 / K8: witness columns built on the device
+@pytest.mark.parametrize("ns", [1, 2, 3, 63, 64, 65, 100, 1000, 4097])
+def test_witness_from_rows(ctx, ns):
+    """Packed trace rows [ns][43] (raw u64, full 64-bit range) -> 43 padded columns, vs the reference rule:
+    cell = x mod p; padding repeats the last row for pc/registers (columns 0..32) and is 0 elsewhere."""
+    rng = np.random.default_rng(ns)
+    rows = rng.integers(0, 2**64, size=(ns, 43), dtype=np.uint64)
+    rows[ns // 2, :5] = [0, P - 1, P, P + 1, 2**64 - 1]
+    nv = 0 if ns == 1 else int(ns - 1).bit_length()
+    N = 1 << nv
+    stride = max(N, 4)
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        ctx.witness_from_rows(rows, nv, d, stride)
+        got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+    finally:
+        ctx.dev_free(d)
+    exp = np.zeros((43, N), dtype=np.uint64)
+    exp[:, :ns] = (rows % np.uint64(P)).T
+    exp[:33, ns:] = exp[:33, ns - 1:ns]
+    assert np.array_equal(got, exp)

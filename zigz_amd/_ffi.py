@@ -63,6 +63,7 @@ SIGNATURES = {
                                                   C.c_size_t, szp, u64p, u64p, u64p, u8p, u8p]),
     "zigz_lasso_fingerprints": (C.c_int32, [vp, u64p, C.c_size_t, C.c_size_t, u64p]),
     "zigz_dev_reduce_u64": (C.c_int32, [vp, u64p, C.c_size_t, vp]),
+    "zigz_dev_witness_from_rows": (C.c_int32, [vp, u64p, C.c_size_t, C.c_size_t, vp, C.c_size_t]),
     "zigz_dev_mle_bind": (C.c_int32, [vp, vp, C.c_size_t, C.c_uint64, vp]),
     "zigz_dev_mle_bind_sums": (C.c_int32, [vp, vp, C.c_size_t, C.c_uint64, vp, u64p]),
     "zigz_dev_mle_half_sums": (C.c_int32, [vp, vp, C.c_size_t, u64p]),

@@ -287,6 +287,22 @@ extern "C" zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, 
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     return ZIGZ_OK;
 }
+extern "C" zigz_status zigz_dev_witness_from_rows(zigz_ctx *ctx, const uint64_t *h_rows, size_t num_steps, size_t nv,
+                                                  uint32_t *d_cols, size_t col_stride) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !h_rows || !d_cols || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (num_steps == 0) return ZIGZ_ERR_EMPTY_TRACE;
+    const size_t npad = (size_t)1 << nv;
+    if (num_steps > npad || (nv > 0 && num_steps <= npad / 2) || col_stride < npad) return ZIGZ_ERR_INVALID_ARGUMENT;
+    void *d_rows;
+    CHK(ws_get(ctx, WS_IN64, num_steps * 43 * sizeof(uint64_t), &d_rows));
+    HIPCHK(ctx, hipMemcpyAsync(d_rows, h_rows, num_steps * 43 * sizeof(uint64_t), hipMemcpyHostToDevice, ctx->stream));
+    launch_witness_rows((const uint64_t *)d_rows, num_steps, npad, d_cols, col_stride, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_rows may be pageable: do not return before the copy is done
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || (n && (!h_out || !d_in))) return ZIGZ_ERR_INVALID_ARGUMENT;

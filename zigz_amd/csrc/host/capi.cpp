@@ -96,10 +96,8 @@ extern "C" int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out) {
 
 extern "C" int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride) {
     return guard([&] {
-        Witness w = WitnessGenerator::generate(t->trace);
-        const size_t N = (size_t)1 << w.num_vars;
-        if (stride < N) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "stride < 2^num_vars");
-        for (size_t c = 0; c < ROW_WORDS; c++) check(ctx, zigz_dev_upload_u64(ctx, w.column(c), N, d_cols + c * stride));
+        // the trace is already recorded as packed witness rows: one H2D + one transpose/mod-p kernel (K8)
+        check(ctx, zigz_dev_witness_from_rows(ctx, t->trace.rows.data(), t->trace.stepCount(), t->num_vars, d_cols, stride));
     });
 }
 

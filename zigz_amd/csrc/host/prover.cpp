@@ -236,8 +236,16 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     }
     const size_t num_steps = vm->trace.stepCount();
     if (num_steps == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
-    // [2/6] witness (prover.zig:156-162)
-    Witness witness = WitnessGenerator::generate(vm->trace);
+    // [2/6] witness (prover.zig:156-162): built directly in HBM from the packed trace rows (K8); the host
+    // WitnessGenerator::generate stays available for callers that want the columns on the host
+    const size_t nv = log2_int_ceil(num_steps), N = (size_t)1 << nv, stride = N < 4 ? 4 : N;
+    struct DevCols {
+        zigz_ctx *ctx;
+        void *p = nullptr;
+        ~DevCols() { if (p) zigz_dev_free(ctx, p); }
+    } dcols{ctx_};
+    check(ctx_, zigz_dev_alloc(ctx_, ROW_WORDS * stride * sizeof(uint32_t), &dcols.p));
+    check(ctx_, zigz_dev_witness_from_rows(ctx_, vm->trace.rows.data(), num_steps, nv, (uint32_t *)dcols.p, stride));
     // [3/6] constraint system: only the number of lookup constraints is observable (builder.zig:253-267)
     size_t L = 0;
     for (uint8_t f : vm->trace.is_lookup) L += f;
@@ -247,7 +255,7 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     io.final_regs = fr;
     io.num_steps = num_steps;
     if (!vm->output_tape.empty()) io.outputs = vm->output_tape;
-    return proveWitness(io, L, &witness, nullptr, 0, witness.num_vars, initial_regs);
+    return proveWitness(io, L, nullptr, (const uint32_t *)dcols.p, stride, nv, initial_regs);
 }
 
 // ---------------------------------------------------------------- BinarySerializer (serialization.zig)

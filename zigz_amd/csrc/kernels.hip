@@ -205,6 +205,36 @@ __global__ __launch_bounds__(TPB) void k_widen_u32(const uint32_t *__restrict__ 
     for (; i < n; i += step) out[i] = in[i];
 }
 
+// ------------------------------------------------------------------ K8: witness columns from packed trace rows
+// One workgroup transposes a tile of 64 steps x 43 words through LDS: coalesced 8-byte reads of the row-major
+// trace, `x mod p`, then per column 64 consecutive u32 (256 B per wave store).  LDS row pitch 43 words (odd)
+// keeps the transposed reads conflict-free.
+constexpr int WROW = 43, WTILE = 64;
+__global__ __launch_bounds__(TPB) void k_witness_rows(const uint64_t *__restrict__ rows, size_t num_steps, size_t npad,
+                                                      uint32_t *__restrict__ cols, size_t stride) {
+    __shared__ uint32_t tile[WTILE * WROW];
+    const size_t base = (size_t)blockIdx.x * WTILE;
+    for (int k = threadIdx.x; k < WTILE * WROW; k += TPB) {
+        const size_t step = base + (size_t)(k / WROW);
+        const int c = k % WROW;
+        uint32_t v = 0;
+        if (step < num_steps) v = (uint32_t)(rows[base * WROW + k] % (uint64_t)P);
+        else if (c <= 32) v = (uint32_t)(rows[(num_steps - 1) * WROW + c] % (uint64_t)P);
+        tile[k] = v;
+    }
+    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (base + lane < npad)
+        for (int c = wave; c < WROW; c += TPB / 64) cols[(size_t)c * stride + base + lane] = tile[lane * WROW + c];
+}
+
+void launch_witness_rows(const uint64_t *d_rows, size_t num_steps, size_t npad, uint32_t *d_cols, size_t stride,
+                         hipStream_t s) {
+    if (num_steps == 0) return;
+    hipLaunchKernelGGL(k_witness_rows, dim3((unsigned)((npad + WTILE - 1) / WTILE)), dim3(TPB), 0, s, d_rows, num_steps, npad,
+                       d_cols, stride);
+}
+
 static unsigned stream_grid(size_t n) {
     size_t b = (n + TPB - 1) / TPB;
     return (unsigned)(b < 1 ? 1 : (b > 4096 ? 4096 : b));

@@ -16,6 +16,11 @@ inline size_t tree_nodes(size_t npad) { return 2 * npad; }
 void launch_narrow_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, uint32_t *d_flag, hipStream_t s);
 // d_out[i] = d_in[i] mod p  (F.init on raw 64-bit words, src/core/field.zig:36-38)
 void launch_reduce_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, hipStream_t s);
+// K8 (witness): packed trace rows [num_steps][43] raw u64 -> 43 columns of 2^nv packed u32, column stride
+// `stride`: cols[c][i] = rows[i][c] mod p for i < num_steps; padding i >= num_steps repeats the last row for
+// c <= 32 (pc, x0..x31) and is 0 otherwise (src/constraints/witness.zig:80-87,116-123,174-182,249-253).
+void launch_witness_rows(const uint64_t *d_rows, size_t num_steps, size_t npad, uint32_t *d_cols, size_t stride,
+                         hipStream_t s);
 void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream_t s);
 
 // K1 (+K2 fused): batched MLE bind.  For column c in [0,ncols):

@@ -93,6 +93,11 @@ class Context:
         a, ap = _u64(raw_u64)
         self.check(lib.zigz_dev_reduce_u64(self.h, ap, len(raw_u64), vp(d_ptr)))
 
+    def witness_from_rows(self, rows, nv, d_cols, stride):
+        """WitnessGenerator.generate on the device from packed trace rows [num_steps, 43] (raw u64)."""
+        rows = np.ascontiguousarray(rows, dtype=np.uint64)
+        self.check(lib.zigz_dev_witness_from_rows(self.h, rows.ctypes.data_as(u64p), rows.shape[0], nv, vp(d_cols), stride))
+
     def download(self, d_ptr, n):
         o, op = _out_u64(n)
         self.check(lib.zigz_dev_download_u64(self.h, vp(d_ptr), n, op))
