@@ -224,6 +224,8 @@ typedef struct zigz_kernel_stats {
     uint64_t bind_vec_bytes;
 } zigz_kernel_stats;
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
+/* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form */
+zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
 
 #ifdef __cplusplus

@@ -359,3 +359,33 @@ def test_witness_from_rows(ctx, ns):
     exp[:, :ns] = (rows % np.uint64(P)).T
     exp[:33, ns:] = exp[:33, ns - 1:ns]
     assert np.array_equal(got, exp)
+
+
+# ---------------------------------------------------------------- A5: both sumcheck forms agree
+@pytest.mark.parametrize("nv", [14, 15, 16, 18, 19, 21, 24])
+def test_sumcheck_radix_equals_per_round(ctx, nv):
+    """Tables >= 2^14 take the radix-2^k form (k rounds per pass from block sums); it must reproduce the
+    one-launch-per-round form bit for bit, with Fiat-Shamir and with fixed challenges, and the oracle where
+    the oracle is affordable."""
+    n = 1 << nv
+    ev = rnd(900 + nv, n)
+    d = ctx.dev_alloc(n * 4)
+    try:
+        ctx.upload(ev, d)
+        chs = rnd(950 + nv, nv)
+        ctx.set_option("per_round_sumcheck", 0)
+        a = ctx.dev_sumcheck_prove(d, n)
+        a2 = ctx.dev_sumcheck_prove(d, n, chs)
+        ctx.set_option("per_round_sumcheck", 1)
+        b = ctx.dev_sumcheck_prove(d, n)
+        b2 = ctx.dev_sumcheck_prove(d, n, chs)
+        ctx.set_option("per_round_sumcheck", 0)
+    finally:
+        ctx.dev_free(d)
+    for x, y in ((a, b), (a2, b2)):
+        assert np.array_equal(x[0], y[0]) and np.array_equal(x[1], y[1]) and x[2] == y[2]
+    if nv <= 19:
+        o = O.sumcheck_prove(P, ev)
+        assert np.array_equal(a[0], o[0]) and np.array_equal(a[1], o[1]) and a[2] == o[2]
+        o2 = O.sumcheck_prove(P, ev, chs)
+        assert np.array_equal(a2[0], o2[0]) and a2[2] == o2[2]

@@ -79,6 +79,7 @@ SIGNATURES = {
     "zigz_sha256": (None, [C.c_char_p, C.c_size_t, u8p]),
     "zigz_host_keccak_impl": (C.c_char_p, []),
     "zigz_host_keccak_permute": (None, [u64p, C.c_int]),
+    "zigz_ctx_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
     "zigz_ctx_enable_timing": (C.c_int32, [vp, C.c_int]),
     "zigz_ctx_get_stats": (C.c_int32, [vp, C.POINTER(KernelStats)]),
 }

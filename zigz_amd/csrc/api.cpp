@@ -32,6 +32,7 @@ struct zigz_ctx {
     uint32_t *d_flag;
     uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
     bool timing;
+    bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs for k_bind_vec timing
     int pool_used;
@@ -40,6 +41,9 @@ struct zigz_ctx {
     zigz_commit_job *active_job;
 };
 static const size_t SUMS_SLOTS = 4096;
+constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck stage
+constexpr size_t RADIX_MIN_N = 1 << 14;  // smaller tables use the per-round form (everything on the GPU)
+constexpr size_t HOST_TAIL_MAX = 1024;
 static const size_t PIN_WORDS = 1 << 16;
 
 static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
@@ -231,6 +235,11 @@ extern "C" zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable) {
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     ctx->timing = enable != 0;
     return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value) {
+    if (!ctx || !name) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
+    return ZIGZ_ERR_INVALID_ARGUMENT;
 }
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
     ZIGZ_ENTER(ctx);
@@ -492,6 +501,9 @@ extern "C" zigz_status zigz_dev_mle_eval(zigz_ctx *ctx, const uint32_t *d_in, si
     return ZIGZ_OK;
 }
 
+static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *fixed, uint64_t *rounds,
+                                  uint64_t *point, uint64_t *final_eval);
+
 // ------------------------------------------------------------------ sumcheck (device-resident core)
 // SumcheckProver.prove, sumcheck_prover.zig:26-91.  Per round: [s0, s1-s0] -> host transcript ->
 // challenge -> fused bind + next-round half sums (one launch, one 16-byte read-back per round).
@@ -499,6 +511,8 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
                                  const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
     const size_t nv = log2_floor(n);
     if (2 * (nv + 1) > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n >= RADIX_MIN_N && !ctx->per_round_sumcheck && !ctx->timing)
+        return sumcheck_radix(ctx, d_in, n, fixed, rounds, point, final_eval);
     if (!d_scratch) {
         void *s;
         CHK(ws_get(ctx, WS_SCRATCH, (n / 2 + n / 4 + 8) * 4, &s));
@@ -555,6 +569,122 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
         ctx->stats.bind_launches = nv;
         CHK(bind_pool_collect(ctx));
     }
+    return ZIGZ_OK;
+}
+
+// ------------------------------------------------------------------ sumcheck, radix-2^k form
+// The per-round form above costs one launch + one host round trip per round (~17 us each on MI355X), which
+// dwarfs the HBM time of even a 2^24 table.  Round polynomials only need HALF SUMS of the bound table, and
+// binding is linear, so the sums of the next k rounds follow from the 2^k block sums of the current table:
+//   pass 1  GPU: block sums B[2^k] of the table (one read of the table)
+//   host    k rounds on the 2^k-entry sums table (SHA3 challenge per round, O(2^k) scalar field ops in total)
+//   pass 2  GPU: T'[i] = sum_b eq(r_0..r_{k-1}; b) * T[b*m + i]  (one more read, writes n/2^k) + next block sums
+// i.e. two passes over the table per k <= 10 rounds and two host round trips instead of k.  The O(n) data work
+// stays on the GPU; the host touches only the <= 1024-entry sums tables (and the final <= 1024-entry table).
+// Exact field arithmetic => identical round polynomials, challenges and final_eval (tests compare both forms).
+namespace {
+inline uint64_t h_add(uint64_t a, uint64_t b) { uint64_t s = a + b; return s >= P ? s - P : s; }
+inline uint64_t h_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + P - b; }
+inline uint64_t h_mul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % P); }
+}  // namespace
+
+static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *fixed, uint64_t *rounds,
+                                  uint64_t *point, uint64_t *final_eval) {
+    const unsigned nv = log2_floor(n);
+    Transcript tr;  // fresh transcript per sumcheck, sumcheck_protocol.zig:161
+    size_t round = 0;
+    auto next_challenge = [&](uint64_t c0, uint64_t c1, uint64_t *ch) -> zigz_status {
+        rounds[2 * round] = c0;
+        rounds[2 * round + 1] = c1;
+        if (fixed) {
+            if (fixed[round] >= P) return ZIGZ_ERR_NOT_CANONICAL;
+            *ch = fixed[round];
+        } else {
+            tr.append_field(c0);  // generateChallenge, sumcheck_protocol.zig:176-184
+            tr.append_field(c1);
+            *ch = tr.challenge();
+        }
+        point[round++] = *ch;
+        return ZIGZ_OK;
+    };
+    unsigned k = nv - 8 < RADIX_MAX_K ? nv - 8 : RADIX_MAX_K;
+    size_t len = n, m = len >> k;
+    // workspace: two (acc u64[m0], out u32[m0]) regions, sized by the first (largest) stage output
+    const size_t m0 = m;
+    void *ws;
+    CHK(ws_get(ctx, WS_SCRATCH, 2 * m0 * 12 + 256, &ws));
+    uint8_t *wsb = (uint8_t *)ws;
+    void *wbuf;
+    CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &wbuf));
+    unsigned long long *d_B = ctx->d_sums;  // two alternating regions of 1024 block sums
+    HIPCHK(ctx, hipMemsetAsync(d_B, 0, ((size_t)1 << k) * 8, ctx->stream));
+    launch_block_sums(d_in, len, log2_floor(m), d_B, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    std::vector<uint64_t> B((size_t)1 << k), W;
+    CHK(read_u64(ctx, d_B, (size_t)1 << k, B.data()));
+    const uint32_t *cur = d_in;
+    std::vector<uint64_t> tail;
+    for (unsigned stage = 0;; stage++) {
+        for (auto &b : B) b %= P;
+        W.assign(1, 1);
+        for (unsigned j = 0; j < k; j++) {  // k rounds on the block-sums table (MSB-first, like partialEval)
+            const size_t half = B.size() / 2;
+            uint64_t s0 = 0, s1 = 0;
+            for (size_t x = 0; x < half; x++) { s0 = h_add(s0, B[x]); s1 = h_add(s1, B[x + half]); }
+            uint64_t ch;
+            CHK(next_challenge(s0, h_sub(s1, s0), &ch));
+            for (size_t x = 0; x < half; x++) B[x] = h_add(B[x], h_mul(ch, h_sub(B[x + half], B[x])));
+            B.resize(half);
+            std::vector<uint64_t> W2(W.size() * 2);
+            const uint64_t one_minus = h_sub(1, ch);
+            for (size_t x = 0; x < W.size(); x++) { W2[2 * x] = h_mul(W[x], one_minus); W2[2 * x + 1] = h_mul(W[x], ch); }
+            W.swap(W2);
+        }
+        // pass 2: radix fold with the eq weights (Montgomery form), accumulate in u64, finalize mod p
+        const size_t nb = (size_t)1 << k;
+        uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
+        for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(W[b]);
+        HIPCHK(ctx, hipMemcpyAsync(wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t *region = wsb + (stage & 1) * (m0 * 12 + 128);
+        unsigned long long *d_acc = (unsigned long long *)region;
+        uint32_t *d_out = (uint32_t *)(region + m0 * 8);
+        HIPCHK(ctx, hipMemsetAsync(d_acc, 0, m * 8, ctx->stream));
+        launch_radix_fold(cur, m, nb, (const uint32_t *)wbuf, d_acc, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        if (m <= HOST_TAIL_MAX) {
+            launch_radix_finalize(d_acc, d_out, m, 0, nullptr, ctx->stream);
+            HIPCHK(ctx, hipGetLastError());
+            uint32_t *h32 = (uint32_t *)ctx->h_pin;
+            HIPCHK(ctx, hipMemcpyAsync(h32, d_out, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            tail.assign(h32, h32 + m);
+            break;
+        }
+        const unsigned lm = log2_floor(m);
+        const unsigned k2 = lm - 8 < RADIX_MAX_K ? lm - 8 : RADIX_MAX_K;
+        unsigned long long *d_B2 = ctx->d_sums + (((stage + 1) & 1) ? 1024 : 0);
+        HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k2) * 8, ctx->stream));
+        launch_radix_finalize(d_acc, d_out, m, lm - k2, d_B2, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        B.assign((size_t)1 << k2, 0);
+        CHK(read_u64(ctx, d_B2, (size_t)1 << k2, B.data()));
+        cur = d_out;
+        len = m;
+        k = k2;
+        m = len >> k;
+    }
+    // last <= 10 rounds on the <= 1024-entry table
+    while (tail.size() > 1) {
+        const size_t half = tail.size() / 2;
+        uint64_t s0 = 0, s1 = 0;
+        for (size_t x = 0; x < half; x++) { s0 = h_add(s0, tail[x]); s1 = h_add(s1, tail[x + half]); }
+        uint64_t ch;
+        CHK(next_challenge(s0, h_sub(s1, s0), &ch));
+        for (size_t x = 0; x < half; x++) tail[x] = h_add(tail[x], h_mul(ch, h_sub(tail[x + half], tail[x])));
+        tail.resize(half);
+    }
+    if (round != nv) return ZIGZ_ERR_PROTOCOL_ERROR;  // sumcheck_prover.zig:80-82
+    *final_eval = tail[0];
     return ZIGZ_OK;
 }
 

@@ -177,6 +177,92 @@ void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t n
     }
 }
 
+// ------------------------------------------------------------------ radix-2^k sumcheck stage
+// Block sums of 2^k contiguous blocks of m elements: every wave-level 256-element segment lies inside one block
+// (m >= 256), so it is reduced by shuffles and costs one u64 atomic.
+__global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__ in, size_t n, unsigned log2_m,
+                                                    unsigned long long *__restrict__ sums) {
+    const uint4 *p = reinterpret_cast<const uint4 *>(in);
+    const size_t base = (size_t)blockIdx.x * (TPB * UNROLL) + threadIdx.x;
+    const size_t chunks = n / 4;
+    uint4 a[UNROLL];
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        const size_t c = base + (size_t)u * TPB;
+        a[u] = c < chunks ? p[c] : make_uint4(0, 0, 0, 0);
+    }
+#pragma unroll
+    for (int u = 0; u < UNROLL; u++) {
+        const size_t c = base + (size_t)u * TPB;
+        unsigned long long v = wave_sum((unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w);
+        if ((threadIdx.x & 63) == 0 && c < chunks && v) atomicAdd(&sums[(c * 4) >> log2_m], v);
+    }
+}
+
+void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s) {
+    const size_t chunks = n / 4, per_block = (size_t)TPB * UNROLL;
+    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(TPB), 0, s, d_in, n, log2_m,
+                       d_sums);
+}
+
+// acc[i] += sum over a chunk of RB block indices b of W[b] * in[b*m + i].  Thread = 4 consecutive outputs
+// (16-byte loads, coalesced across the wave), RB independent loads in flight; the b range is split over
+// gridDim.y so that even a 2^20 table (m = 1024) spreads over the chip; partial results meet in u64 atomics
+// (exact: integer adds commute), one per output per chunk.
+constexpr int RB = 16;
+__global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t m, size_t nb,
+                                                    const uint32_t *__restrict__ w_m,
+                                                    unsigned long long *__restrict__ acc) {
+    const size_t q = (size_t)blockIdx.x * TPB + threadIdx.x;  // uint4 index of the outputs
+    if (q * 4 >= m) return;
+    const size_t b0 = (size_t)blockIdx.y * RB;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in) + q;
+    const size_t mq = m / 4;
+    uint4 v[RB];
+#pragma unroll
+    for (int j = 0; j < RB; j++) v[j] = (b0 + j < nb) ? p[(b0 + j) * mq] : make_uint4(0, 0, 0, 0);
+    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll
+    for (int j = 0; j < RB; j++) {
+        const uint32_t w = (b0 + j < nb) ? w_m[b0 + j] : 0;  // wave-uniform
+        s0 += mont_mul(w, v[j].x);
+        s1 += mont_mul(w, v[j].y);
+        s2 += mont_mul(w, v[j].z);
+        s3 += mont_mul(w, v[j].w);
+    }
+    unsigned long long *o = acc + q * 4;
+    atomicAdd(o + 0, s0);
+    atomicAdd(o + 1, s1);
+    atomicAdd(o + 2, s2);
+    atomicAdd(o + 3, s3);
+}
+
+void launch_radix_fold(const uint32_t *d_in, size_t m, size_t nb, const uint32_t *d_w_m, unsigned long long *d_acc,
+                       hipStream_t s) {
+    dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)((nb + RB - 1) / RB));
+    hipLaunchKernelGGL(k_radix_fold, grid, dim3(TPB), 0, s, d_in, m, nb, d_w_m, d_acc);
+}
+
+__global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ acc,
+                                                        uint32_t *__restrict__ out, size_t m, unsigned log2_m2,
+                                                        unsigned long long *__restrict__ sums) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    uint32_t v = 0;
+    if (i < m) {
+        v = (uint32_t)(acc[i] % (unsigned long long)P);
+        out[i] = v;
+    }
+    if (sums) {  // m2 >= 256: the 64 outputs of a wave fall into one block of the next stage
+        unsigned long long t = wave_sum((unsigned long long)v);
+        if ((threadIdx.x & 63) == 0 && i < m && t) atomicAdd(&sums[i >> log2_m2], t);
+    }
+}
+
+void launch_radix_finalize(const unsigned long long *d_acc, uint32_t *d_out, size_t m, unsigned log2_m2,
+                           unsigned long long *d_sums, hipStream_t s) {
+    hipLaunchKernelGGL(k_radix_finalize, dim3((unsigned)((m + TPB - 1) / TPB)), dim3(TPB), 0, s, d_acc, d_out, m, log2_m2, d_sums);
+}
+
 // ------------------------------------------------------------------ layout conversion at the boundary
 __global__ __launch_bounds__(TPB) void k_narrow_u64(const uint64_t *__restrict__ in, uint32_t *__restrict__ out,
                                                     size_t n, uint32_t *flag) {

@@ -35,6 +35,16 @@ bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_str
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols,
                       unsigned long long *d_sums, hipStream_t s);
 
+// Radix-2^k sumcheck stage (k rounds per pass over the table; see DESIGN.md "Sumcheck"):
+//  (1) block sums: sums[b] += sum of in[b*m .. (b+1)*m), b < n/m   (m = 2^log2_m >= 256, n >= 1024, exact u64)
+void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s);
+//  (2) acc[i] += sum_b W[b] * in[b*m + i]  (i < m, b < nb; W in Montgomery form; acc exact u64, zeroed by the caller)
+void launch_radix_fold(const uint32_t *d_in, size_t m, size_t nb, const uint32_t *d_w_m, unsigned long long *d_acc,
+                       hipStream_t s);
+//  (3) out[i] = acc[i] mod p; if d_sums: sums[i >> log2_m2] += out[i]  (next stage's block sums, m2 >= 256)
+void launch_radix_finalize(const unsigned long long *d_acc, uint32_t *d_out, size_t m, unsigned log2_m2,
+                           unsigned long long *d_sums, hipStream_t s);
+
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s);

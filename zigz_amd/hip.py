@@ -106,6 +106,9 @@ class Context:
     def enable_timing(self, on=True):
         self.check(lib.zigz_ctx_enable_timing(self.h, 1 if on else 0))
 
+    def set_option(self, name, value):
+        self.check(lib.zigz_ctx_set_option(self.h, name.encode(), int(value)))
+
     def stats(self):
         s = KernelStats()
         self.check(lib.zigz_ctx_get_stats(self.h, C.byref(s)))
