@@ -30,9 +30,9 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
-# 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (max clock) int32 VALU lane-ops/s; one Keccak-f[1600] ~ 4.4e3 such ops
+# 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (max clock) int32 VALU lane-ops/s
 VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9
-KECCAK_OPS = 4400.0
+KECCAK_OPS = 4170.0  # VALU instructions per permutation in k_keccak_* (2746 v_bitop3 + 1342 v_alignbit + misc)
 
 
 def cpu_baseline(nv, program, num_lookups, sample_cols):
@@ -77,12 +77,18 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist = None
     torch = None
+    backend = os.environ.get("ZIGZ_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a 1-GPU box
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=backend)
+            local_rank = local_rank % max(torch.cuda.device_count(), 1)
+    tdev = "cuda" if backend == "nccl" else "cpu"
 
     import zigz_amd
     from zigz_amd import host
@@ -117,7 +123,8 @@ def main():
         for l in lanes:
             l.ctx.synchronize()
         if torch is not None:
-            torch.cuda.synchronize()
+            if backend == "nccl":
+                torch.cuda.synchronize()
             dist.barrier()
 
     def run_step():
@@ -150,10 +157,10 @@ def main():
     proof = lanes[0].proof
     nproofs = args.steps * B
     if torch is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
-        s = torch.tensor([local_steps], dtype=torch.float64, device="cuda")
+        s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = float(s.item())
     else:
@@ -197,8 +204,15 @@ def main():
                         "eval_ms_per_proof": eval_us / nproofs / 1e3,
                         "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
                         "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode(),
-                        "keccak_gperm_per_s": (perms / 1e9) / (merkle_us / 1e6) if merkle_us else 0.0,
-                        "keccak_frac_of_int_valu_peak": ((perms * KECCAK_OPS) / (merkle_us / 1e6)) / VALU_PEAK_OPS if merkle_us else 0.0},
+                        # Keccak Merkle build of ONE proof alone on the GPU (the per-proof figures above are wall
+                        # times of concurrent lanes): permutations/s and the share of the int-VALU issue peak
+                        "uncontended": {
+                            "merkle_build_ms": solo_st["merkle_build_us"] / 1e3,
+                            "keccak_gperm_per_s": (solo_st["keccak_permutations"] / 1e9) / (solo_st["merkle_build_us"] / 1e6),
+                            "keccak_frac_of_int_valu_peak": (solo_st["keccak_permutations"] * KECCAK_OPS /
+                                                             (solo_st["merkle_build_us"] / 1e6)) / VALU_PEAK_OPS,
+                            "eval_ms": solo_st["eval_us"] / 1e3},
+                        "gpu_busy_keccak_gperm_per_s": (perms / 1e9) / dt},
         }
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(nv, prog, trace.num_lookups, args.cpu_sample_cols)

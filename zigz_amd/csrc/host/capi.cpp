@@ -61,6 +61,7 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
         VMState vm(prog, entry_pc, input ? &in : nullptr);
         if (t->initial_regs)
             for (size_t i = 0; i < t->initial_regs->size() && i < 32; i++) vm.writeReg((unsigned)i, (*t->initial_regs)[i]);
+        vm.trace.reserveSteps(max_steps < ((size_t)1 << 22) ? max_steps : ((size_t)1 << 22));
         size_t step_count = 0;
         while (!vm.halted && step_count < max_steps) {  // prover.zig:132-142
             vm.step();

@@ -243,6 +243,23 @@ uint64_t VMState::execute(const Instruction &in, uint64_t *mem_row) {  // state.
     }
 }
 
+void ExecutionTrace::reserveSteps(size_t n) {
+    rows.reserve(n * ROW_WORDS);
+    is_lookup.reserve(n);
+}
+
+uint64_t *ExecutionTrace::appendRow() {
+    const size_t i = is_lookup.size();
+    if ((i + 1) * ROW_WORDS > rows.size()) {
+        // grow the logical size in blocks of 4096 steps so the per-step cost is one bounds check; rows beyond
+        // stepCount() are scratch until recorded (consumers use stepCount(), never rows.size())
+        size_t want = (i + 4096) * ROW_WORDS;
+        if (want > rows.capacity()) rows.reserve(rows.capacity() * 2 > want ? rows.capacity() * 2 : want);
+        rows.resize(want);
+    }
+    return rows.data() + i * ROW_WORDS;
+}
+
 void VMState::step() {  // state.zig:128-167
     if (halted) throw Error(ERR_VM_HALTED, "error.VMHalted");
     Instruction in;
@@ -254,9 +271,7 @@ void VMState::step() {  // state.zig:128-167
     uint64_t mem_row[3] = {0, 0, 0};
     const uint64_t pc_before = pc;
     const uint64_t next_pc = execute(in, mem_row);
-    const size_t i = trace.is_lookup.size();
-    trace.rows.resize((i + 1) * ROW_WORDS);
-    uint64_t *row = trace.rows.data() + i * ROW_WORDS;
+    uint64_t *row = trace.appendRow();
     row[0] = pc_before;
     for (unsigned r = 0; r < 32; r++) row[1 + r] = readReg(r);
     row[33] = in.opcode; row[34] = in.rd; row[35] = in.rs1; row[36] = in.rs2; row[37] = in.funct3; row[38] = in.funct7;

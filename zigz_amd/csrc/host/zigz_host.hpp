@@ -158,10 +158,12 @@ struct Segment { uint64_t vaddr; std::vector<uint8_t> data; };  // src/elf.zig:8
 // `mod p` are the witness cells of that step (witness.zig:76,112,164-170,237-239).
 constexpr size_t ROW_WORDS = 43;
 struct ExecutionTrace {  // trace.zig:16-70 (steps kept as packed rows instead of Step structs)
-    std::vector<uint64_t> rows;     // [num_steps][43] raw u64
+    std::vector<uint64_t> rows;     // [num_steps][43] raw u64 (capacity grows in large chunks; see appendRow)
     std::vector<uint8_t> is_lookup; // per step
     size_t stepCount() const { return is_lookup.size(); }
     const uint64_t *row(size_t i) const { return rows.data() + i * ROW_WORDS; }
+    void reserveSteps(size_t n);    // virtual reservation only: pages are touched as steps are recorded
+    uint64_t *appendRow();          // storage of the next step's 43 words (trace.addStep)
 };
 class VMState {  // state.zig:35-598
   public:

@@ -348,24 +348,35 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
     return Digest{{x.x, x.y, y.x, y.y}};
 }
 
+// HPT hashes per thread (strided by the workgroup size so loads/stores stay coalesced): amortises wave launch
+// and set-up over several ~4.2 k-instruction permutations.
+constexpr int HPT = 4;
 __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                        size_t tree_stride_nodes) {
     const size_t col = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= npad) return;
-    const uint64_t v = i < n_values ? vals[col * val_stride + i] : 0;  // pad with hashLeaf(0), merkle_tree.zig:302-306
-    store_digest(tree + col * tree_stride_nodes * 32, i, sha3_leaf(v));
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const uint32_t *v = vals + col * val_stride;
+#pragma unroll 1
+    for (int h = 0; h < HPT; h++) {
+        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
+        if (i >= npad) return;
+        const uint64_t x = i < n_values ? v[i] : 0;  // pad with hashLeaf(0), merkle_tree.zig:302-306
+        store_digest(t, i, sha3_leaf(x));
+    }
 }
 
 __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                       size_t in_off, size_t out_off, size_t n_out) {
     const size_t col = blockIdx.y;
-    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (i >= n_out) return;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
-    Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
-    store_digest(t, out_off + i, sha3_node(l, r));
+#pragma unroll 1
+    for (int h = 0; h < HPT; h++) {
+        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
+        if (i >= n_out) return;
+        Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
+        store_digest(t, out_off + i, sha3_node(l, r));
+    }
 }
 
 // Finishes a tree from a level of at most 2*TPB nodes up to the root in ONE launch (one workgroup
@@ -389,14 +400,14 @@ __global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, 
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                           size_t tree_stride_nodes, size_t ncols, hipStream_t s) {
-    dim3 grid((unsigned)((npad + TPB - 1) / TPB), (unsigned)ncols);
+    dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
     hipLaunchKernelGGL(k_keccak_leaves, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
                        tree_stride_nodes);
 }
 
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
                          size_t ncols, hipStream_t s) {
-    dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
+    dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
     hipLaunchKernelGGL(k_keccak_level, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
 }
 
