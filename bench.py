@@ -191,7 +191,8 @@ def main():
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
                        "parallelism": "independent traces: %d GPU x %d concurrent proofs" % (world, B)},
-            "roofline": {"kernel": "k_bind_vec (MLE bind, 43 columns batched; eval folds inside the timed region)",
+            "roofline": {"kernel": "k_radix_fold (MLE bind of the top v-10 variables of all 43 columns in one pass: the bulk "
+                                   "of the 43 evals inside the timed region; 4 B read per element + partial sums)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
                          "uncontended": {"achieved": (solo_st["bind_vec_bytes"] / 1e9) / (solo_st["bind_vec_us"] / 1e6),

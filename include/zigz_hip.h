@@ -217,14 +217,16 @@ typedef struct zigz_kernel_stats {
     double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch, or all binds of the last sumcheck */
     uint64_t bind_launches;
     uint64_t keccak_permutations;
-    /* vector-path MLE bind launches (kernel k_bind_vec) of the last eval / sumcheck / bind call, each timed
-     * with its own HIP event pair: total device time, launch count, algorithmic bytes (6 B per table element) */
+    /* the bulk MLE-bind launches of the last eval / sumcheck / bind call, each timed with its own HIP event pair:
+     * total device time, launch count, algorithmic bytes.  Kernel k_radix_fold (one pass binding v-10 variables,
+     * 4 B read per element) for evals of tables >= 2^14, k_bind_vec (6 B per table element) otherwise. */
     double bind_vec_us;
     uint64_t bind_vec_launches;
     uint64_t bind_vec_bytes;
 } zigz_kernel_stats;
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
-/* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form */
+/* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
+ * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form */
 zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
 

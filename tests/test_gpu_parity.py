@@ -389,3 +389,32 @@ def test_sumcheck_radix_equals_per_round(ctx, nv):
         assert np.array_equal(a[0], o[0]) and np.array_equal(a[1], o[1]) and a[2] == o[2]
         o2 = O.sumcheck_prove(P, ev, chs)
         assert np.array_equal(a2[0], o2[0]) and a2[2] == o2[2]
+
+
+@pytest.mark.parametrize("nv", [14, 15, 17, 20])
+def test_eval_radix_equals_folds(ctx, nv):
+    """Evals of tables >= 2^14 run as one radix pass + a 1024-term weighted dot; must equal the fold form and
+    (where affordable) the oracle's naive eval, batched over ragged column counts."""
+    N = 1 << nv
+    d = ctx.dev_alloc(N * 4)
+    try:
+        ev = rnd(1200 + nv, N)
+        ctx.upload(ev, d)
+        for s in range(2):
+            pt = rnd(1300 + nv + s, nv)
+            ctx.set_option("fold_eval", 0)
+            a = ctx.dev_mle_eval(d, N, pt)
+            ctx.set_option("fold_eval", 1)
+            b = ctx.dev_mle_eval(d, N, pt)
+            ctx.set_option("fold_eval", 0)
+            assert a == b
+            if nv <= 17:
+                assert a == O.mle_eval(P, ev, pt)
+        for pt in ([0] * nv, [1] * nv, [P - 1] * nv, [1] + [0] * (nv - 1)):
+            ctx.set_option("fold_eval", 1)
+            b = ctx.dev_mle_eval(d, N, pt)
+            ctx.set_option("fold_eval", 0)
+            assert ctx.dev_mle_eval(d, N, pt) == b
+        assert ctx.dev_mle_eval(d, N, [1] + [0] * (nv - 1)) == int(ev[1])  # point[0] is the LSB
+    finally:
+        ctx.dev_free(d)

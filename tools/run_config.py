@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Run one BASELINE config at full size on one GPU and check it:
+   --config 2  fibonacci, 2^16 trace          (byte-exact vs the oracle's literal prove)
+   --config 3  RV64I ADD/XOR loop, 2^20
+   --config 4  RV64IM mixed loop, 2^22
+   --config 5  fibonacci guest semantics, 2^24 (needs ~60 GB of HBM and ~12 GB of host memory)
+Checks: Verifier.verify (host mirror) and the oracle's verifier accept; proof size formula; for `--check-cols k`
+columns the Merkle root / opened leaf / value are recomputed by the oracle from the host witness."""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import zigz_amd  # noqa: E402
+from zigz_amd import host  # noqa: E402
+import oracle_lib as O  # noqa: E402
+import programs  # noqa: E402
+
+P = O.P_BB
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--config", type=int, default=4)
+    ap.add_argument("--check-cols", type=int, default=2)
+    args = ap.parse_args()
+    nv = {2: 16, 3: 20, 4: 22, 5: 24}[args.config]
+    N = 1 << nv
+    inp = None
+    if args.config in (2, 5):
+        prog, inp = programs.fibonacci((N - 12) // 5)
+    elif args.config == 3:
+        prog = programs.add_xor_loop((N - 3) // 4)
+    else:
+        prog = programs.mixed_loop((N - 7) // 12)
+    out = {"config": args.config, "nv": nv}
+    ctx = zigz_amd.Context(0)
+    t0 = time.perf_counter()
+    tr = host.Trace(prog, 0x1000, None, 2 * N, inp)
+    out["vm_s"] = time.perf_counter() - t0
+    assert tr.num_vars == nv, (tr.num_steps, tr.num_vars)
+    out.update(num_steps=tr.num_steps, lookups=tr.num_lookups)
+    d = ctx.dev_alloc(43 * N * 4)
+    t0 = time.perf_counter()
+    tr.witness_to_device(ctx, d, N)
+    out["witness_to_device_s"] = time.perf_counter() - t0
+    tr.prove(ctx, d, N, want_bytes="borrow")  # warm-up (workspace allocation)
+    ctx.enable_timing(True)
+    t0 = time.perf_counter()
+    bp = tr.prove(ctx, d, N, want_bytes="borrow")
+    out["prove_s"] = time.perf_counter() - t0
+    out["steps_per_s"] = tr.num_steps / out["prove_s"]
+    st = ctx.stats()
+    out["merkle_build_ms"] = st["merkle_build_us"] / 1e3
+    out["eval_ms"] = st["eval_us"] / 1e3
+    out["bind_vec_GBs"] = (st["bind_vec_bytes"] / 1e9) / (st["bind_vec_us"] / 1e6)
+    out["phases_ms"] = {k: v * 1e3 for k, v in host.last_timings().items()}
+    proof = bp.tobytes()
+    out["proof_bytes"] = len(proof)
+    n_out = 2 if inp is not None else 0
+    assert len(proof) == O.proof_size(nv, 0, n_out, tr.num_lookups)
+    t0 = time.perf_counter()
+    assert host.verify(proof, prog) == "Accept"
+    assert O.verify(P, proof, prog) == (0, 0)
+    out["verify_both_s"] = time.perf_counter() - t0
+    if args.config == 2:
+        oproof, _ = O.prove(P, prog, 0x1000, None, 2 * N, inp)
+        assert oproof == proof
+        out["byte_identical_to_oracle"] = True
+    if args.check_cols:
+        cols = tr.witness()
+        off = 32 + (324 + 8 * n_out) + (40 * nv + 8) + (4 + 24 * tr.num_lookups)
+        rec = 68 + 41 * nv
+        for c in [0, 3, 41][: args.check_cols]:
+            r = proof[off + c * rec: off + (c + 1) * rec]
+            lv, h = O.merkle_levels(cols[c])
+            assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r[:32], c
+            pts = np.frombuffer(r[32:32 + 8 * nv], dtype="<u8")
+            val, val2, idx, leaf = (int(x) for x in np.frombuffer(r[32 + 8 * nv: 64 + 8 * nv], dtype="<u8"))
+            assert idx == int(pts[0]) % N and leaf == int(cols[c][idx]) and val == val2
+            _, _, fe = O.sumcheck_prove(P, cols[c], [int(x) for x in pts[::-1]])  # eval by folds in the oracle
+            assert fe == val, c
+        out["checked_columns_vs_oracle"] = args.check_cols
+    ctx.dev_free(d)
+    ctx.close()
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -33,6 +33,7 @@ struct zigz_ctx {
     uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
+    bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs for k_bind_vec timing
     int pool_used;
@@ -239,6 +240,7 @@ extern "C" zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable) {
 extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value) {
     if (!ctx || !name) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
@@ -439,6 +441,48 @@ extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_i
     return ZIGZ_OK;
 }
 
+// eval(point) for tables >= 2^14, batched over columns, in ONE pass over the data: the first k1 = v - 10 variables
+// (MSB side, i.e. point[v-1] ... point[10]) are bound by a radix-2^k1 fold with eq weights built on the device,
+// leaving 1024 elements per column that a weighted dot product with the eq weights of point[9..0] finishes.
+// HBM traffic 4*N B per column instead of 12*N for v successive binds.  Exact arithmetic => same value.
+static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t col_stride, size_t ncols, size_t nv,
+                                  const uint64_t *points, uint32_t *d_vals) {
+    const size_t N = (size_t)1 << nv;
+    const unsigned k2 = 10, k1 = (unsigned)nv - k2;
+    const size_t m = (size_t)1 << k2, nb = (size_t)1 << k1, groups = radix_fold_groups(nb);
+    if (nv * ncols * 4 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *rt = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);  // [col][j], j-th bound variable = point[v-1-j]
+    for (size_t c = 0; c < ncols; c++)
+        for (size_t j = 0; j < nv; j++) {
+            const uint64_t r = points[c * nv + (nv - 1 - j)];
+            if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
+            rt[c * nv + j] = host_to_mont(r);
+        }
+    void *d_rt;
+    CHK(ws_get(ctx, WS_MISC, nv * ncols * 4 + 64, &d_rt));
+    HIPCHK(ctx, hipMemcpyAsync(d_rt, rt, nv * ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    // workspace: part[ncols][groups][m] u64 | W1[ncols][nb] u32 | W2[ncols][m] u32 | T1[ncols][m] u32
+    void *ws;
+    CHK(ws_get(ctx, WS_FOLD, ncols * (groups * m * 8 + nb * 4 + m * 4 + m * 4) + 256, &ws));
+    unsigned long long *d_part = (unsigned long long *)ws;
+    uint32_t *d_w1 = (uint32_t *)(d_part + ncols * groups * m), *d_w2 = d_w1 + ncols * nb, *d_t1 = d_w2 + ncols * m;
+    launch_eq_weights((const uint32_t *)d_rt, nv, k1, d_w1, nb, ncols, ctx->stream);
+    launch_eq_weights((const uint32_t *)d_rt + k1, nv, k2, d_w2, m, ncols, ctx->stream);
+    bind_pool_reset(ctx);
+    const bool rec = ctx->timing;
+    if (rec) HIPCHK(ctx, hipEventRecord(ctx->pool[0], ctx->stream));
+    launch_radix_fold(d_cols, col_stride, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream);  // the one pass over the data
+    if (rec) {
+        HIPCHK(ctx, hipEventRecord(ctx->pool[1], ctx->stream));
+        ctx->pool_used = 1;
+        ctx->pool_bytes = (uint64_t)ncols * (N * 4 + groups * m * 8);  // one read of the tables + the partial sums
+    }
+    launch_radix_finalize(d_part, groups * m, groups, d_t1, m, m, 0, nullptr, ncols, ctx->stream);
+    launch_weighted_dot(d_t1, m, d_w2, m, m, d_vals, ncols, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return ZIGZ_OK;
+}
+
 // eval(point), multilinear.zig:110-144: point[0] <-> LSB.  Computed as v MSB-first binds with the
 // point reversed (exact arithmetic => the same canonical value as the reference's O(v*2^v) loop).
 // Batched over `ncols` columns, column c using point row c.  Result words land in d_vals[ncols].
@@ -450,6 +494,8 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
         HIPCHK(ctx, hipGetLastError());
         return ZIGZ_OK;
     }
+    if (nv >= 14 && nv <= 24 && col_stride % 4 == 0 && !ctx->fold_eval)
+        return dev_eval_radix(ctx, d_cols, col_stride, ncols, nv, points, d_vals);
     // r table in Montgomery form, [round][col], staged in the upper half of the pinned buffer so the
     // asynchronous H2D copy never reads freed host memory
     if (nv * ncols * 4 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -609,11 +655,12 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
     };
     unsigned k = nv - 8 < RADIX_MAX_K ? nv - 8 : RADIX_MAX_K;
     size_t len = n, m = len >> k;
-    // workspace: two (acc u64[m0], out u32[m0]) regions, sized by the first (largest) stage output
-    const size_t m0 = m;
+    // workspace: partial sums u64[G][m0] + two out u32[m0] regions, sized by the first (largest) stage
+    const size_t m0 = m, g0 = radix_fold_groups((size_t)1 << k);
     void *ws;
-    CHK(ws_get(ctx, WS_SCRATCH, 2 * m0 * 12 + 256, &ws));
-    uint8_t *wsb = (uint8_t *)ws;
+    CHK(ws_get(ctx, WS_SCRATCH, g0 * m0 * 8 + 2 * m0 * 4 + 256, &ws));
+    unsigned long long *d_part = (unsigned long long *)ws;
+    uint32_t *d_outs = (uint32_t *)(d_part + g0 * m0);
     void *wbuf;
     CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &wbuf));
     unsigned long long *d_B = ctx->d_sums;  // two alternating regions of 1024 block sums
@@ -645,14 +692,12 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
         uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
         for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(W[b]);
         HIPCHK(ctx, hipMemcpyAsync(wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        uint8_t *region = wsb + (stage & 1) * (m0 * 12 + 128);
-        unsigned long long *d_acc = (unsigned long long *)region;
-        uint32_t *d_out = (uint32_t *)(region + m0 * 8);
-        HIPCHK(ctx, hipMemsetAsync(d_acc, 0, m * 8, ctx->stream));
-        launch_radix_fold(cur, m, nb, (const uint32_t *)wbuf, d_acc, ctx->stream);
+        uint32_t *d_out = d_outs + (stage & 1) * m0;
+        const size_t groups = radix_fold_groups(nb);
+        launch_radix_fold(cur, 0, m, nb, (const uint32_t *)wbuf, 0, d_part, 0, 1, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         if (m <= HOST_TAIL_MAX) {
-            launch_radix_finalize(d_acc, d_out, m, 0, nullptr, ctx->stream);
+            launch_radix_finalize(d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
             HIPCHK(ctx, hipGetLastError());
             uint32_t *h32 = (uint32_t *)ctx->h_pin;
             HIPCHK(ctx, hipMemcpyAsync(h32, d_out, m * 4, hipMemcpyDeviceToHost, ctx->stream));
@@ -664,7 +709,7 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
         const unsigned k2 = lm - 8 < RADIX_MAX_K ? lm - 8 : RADIX_MAX_K;
         unsigned long long *d_B2 = ctx->d_sums + (((stage + 1) & 1) ? 1024 : 0);
         HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k2) * 8, ctx->stream));
-        launch_radix_finalize(d_acc, d_out, m, lm - k2, d_B2, ctx->stream);
+        launch_radix_finalize(d_part, 0, groups, d_out, 0, m, lm - k2, d_B2, 1, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         B.assign((size_t)1 << k2, 0);
         CHK(read_u64(ctx, d_B2, (size_t)1 << k2, B.data()));

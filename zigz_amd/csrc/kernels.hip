@@ -205,62 +205,134 @@ void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned
                        d_sums);
 }
 
-// acc[i] += sum over a chunk of RB block indices b of W[b] * in[b*m + i].  Thread = 4 consecutive outputs
-// (16-byte loads, coalesced across the wave), RB independent loads in flight; the b range is split over
-// gridDim.y so that even a 2^20 table (m = 1024) spreads over the chip; partial results meet in u64 atomics
-// (exact: integer adds commute), one per output per chunk.
-constexpr int RB = 16;
-__global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t m, size_t nb,
-                                                    const uint32_t *__restrict__ w_m,
-                                                    unsigned long long *__restrict__ acc) {
+// Radix-2^k fold  T'[i] = sum_b W[b] * T[b*m + i].  Work split: a workgroup owns 1024 consecutive outputs (one
+// 16-byte load per lane per table row) and RB*RLOOPS = 64 CONSECUTIVE rows, i.e. it streams one contiguous range when
+// m = 1024 and long row segments otherwise -- the HBM access pattern of k_bind_vec.  Each (row-group g, output i)
+// partial sum is written once as an exact u64 (part[col][g][i]; no atomics, no memset); k_radix_finalize adds the
+// G = nb/64 partials and reduces mod p.
+constexpr int RB = 16;     // independent 16-byte loads in flight per lane
+constexpr int RLOOPS = 4;  // RB-chunks per thread: accumulators stay in registers
+__global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t in_stride, size_t m, size_t nb,
+                                                    const uint32_t *__restrict__ w_m, size_t w_stride,
+                                                    unsigned long long *__restrict__ part, size_t part_col_stride) {
     const size_t q = (size_t)blockIdx.x * TPB + threadIdx.x;  // uint4 index of the outputs
     if (q * 4 >= m) return;
-    const size_t b0 = (size_t)blockIdx.y * RB;
-    const uint4 *p = reinterpret_cast<const uint4 *>(in) + q;
+    const size_t col = blockIdx.z;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride) + q;
+    const uint32_t *w = w_m + col * w_stride;
     const size_t mq = m / 4;
-    uint4 v[RB];
-#pragma unroll
-    for (int j = 0; j < RB; j++) v[j] = (b0 + j < nb) ? p[(b0 + j) * mq] : make_uint4(0, 0, 0, 0);
     unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+#pragma unroll 1
+    for (int l = 0; l < RLOOPS; l++) {
+        const size_t b0 = ((size_t)blockIdx.y * RLOOPS + l) * RB;
+        if (b0 >= nb) break;
+        uint4 v[RB];
 #pragma unroll
-    for (int j = 0; j < RB; j++) {
-        const uint32_t w = (b0 + j < nb) ? w_m[b0 + j] : 0;  // wave-uniform
-        s0 += mont_mul(w, v[j].x);
-        s1 += mont_mul(w, v[j].y);
-        s2 += mont_mul(w, v[j].z);
-        s3 += mont_mul(w, v[j].w);
+        for (int j = 0; j < RB; j++) v[j] = (b0 + j < nb) ? p[(b0 + j) * mq] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int j = 0; j < RB; j++) {
+            const uint32_t wj = (b0 + j < nb) ? w[b0 + j] : 0;  // wave-uniform
+            s0 += mont_mul(wj, v[j].x);
+            s1 += mont_mul(wj, v[j].y);
+            s2 += mont_mul(wj, v[j].z);
+            s3 += mont_mul(wj, v[j].w);
+        }
     }
-    unsigned long long *o = acc + q * 4;
-    atomicAdd(o + 0, s0);
-    atomicAdd(o + 1, s1);
-    atomicAdd(o + 2, s2);
-    atomicAdd(o + 3, s3);
+    ulonglong2 *o = reinterpret_cast<ulonglong2 *>(part + col * part_col_stride + (size_t)blockIdx.y * m + q * 4);
+    o[0] = make_ulonglong2(s0, s1);
+    o[1] = make_ulonglong2(s2, s3);
 }
 
-void launch_radix_fold(const uint32_t *d_in, size_t m, size_t nb, const uint32_t *d_w_m, unsigned long long *d_acc,
-                       hipStream_t s) {
-    dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)((nb + RB - 1) / RB));
-    hipLaunchKernelGGL(k_radix_fold, grid, dim3(TPB), 0, s, d_in, m, nb, d_w_m, d_acc);
+size_t radix_fold_groups(size_t nb) { return (nb + RB * RLOOPS - 1) / (RB * RLOOPS); }
+
+void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
+                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s) {
+    dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)radix_fold_groups(nb), (unsigned)ncols);
+    hipLaunchKernelGGL(k_radix_fold, grid, dim3(TPB), 0, s, d_in, in_stride, m, nb, d_w_m, w_stride, d_part,
+                       part_col_stride);
 }
 
-__global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ acc,
-                                                        uint32_t *__restrict__ out, size_t m, unsigned log2_m2,
-                                                        unsigned long long *__restrict__ sums) {
+__global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ part, size_t part_col_stride,
+                                                        size_t groups, uint32_t *__restrict__ out, size_t out_stride,
+                                                        size_t m, unsigned log2_m2, unsigned long long *__restrict__ sums) {
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t col = blockIdx.z;
     uint32_t v = 0;
     if (i < m) {
-        v = (uint32_t)(acc[i] % (unsigned long long)P);
-        out[i] = v;
+        const unsigned long long *pp = part + col * part_col_stride + i;
+        unsigned long long t = 0;
+        for (size_t g = 0; g < groups; g++) t += pp[g * m];
+        v = (uint32_t)(t % (unsigned long long)P);
+        out[col * out_stride + i] = v;
     }
-    if (sums) {  // m2 >= 256: the 64 outputs of a wave fall into one block of the next stage
+    if (sums) {  // single-column use; m2 >= 256: the 64 outputs of a wave fall into one block of the next stage
         unsigned long long t = wave_sum((unsigned long long)v);
         if ((threadIdx.x & 63) == 0 && i < m && t) atomicAdd(&sums[i >> log2_m2], t);
     }
 }
 
-void launch_radix_finalize(const unsigned long long *d_acc, uint32_t *d_out, size_t m, unsigned log2_m2,
-                           unsigned long long *d_sums, hipStream_t s) {
-    hipLaunchKernelGGL(k_radix_finalize, dim3((unsigned)((m + TPB - 1) / TPB)), dim3(TPB), 0, s, d_acc, d_out, m, log2_m2, d_sums);
+void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
+                           size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
+                           hipStream_t s) {
+    dim3 grid((unsigned)((m + TPB - 1) / TPB), 1, (unsigned)ncols);
+    hipLaunchKernelGGL(k_radix_finalize, grid, dim3(TPB), 0, s, d_part, part_col_stride, groups, d_out, out_stride, m, log2_m2,
+                       d_sums);
+}
+
+// eq weights by doubling in LDS, one workgroup per column (all values Montgomery form: mont_mul keeps the form)
+__global__ __launch_bounds__(TPB) void k_eq_weights(const uint32_t *__restrict__ r_m, size_t r_stride, unsigned k,
+                                                    uint32_t *__restrict__ w_m, size_t w_stride) {
+    extern __shared__ uint32_t eqw[];
+    const size_t col = blockIdx.x;
+    if (threadIdx.x == 0) eqw[0] = R_MOD_P;
+    __syncthreads();
+    for (unsigned j = 0; j < k; j++) {
+        const uint32_t r = r_m[col * r_stride + j];
+        const uint32_t one_minus = sub_mod(R_MOD_P, r);
+        const size_t cur = (size_t)1 << j;
+        // in-place doubling from the top so sources are read before they are overwritten: W'[2x+1], W'[2x] <- W[x]
+        for (size_t base = 0; base < cur; base += TPB) {
+            const size_t x = cur - 1 - (base + threadIdx.x);  // descending order across iterations
+            uint32_t v = 0;
+            const bool live = base + threadIdx.x < cur;
+            if (live) v = eqw[x];
+            __syncthreads();
+            if (live) {
+                eqw[2 * x + 1] = mont_mul(v, r);
+                eqw[2 * x] = mont_mul(v, one_minus);
+            }
+            __syncthreads();
+        }
+    }
+    for (size_t i = threadIdx.x; i < ((size_t)1 << k); i += TPB) w_m[col * w_stride + i] = eqw[i];
+}
+
+void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
+                       hipStream_t s) {
+    hipLaunchKernelGGL(k_eq_weights, dim3((unsigned)ncols), dim3(TPB), ((size_t)1 << k) * 4, s, d_r_m, r_stride, k, d_w_m,
+                       w_stride);
+}
+
+__global__ __launch_bounds__(TPB) void k_weighted_dot(const uint32_t *__restrict__ in, size_t in_stride,
+                                                      const uint32_t *__restrict__ w_m, size_t w_stride, size_t n,
+                                                      uint32_t *__restrict__ out) {
+    __shared__ unsigned long long red[TPB / 64];
+    const size_t col = blockIdx.x;
+    unsigned long long acc = 0;
+    for (size_t i = threadIdx.x; i < n; i += TPB) acc += mont_mul(w_m[col * w_stride + i], in[col * in_stride + i]);
+    acc = wave_sum(acc);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < TPB / 64; w++) t += red[w];
+        out[col] = (uint32_t)(t % (unsigned long long)P);
+    }
+}
+
+void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
+                         uint32_t *d_out, size_t ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_weighted_dot, dim3((unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, d_w_m, w_stride, n, d_out);
 }
 
 // ------------------------------------------------------------------ layout conversion at the boundary
@@ -366,16 +438,42 @@ __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restric
     }
 }
 
+// One level.  The 64 hashes of a wave consume 4 KiB of contiguous child digests: they are fetched with fully
+// coalesced 16-byte loads (1 KiB per wave instruction) and handed to their lanes through LDS (rows padded to 80 B so
+// the per-lane 4 x ds_read_b128 are bank-conflict free), instead of four 64-byte-strided loads per lane.
+// Requires n_out % 64 == 0 (levels handled here have >= 512 nodes).
+template <int H>
 __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                       size_t in_off, size_t out_off, size_t n_out) {
+    __shared__ uint4 stage[TPB / 64][64 * 5];
     const size_t col = blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll 1
-    for (int h = 0; h < HPT; h++) {
-        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
-        if (i >= n_out) return;
-        Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
-        store_digest(t, out_off + i, sha3_node(l, r));
+    for (int h = 0; h < H; h++) {
+        const size_t first = ((size_t)blockIdx.x * H + h) * TPB + (size_t)wave * 64;  // first output node of this wave
+        const bool active = first < n_out;                                          // wave-uniform
+        if (active) {
+            const uint4 *g = reinterpret_cast<const uint4 *>(t + (in_off + 2 * first) * 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const unsigned c = lane + 64 * k;  // 16-byte chunk of the wave's 4 KiB
+                stage[wave][(c >> 2) * 5 + (c & 3)] = g[c];
+            }
+        }
+        __syncthreads();
+        if (active) {
+            const uint4 *r = &stage[wave][lane * 5];
+            const uint4 a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3];
+            Digest l{{((uint64_t)a0.y << 32) | a0.x, ((uint64_t)a0.w << 32) | a0.z, ((uint64_t)a1.y << 32) | a1.x,
+                      ((uint64_t)a1.w << 32) | a1.z}};
+            Digest rr{{((uint64_t)b0.y << 32) | b0.x, ((uint64_t)b0.w << 32) | b0.z, ((uint64_t)b1.y << 32) | b1.x,
+                       ((uint64_t)b1.w << 32) | b1.z}};
+            // (staging the 32-byte digest stores through LDS as well was measured slower: the extra barriers cost
+            // more than the half-coalesced stores)
+            store_digest(t, out_off + first + lane, sha3_node(l, rr));
+        }
+        __syncthreads();
     }
 }
 
@@ -407,8 +505,14 @@ void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_va
 
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
                          size_t ncols, hipStream_t s) {
-    dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_keccak_level, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+    // several hashes per thread only while that still leaves >= 16 workgroups per CU (small levels need the waves)
+    if (n_out * ncols >= (size_t)TPB * HPT * 4096) {
+        dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
+        hipLaunchKernelGGL(k_keccak_level<HPT>, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+    } else {
+        dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
+        hipLaunchKernelGGL(k_keccak_level<1>, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+    }
 }
 
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,

@@ -38,12 +38,23 @@ void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t n
 // Radix-2^k sumcheck stage (k rounds per pass over the table; see DESIGN.md "Sumcheck"):
 //  (1) block sums: sums[b] += sum of in[b*m .. (b+1)*m), b < n/m   (m = 2^log2_m >= 256, n >= 1024, exact u64)
 void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s);
-//  (2) acc[i] += sum_b W[b] * in[b*m + i]  (i < m, b < nb; W in Montgomery form; acc exact u64, zeroed by the caller)
-void launch_radix_fold(const uint32_t *d_in, size_t m, size_t nb, const uint32_t *d_w_m, unsigned long long *d_acc,
+//  (2) part[c][g][i] = sum over the g-th group of 64 consecutive b of W[c][b] * in[c][b*m + i]   (exact u64; i < m,
+//      m % 4 == 0, column c < ncols; W in Montgomery form; G = radix_fold_groups(nb) groups; strides in elements)
+size_t radix_fold_groups(size_t nb);
+void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
+                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s);
+//  (3) out[c][i] = (sum_g part[c][g][i]) mod p; if d_sums (ncols == 1): sums[i >> log2_m2] += out[i]  (block sums of
+//      the next stage, m2 >= 256; must be zeroed by the caller)
+void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
+                           size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
+                           hipStream_t s);
+// eq weights of k variables, Montgomery form: W[c][b] = prod_j (bit_j(b) ? r_cj : 1 - r_cj) with bit 0 of the
+// loop being the MOST significant bit of b; d_r_m[c*r_stride + j] = r_cj in Montgomery form.  k <= 14.
+void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
                        hipStream_t s);
-//  (3) out[i] = acc[i] mod p; if d_sums: sums[i >> log2_m2] += out[i]  (next stage's block sums, m2 >= 256)
-void launch_radix_finalize(const unsigned long long *d_acc, uint32_t *d_out, size_t m, unsigned log2_m2,
-                           unsigned long long *d_sums, hipStream_t s);
+// out[c] = sum_i W[c][i] * in[c][i] mod p  (i < n <= 16384; W Montgomery, in canonical)
+void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
+                         uint32_t *d_out, size_t ncols, hipStream_t s);
 
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
