@@ -67,3 +67,44 @@ def fibonacci(n):
         0x00100073,                              # EBREAK
     ]
     return _pack(w), [n]
+
+
+def random_program(rng, n_insts=60):
+    """Random straight-line RV64IM program (ALU / ALU-imm / *W / M / loads+stores at small addresses / LUI / AUIPC):
+    exercises sign extension, shifts and division corner cases.  rng: numpy Generator."""
+    ops_r = [(0x33, f3, f7) for f3 in range(8) for f7 in (0, 0x20, 1)] + [(0x3b, f3, f7) for f3, f7 in
+             ((0, 0), (0, 0x20), (1, 0), (5, 0), (5, 0x20), (0, 1), (4, 1), (5, 1), (6, 1), (7, 1))]
+    words = []
+    for r in range(1, 8):
+        words.append((int(rng.integers(0, 1 << 20)) << 12) | (r << 7) | 0x37)
+        words.append((int(rng.integers(0, 1 << 12)) << 20) | (r << 15) | (r << 7) | 0x13)
+        if rng.integers(0, 2):
+            words.append((int(rng.integers(0, 64)) << 20) | (r << 15) | (1 << 12) | (r << 7) | 0x13)
+    for _ in range(n_insts):
+        kind = int(rng.integers(0, 5))
+        rd, rs1, rs2 = (int(x) for x in rng.integers(0, 8, 3))
+        if kind == 0:
+            op, f3, f7 = ops_r[int(rng.integers(0, len(ops_r)))]
+            if op == 0x33 and f7 == 0x20 and f3 not in (0, 5):
+                f7 = 0
+            words.append((f7 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op)
+        elif kind == 1:
+            f3 = int(rng.integers(0, 8))
+            imm = int(rng.integers(0, 1 << 12))
+            if f3 == 1:
+                imm &= 63
+            if f3 == 5:
+                imm = (imm & 63) | (0x400 if rng.integers(0, 2) else 0)
+            words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x13)
+        elif kind == 2:
+            f3 = [0, 1, 5][int(rng.integers(0, 3))]
+            imm = int(rng.integers(0, 1 << 12)) if f3 == 0 else (int(rng.integers(0, 32)) | (0x400 if (f3 == 5 and rng.integers(0, 2)) else 0))
+            words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x1b)
+        elif kind == 3:
+            f3s = int(rng.integers(0, 4)); off = int(rng.integers(0, 64))
+            words.append(((off >> 5) << 25) | (rs2 << 20) | (0 << 15) | (f3s << 12) | ((off & 31) << 7) | 0x23)
+            f3l = int(rng.integers(0, 7))
+            words.append((off << 20) | (0 << 15) | (f3l << 12) | (rd << 7) | 0x03)
+        else:
+            words.append((int(rng.integers(0, 1 << 20)) << 12) | (rd << 7) | (0x17 if rng.integers(0, 2) else 0x37))
+    return _pack(words)

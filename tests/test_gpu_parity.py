@@ -418,3 +418,30 @@ def test_eval_radix_equals_folds(ctx, nv):
         assert ctx.dev_mle_eval(d, N, [1] + [0] * (nv - 1)) == int(ev[1])  # point[0] is the LSB
     finally:
         ctx.dev_free(d)
+
+
+def test_unaligned_device_pointers(ctx):
+    """Device-resident entry points must accept tables whose base is only 4-byte aligned (e.g. a slice of a larger
+    buffer): the 16-byte vector kernels then give way to the scalar ones -- same results, no fault."""
+    nv = 15
+    n = 1 << nv
+    ev = rnd(4242, n)
+    d = ctx.dev_alloc((n + 8) * 4)
+    o = ctx.dev_alloc((n + 8) * 4)
+    try:
+        for off in (1, 2, 3):
+            ctx.upload(ev, d + 4 * off)
+            r = int(rnd(off, 1)[0])
+            ctx.dev_mle_bind(d + 4 * off, n, r, o + 4 * off)
+            assert np.array_equal(ctx.download(o + 4 * off, n // 2), O.mle_partial_eval(P, ev, r))
+            s = ctx.dev_mle_half_sums(d + 4 * off, n)
+            rp = O.mle_round_poly(P, ev)
+            assert s[0] == rp[0] and (s[1] - s[0]) % P == rp[1]
+            pt = rnd(10 + off, nv)
+            assert ctx.dev_mle_eval(d + 4 * off, n, pt) == O.mle_eval(P, ev, pt)
+            a = ctx.dev_sumcheck_prove(d + 4 * off, n)
+            b = O.sumcheck_prove(P, ev)
+            assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[2] == b[2]
+    finally:
+        ctx.dev_free(d)
+        ctx.dev_free(o)

@@ -182,3 +182,17 @@ def test_concurrent_proofs_on_one_gpu(ctx):
     [t.join() for t in th]
     assert not errs, errs
     assert got == expect
+
+
+def test_prove_random_programs_vs_oracle(ctx):
+    """25 random straight-line RV64IM programs (random lengths => ragged num_steps, loads/stores, initial registers):
+    proof bytes from the HIP path == proof bytes from the oracle."""
+    from zigz_amd import host
+    rng = np.random.default_rng(2024)
+    for trial in range(25):
+        prog = programs.random_program(rng, n_insts=int(rng.integers(1, 200)))
+        iregs = None if trial % 3 else [0] + [int(x) for x in rng.integers(0, 2**63, size=int(rng.integers(1, 12)), dtype=np.int64)]
+        proof, ns = host.prove(ctx, prog, 0x1000 + 4 * trial, iregs, 1 << 20)
+        oproof, ons = O.prove(P, prog, 0x1000 + 4 * trial, iregs, 1 << 20)
+        assert ns == ons and proof == oproof, trial
+        assert host.verify(proof, prog) == "Accept"

@@ -52,44 +52,10 @@ def test_trace_and_witness_golden(i):
 def test_vm_random_programs_vs_oracle():
     """Random straight-line RV64IM programs (ALU/ALU-imm/*W/M/load/store/LUI/AUIPC): final registers and
     witness must equal the oracle's, including sign/shift/division corner cases."""
+    import programs
     rng = np.random.default_rng(42)
-    ops_r = [(0x33, f3, f7) for f3 in range(8) for f7 in (0, 0x20, 1)] + [(0x3b, f3, f7) for f3, f7 in
-             ((0, 0), (0, 0x20), (1, 0), (5, 0), (5, 0x20), (0, 1), (4, 1), (5, 1), (6, 1), (7, 1))]
     for trial in range(30):
-        words = []
-        for r in range(1, 8):  # seed registers with interesting values via LUI/ADDI/SLLI
-            words.append((int(rng.integers(0, 1 << 20)) << 12) | (r << 7) | 0x37)
-            words.append((int(rng.integers(0, 1 << 12)) << 20) | (r << 15) | (r << 7) | 0x13)
-            if rng.integers(0, 2):
-                words.append((int(rng.integers(0, 64)) << 20) | (r << 15) | (1 << 12) | (r << 7) | 0x13)
-        for _ in range(60):
-            kind = int(rng.integers(0, 5))
-            rd, rs1, rs2 = (int(x) for x in rng.integers(0, 8, 3))
-            if kind == 0:
-                op, f3, f7 = ops_r[int(rng.integers(0, len(ops_r)))]
-                if op == 0x33 and f7 == 0x20 and f3 not in (0, 5):
-                    f7 = 0
-                words.append((f7 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | op)
-            elif kind == 1:
-                f3 = int(rng.integers(0, 8))
-                imm = int(rng.integers(0, 1 << 12))
-                if f3 == 1:
-                    imm &= 63
-                if f3 == 5:
-                    imm = (imm & 63) | (0x400 if rng.integers(0, 2) else 0)
-                words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x13)
-            elif kind == 2:
-                f3 = [0, 1, 5][int(rng.integers(0, 3))]
-                imm = int(rng.integers(0, 1 << 12)) if f3 == 0 else (int(rng.integers(0, 32)) | (0x400 if (f3 == 5 and rng.integers(0, 2)) else 0))
-                words.append((imm << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x1b)
-            elif kind == 3:  # store then load back with random widths at small addresses off x0
-                f3s = int(rng.integers(0, 4)); off = int(rng.integers(0, 64))
-                words.append(((off >> 5) << 25) | (rs2 << 20) | (0 << 15) | (f3s << 12) | ((off & 31) << 7) | 0x23)
-                f3l = int(rng.integers(0, 7))
-                words.append((off << 20) | (0 << 15) | (f3l << 12) | (rd << 7) | 0x03)
-            else:
-                words.append((int(rng.integers(0, 1 << 20)) << 12) | (rd << 7) | (0x17 if rng.integers(0, 2) else 0x37))
-        prog = b"".join(int(w).to_bytes(4, "little") for w in words)
+        prog = programs.random_program(rng)
         a = host.vm_run(prog, 0x1000, 10000)
         b = O.vm_run_kat(prog, 0x1000, 10000)
         assert a == b, trial

@@ -373,7 +373,7 @@ static zigz_status timed_end(zigz_ctx *ctx, int ev, double *us_out) {
 // launch_bind with a private HIP event pair around every vector-path launch (timing mode only)
 static zigz_status bind_launch(zigz_ctx *ctx, const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride,
                                size_t half, size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums) {
-    const bool rec = ctx->timing && ctx->pool_used < 64 && bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride);
+    const bool rec = ctx->timing && ctx->pool_used < 64 && bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride, d_in, d_out);
     if (rec) HIPCHK(ctx, hipEventRecord(ctx->pool[2 * ctx->pool_used], ctx->stream));
     launch_bind(d_in, in_stride, d_out, out_stride, half, ncols, r_m, d_r_m, d_sums, ctx->stream);
     if (rec) {
@@ -494,7 +494,7 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
         HIPCHK(ctx, hipGetLastError());
         return ZIGZ_OK;
     }
-    if (nv >= 14 && nv <= 24 && col_stride % 4 == 0 && !ctx->fold_eval)
+    if (nv >= 14 && nv <= 24 && col_stride % 4 == 0 && aligned16(d_cols) && !ctx->fold_eval)
         return dev_eval_radix(ctx, d_cols, col_stride, ncols, nv, points, d_vals);
     // r table in Montgomery form, [round][col], staged in the upper half of the pinned buffer so the
     // asynchronous H2D copy never reads freed host memory
@@ -557,7 +557,7 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
                                  const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
     const size_t nv = log2_floor(n);
     if (2 * (nv + 1) > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
-    if (n >= RADIX_MIN_N && !ctx->per_round_sumcheck && !ctx->timing)
+    if (n >= RADIX_MIN_N && aligned16(d_in) && !ctx->per_round_sumcheck && !ctx->timing)
         return sumcheck_radix(ctx, d_in, n, fixed, rounds, point, final_eval);
     if (!d_scratch) {
         void *s;

@@ -111,14 +111,17 @@ __global__ __launch_bounds__(TPB) void k_bind_small(const uint32_t *__restrict__
     if (SUMS) block_add2(s0, s1, sums + 2 * col);
 }
 
-bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride) {
-    return half >= (with_sums ? 2 * VEC_MIN_HALF : VEC_MIN_HALF) && (in_stride % 4 == 0) && (out_stride % 4 == 0);
+// the vector kernels use 16-byte accesses: every column base must be 16-byte aligned, otherwise the scalar
+// workgroup-per-column kernels run (any alignment)
+bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out) {
+    return half >= (with_sums ? 2 * VEC_MIN_HALF : VEC_MIN_HALF) && (in_stride % 4 == 0) && (out_stride % 4 == 0) &&
+           aligned16(in) && aligned16(out);
 }
 
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
                  size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s) {
     if (half == 0 || ncols == 0) return;
-    const bool vec = bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride);
+    const bool vec = bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride, d_in, d_out);
     if (vec) {
         dim3 grid((unsigned)(half / (4 * TPB * UNROLL)), (unsigned)ncols);
         if (d_sums)
@@ -169,7 +172,7 @@ __global__ __launch_bounds__(TPB) void k_half_sums_small(const uint32_t *__restr
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols, unsigned long long *d_sums,
                       hipStream_t s) {
     if (n == 0 || ncols == 0) return;
-    if (n >= 2 * (size_t)(4 * TPB * UNROLL) && in_stride % 4 == 0) {
+    if (n >= 2 * (size_t)(4 * TPB * UNROLL) && in_stride % 4 == 0 && aligned16(d_in)) {
         dim3 grid((unsigned)(n / (4 * TPB * UNROLL)), (unsigned)ncols);
         hipLaunchKernelGGL(k_half_sums_vec, grid, dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
     } else {

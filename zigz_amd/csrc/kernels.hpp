@@ -30,7 +30,8 @@ void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
                  size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s);
 // true when launch_bind takes the vectorised k_bind_vec path for these arguments
-bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride);
+bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out);
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // K2/K3: sums[2c] += sum in[0..n/2), sums[2c+1] += sum in[n/2..n)   (n >= 2); n == 1: sums[2c] += in[0]
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols,
                       unsigned long long *d_sums, hipStream_t s);
