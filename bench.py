@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="independent traces proven concurrently per GPU per step")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
+    ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
+                    "the headline is measured with the dense, data-independent build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=2)
     args = ap.parse_args()
@@ -103,6 +105,8 @@ def main():
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
         def __init__(self, k):
             self.ctx = zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
+            if args.dedup:
+                self.ctx.set_option("merkle_dedup", 1)
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
             self.prog = programs.add_xor_loop((N - 3) // 4 - (rank * B + k))
             self.trace = host.Trace(self.prog, 0x1000, None, 2 * N)  # [1/6] VM execution: outside the timed region
@@ -189,6 +193,7 @@ def main():
                                    "Prover.prove hot path incl. Fiat-Shamir transcript and ZIGZ v1 serialisation; "
                                    "%d independent traces (proofs) per GPU per step" % (nv, B),
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
+                       "merkle_build": "run-aware (merkle_dedup)" if args.dedup else "dense",
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
                        "parallelism": "independent traces: %d GPU x %d concurrent proofs" % (world, B)},
             "roofline": {"kernel": "k_radix_fold (MLE bind of the top v-10 variables of all 43 columns in one pass: the bulk "

@@ -223,10 +223,15 @@ typedef struct zigz_kernel_stats {
     double bind_vec_us;
     uint64_t bind_vec_launches;
     uint64_t bind_vec_bytes;
+    /* run-aware Merkle build (option "merkle_dedup"): 256-leaf blocks in the last batched commit and how many of
+     * them were uniform (0 / 0 when the option is off or the trees are smaller than 2^17 leaves) */
+    uint64_t merkle_blocks;
+    uint64_t merkle_uniform_blocks;
 } zigz_kernel_stats;
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
 /* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
- * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form */
+ * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;
+ * "merkle_dedup" = 1 enables the run-aware Merkle build (identical trees; fewer hashes on piecewise-constant columns) */
 zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
 

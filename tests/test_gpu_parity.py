@@ -445,3 +445,44 @@ def test_unaligned_device_pointers(ctx):
     finally:
         ctx.dev_free(d)
         ctx.dev_free(o)
+
+
+def test_merkle_dedup_identical_trees(ctx):
+    """Option "merkle_dedup": uniform 256-leaf blocks are chained instead of hashed densely.  Roots and every opened
+    path must equal the dense build and the oracle on columns with every kind of structure."""
+    import zigz_amd
+    nv = 17
+    N = 1 << nv
+    rng = np.random.default_rng(7)
+    cols = rnd(5150, 43 * N).reshape(43, N).copy()
+    cols[1, :] = 5                       # constant column
+    cols[2, :] = 0                       # all-zero column (e.g. an unused register)
+    cols[3, :] = np.repeat(rnd(1, N // 1000 + 1), 1000)[:N]      # runs of 1000 (not block aligned)
+    cols[4, :] = 9; cols[4, 70000] = 10  # uniform except one leaf
+    cols[5, : N // 2] = 123              # constant first half, random second half
+    cols[6, :] = np.repeat(rnd(2, N // 256), 256)                # every block uniform, all different
+    cols[7, :] = np.arange(N) % 4        # period-4 instruction-field pattern
+    cols[8, -300:] = 0                   # zero padding tail crossing a block boundary
+    points = rnd(77, 43 * nv).reshape(43, nv)
+    points[:, 0] = [int(x) for x in rng.integers(0, N, 43)]     # spread the opened indices
+    points[4, 0] = 70000; points[5, 0] = N // 2 - 1; points[8, 0] = N - 300
+    results = []
+    for dedup in (0, 1):
+        ctx.set_option("merkle_dedup", dedup)
+        job = zigz_amd.CommitJob(ctx, cols=cols)
+        roots = job.roots()
+        st = ctx.stats()
+        o = job.open_all(points)
+        job.end()
+        results.append((roots, o, st))
+    ctx.set_option("merkle_dedup", 0)
+    (r0, o0, s0), (r1, o1, s1) = results
+    assert np.array_equal(r0, r1)
+    for k in o0:
+        assert np.array_equal(o0[k], o1[k]), k
+    assert s0["merkle_blocks"] == 0 and s1["merkle_blocks"] == 43 * (N >> 8)
+    assert s1["merkle_uniform_blocks"] >= 3 * (N >> 8)  # columns 1, 2, 6 at least
+    for c in (1, 3, 4, 5, 8):
+        lv, h = O.merkle_levels(cols[c])
+        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r1[c].tobytes()
+        assert O.merkle_verify(r1[c].tobytes(), int(o1["leaves"][c]), o1["siblings"][c].tobytes(), o1["dirs"][c].tobytes())

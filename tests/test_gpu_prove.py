@@ -196,3 +196,20 @@ def test_prove_random_programs_vs_oracle(ctx):
         oproof, ons = O.prove(P, prog, 0x1000 + 4 * trial, iregs, 1 << 20)
         assert ns == ons and proof == oproof, trial
         assert host.verify(proof, prog) == "Accept"
+
+
+def test_prove_with_merkle_dedup_is_byte_identical(ctx):
+    """The run-aware Merkle build is an optimisation only: same proof bytes (2^17 ADD/XOR trace, 32 of 43 columns constant)."""
+    from zigz_amd import host
+    prog = programs.add_xor_loop(((1 << 17) - 3) // 4)
+    t = host.Trace(prog, 0x1000, None, 1 << 18)
+    assert t.num_vars == 17
+    a = t.prove(ctx)
+    ctx.set_option("merkle_dedup", 1)
+    try:
+        b = t.prove(ctx)
+        st = ctx.stats()
+    finally:
+        ctx.set_option("merkle_dedup", 0)
+    assert a == b and st["merkle_uniform_blocks"] > st["merkle_blocks"] // 2
+    assert host.verify(b, prog) == "Accept"

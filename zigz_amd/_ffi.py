@@ -23,7 +23,8 @@ vp = C.c_void_p
 class KernelStats(C.Structure):
     _fields_ = [("merkle_build_us", C.c_double), ("eval_us", C.c_double), ("path_us", C.c_double),
                 ("bind_us", C.c_double), ("bind_launches", C.c_uint64), ("keccak_permutations", C.c_uint64),
-                ("bind_vec_us", C.c_double), ("bind_vec_launches", C.c_uint64), ("bind_vec_bytes", C.c_uint64)]
+                ("bind_vec_us", C.c_double), ("bind_vec_launches", C.c_uint64), ("bind_vec_bytes", C.c_uint64),
+                ("merkle_blocks", C.c_uint64), ("merkle_uniform_blocks", C.c_uint64)]
 
 
 # name -> (restype, argtypes).  Every symbol include/zigz_hip.h declares must appear here

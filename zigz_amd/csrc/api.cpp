@@ -19,7 +19,7 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_SLOTS };
 
 struct zigz_ctx {
     int device;
@@ -34,6 +34,8 @@ struct zigz_ctx {
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
+    bool merkle_dedup;        // run-aware Merkle build (uniform 256-leaf blocks are chained, not hashed densely)
+    unsigned long long *d_dedup_count;
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs for k_bind_vec timing
     int pool_used;
@@ -164,7 +166,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     auto fail = [&](hipError_t e) { return e != hipSuccess; };
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
-        fail(hipMalloc((void **)&ctx->d_flag, 64)) ||
+        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_dedup_count, 64)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
@@ -189,6 +191,7 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
+    if (ctx->d_dedup_count) (void)hipFree(ctx->d_dedup_count);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
@@ -241,6 +244,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (!ctx || !name) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "merkle_dedup") == 0) { ctx->merkle_dedup = value != 0; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
@@ -840,8 +844,26 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
                                uint8_t *d_tree, size_t ncols) {
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
-    launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream);
-    for (unsigned l = 0; l < height; l++) {
+    unsigned l_start = 0;
+    if (ctx->merkle_dedup && height >= 17) {  // levels 0..8 run-aware; above the 256-leaf blocks the build is dense
+        const size_t nblocks = npad >> DEDUP_BLOG;
+        void *w;
+        CHK(ws_get(ctx, WS_DEDUP, ncols * nblocks * (1 + (DEDUP_BLOG + 1) * 32) + 256, &w));
+        uint8_t *d_utab = (uint8_t *)w, *d_flags = d_utab + ncols * nblocks * (DEDUP_BLOG + 1) * 32;
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_dedup_count, 0, 8, ctx->stream));
+        launch_dedup_flags(d_vals, val_stride, n_values, npad, d_flags, ctx->d_dedup_count, ncols, ctx->stream);
+        launch_dedup_chains(d_vals, val_stride, n_values, npad, d_flags, d_utab, ncols, ctx->stream);
+        launch_keccak_leaves_dedup(d_vals, val_stride, n_values, npad, d_tree, stride, d_flags, d_utab, ncols, ctx->stream);
+        for (unsigned L = 1; L <= DEDUP_BLOG; L++)
+            launch_keccak_level_dedup(d_tree, stride, npad, L, d_flags, d_utab, ncols, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        ctx->stats.merkle_blocks = (uint64_t)ncols * nblocks;
+        l_start = DEDUP_BLOG;
+    } else {
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream);
+        ctx->stats.merkle_blocks = 0;
+    }
+    for (unsigned l = l_start; l < height; l++) {
         const size_t n_out = npad >> (l + 1);
         if (n_out <= 256) {
             launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
@@ -1054,6 +1076,13 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
     HIPCHK(ctx, hipEventSynchronize(job->built));
     memcpy(roots, ctx->h_pin, job->ncols * 32);
+    if (ctx->stats.merkle_blocks) {
+        unsigned long long cnt = 0;
+        HIPCHK(ctx, hipMemcpy(&cnt, ctx->d_dedup_count, 8, hipMemcpyDeviceToHost));
+        ctx->stats.merkle_uniform_blocks = cnt;
+    } else {
+        ctx->stats.merkle_uniform_blocks = 0;
+    }
     if (ctx->timing) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));

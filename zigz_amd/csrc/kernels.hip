@@ -499,6 +499,121 @@ __global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, 
     }
 }
 
+// ------------------------------------------------------------------ run-aware Merkle build (optional)
+// one wave per 256-leaf block: uniform iff all 256 (padded) values are equal
+__global__ __launch_bounds__(TPB) void k_dedup_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                     size_t npad, uint8_t *__restrict__ flags,
+                                                     unsigned long long *__restrict__ count) {
+    const size_t col = blockIdx.y;
+    const size_t blk = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const size_t nblocks = npad >> DEDUP_BLOG;
+    if (blk >= nblocks) return;
+    const unsigned lane = threadIdx.x & 63;
+    const uint32_t *v = vals + col * val_stride;
+    const size_t base = (blk << DEDUP_BLOG) + (size_t)lane * 4;
+    uint32_t x[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) x[j] = base + j < n_values ? v[base + j] : 0;
+    const uint32_t first = __builtin_amdgcn_readfirstlane(x[0]);
+    const bool eq = x[0] == first && x[1] == first && x[2] == first && x[3] == first;
+    const bool uni = __all(eq);
+    if (lane == 0) {
+        flags[col * nblocks + blk] = uni ? 1 : 0;
+        if (uni) atomicAdd(count, 1ull);
+    }
+}
+
+// one thread per block: the 9-hash chain of a uniform block (masked for the others)
+__global__ __launch_bounds__(TPB) void k_dedup_chains(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                      size_t npad, const uint8_t *__restrict__ flags,
+                                                      uint8_t *__restrict__ utab) {
+    const size_t col = blockIdx.y;
+    const size_t blk = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t nblocks = npad >> DEDUP_BLOG;
+    if (blk >= nblocks || !flags[col * nblocks + blk]) return;
+    const size_t i0 = blk << DEDUP_BLOG;
+    const uint64_t x = i0 < n_values ? vals[col * val_stride + i0] : 0;
+    uint8_t *u = utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32;
+    Digest d = sha3_leaf(x);
+    store_digest(u, 0, d);
+#pragma unroll 1
+    for (unsigned l = 1; l <= DEDUP_BLOG; l++) {
+        d = sha3_node(d, d);
+        store_digest(u, l, d);
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_keccak_leaves_dedup(const uint32_t *__restrict__ vals, size_t val_stride,
+                                                             size_t n_values, size_t npad, uint8_t *__restrict__ tree,
+                                                             size_t tree_stride_nodes, const uint8_t *__restrict__ flags,
+                                                             const uint8_t *__restrict__ utab) {
+    const size_t col = blockIdx.y;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const uint32_t *v = vals + col * val_stride;
+    const size_t nblocks = npad >> DEDUP_BLOG;
+#pragma unroll 1
+    for (int h = 0; h < HPT; h++) {
+        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
+        if (i >= npad) return;
+        const size_t blk = i >> DEDUP_BLOG;  // wave-uniform: a wave's 64 leaves lie in one block
+        if (flags[col * nblocks + blk]) {
+            store_digest(t, i, load_digest(utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32, 0));
+        } else {
+            const uint64_t x = i < n_values ? v[i] : 0;
+            store_digest(t, i, sha3_leaf(x));
+        }
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_keccak_level_dedup(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
+                                                            unsigned L, const uint8_t *__restrict__ flags,
+                                                            const uint8_t *__restrict__ utab) {
+    const size_t col = blockIdx.y;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const size_t n_out = npad >> L, nblocks = npad >> DEDUP_BLOG;
+    const size_t in_off = 2 * npad - 2 * (npad >> (L - 1)), out_off = 2 * npad - 2 * n_out;
+#pragma unroll 1
+    for (int h = 0; h < HPT; h++) {
+        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
+        const bool live = i < n_out;
+        const size_t blk = live ? i >> (DEDUP_BLOG - L) : 0;
+        const bool uni = live && flags[col * nblocks + blk];
+        if (__all(uni || !live)) {  // the whole wave lies in uniform blocks: copy the chain digests
+            if (live) store_digest(t, out_off + i, load_digest(utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32, L));
+        } else if (live) {
+            Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
+            store_digest(t, out_off + i, sha3_node(l, r));
+        }
+    }
+}
+
+void launch_dedup_flags(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_flags,
+                        unsigned long long *d_count, size_t ncols, hipStream_t s) {
+    const size_t nblocks = npad >> DEDUP_BLOG;
+    dim3 grid((unsigned)((nblocks + TPB / 64 - 1) / (TPB / 64)), (unsigned)ncols);
+    hipLaunchKernelGGL(k_dedup_flags, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_flags, d_count);
+}
+void launch_dedup_chains(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, const uint8_t *d_flags,
+                         uint8_t *d_utab, size_t ncols, hipStream_t s) {
+    const size_t nblocks = npad >> DEDUP_BLOG;
+    dim3 grid((unsigned)((nblocks + TPB - 1) / TPB), (unsigned)ncols);
+    hipLaunchKernelGGL(k_dedup_chains, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_flags, d_utab);
+}
+void launch_keccak_leaves_dedup(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                                size_t tree_stride_nodes, const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols,
+                                hipStream_t s) {
+    dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
+    hipLaunchKernelGGL(k_keccak_leaves_dedup, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                       tree_stride_nodes, d_flags, d_utab);
+}
+void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned out_level,
+                               const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols, hipStream_t s) {
+    const size_t n_out = npad >> out_level;
+    dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
+    hipLaunchKernelGGL(k_keccak_level_dedup, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, out_level, d_flags,
+                       d_utab);
+}
+
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                           size_t tree_stride_nodes, size_t ncols, hipStream_t s) {
     dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
