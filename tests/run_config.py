@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Run one BASELINE config at full size on one GPU and check it:
+"""Manual full-size validation (lives under tests/ because it checks against the oracle; not collected by pytest).
+Run one BASELINE config at full size on one GPU and check it:   python tests/run_config.py --config 4
    --config 2  fibonacci, 2^16 trace          (byte-exact vs the oracle's literal prove)
    --config 3  RV64I ADD/XOR loop, 2^20
    --config 4  RV64IM mixed loop, 2^22
