@@ -11,6 +11,9 @@ using namespace zigz;
 
 static thread_local std::string g_err;
 static thread_local double g_timings[8] = {0};
+// trace-row storage recycled across executions on this thread: first-touch page faults of a fresh 360 MB buffer cost
+// more than running the VM for 2^20 steps
+static thread_local std::vector<uint64_t> g_row_pool;
 static thread_local std::vector<uint8_t> g_proof;  // borrowed-proof buffer of zigzh_prove_trace(want_bytes = 2)
 
 template <class Fn>
@@ -61,6 +64,7 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
         VMState vm(prog, entry_pc, input ? &in : nullptr);
         if (t->initial_regs)
             for (size_t i = 0; i < t->initial_regs->size() && i < 32; i++) vm.writeReg((unsigned)i, (*t->initial_regs)[i]);
+        vm.trace.rows.swap(g_row_pool);  // recycled capacity (contents are overwritten step by step)
         vm.trace.reserveSteps(max_steps < ((size_t)1 << 22) ? max_steps : ((size_t)1 << 22));
         size_t step_count = 0;
         while (!vm.halted && step_count < max_steps) {  // prover.zig:132-142
@@ -82,7 +86,10 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
         *out = t.release();
     });
 }
-extern "C" void zigzh_trace_free(zigzh_trace *t) { delete t; }
+extern "C" void zigzh_trace_free(zigzh_trace *t) {
+    if (t && t->trace.rows.capacity() > g_row_pool.capacity()) g_row_pool.swap(t->trace.rows);
+    delete t;
+}
 extern "C" size_t zigzh_trace_num_steps(const zigzh_trace *t) { return t->trace.stepCount(); }
 extern "C" size_t zigzh_trace_num_vars(const zigzh_trace *t) { return t->num_vars; }
 extern "C" size_t zigzh_trace_num_lookups(const zigzh_trace *t) { return t->num_lookups; }

@@ -228,6 +228,12 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     std::unique_ptr<VMState> vm(segments ? new VMState(*segments, entry_pc, input) : new VMState(program, entry_pc, input));
     if (initial_regs)
         for (size_t i = 0; i < initial_regs->size() && i < 32; i++) vm->writeReg((unsigned)i, (*initial_regs)[i]);
+    static thread_local std::vector<uint64_t> row_pool;  // recycled trace storage (avoids refaulting ~344 B per step)
+    vm->trace.rows.swap(row_pool);
+    struct Recycle {
+        std::vector<uint64_t> &pool, &rows;
+        ~Recycle() { if (rows.capacity() > pool.capacity()) pool.swap(rows); }
+    } recycle{row_pool, vm->trace.rows};
     vm->trace.reserveSteps(max_steps < ((size_t)1 << 22) ? max_steps : ((size_t)1 << 22));
     size_t step_count = 0;
     while (!vm->halted && step_count < max_steps) {

@@ -273,7 +273,7 @@ void VMState::step() {  // state.zig:128-167
     const uint64_t next_pc = execute(in, mem_row);
     uint64_t *row = trace.appendRow();
     row[0] = pc_before;
-    for (unsigned r = 0; r < 32; r++) row[1 + r] = readReg(r);
+    memcpy(row + 1, regs_, sizeof(regs_));  // regs_[0] stays 0: writeReg ignores x0 (registers.zig:38-48)
     row[33] = in.opcode; row[34] = in.rd; row[35] = in.rs1; row[36] = in.rs2; row[37] = in.funct3; row[38] = in.funct7;
     row[39] = (uint64_t)in.imm;
     row[40] = mem_row[0]; row[41] = mem_row[1]; row[42] = mem_row[2];
