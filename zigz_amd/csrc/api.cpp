@@ -474,10 +474,10 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
     launch_eq_weights((const uint32_t *)d_rt + k1, nv, k2, d_w2, m, ncols, ctx->stream);
     bind_pool_reset(ctx);
     const bool rec = ctx->timing;
-    if (rec) HIPCHK(ctx, hipEventRecord(ctx->pool[0], ctx->stream));
-    launch_radix_fold(d_cols, col_stride, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream);  // the one pass over the data
+    // the one pass over the data; in timing mode the events carry the dispatch's own begin/end timestamps
+    launch_radix_fold(d_cols, col_stride, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream, rec ? ctx->pool[0] : nullptr,
+                      rec ? ctx->pool[1] : nullptr);
     if (rec) {
-        HIPCHK(ctx, hipEventRecord(ctx->pool[1], ctx->stream));
         ctx->pool_used = 1;
         ctx->pool_bytes = (uint64_t)ncols * (N * 4 + groups * m * 8);  // one read of the tables + the partial sums
     }

@@ -8,6 +8,7 @@
 //  K7     k_paths                     authentication-path gather               latency
 //  K9     k_lasso_fingerprints        XXH3-64 row fingerprints                  int-VALU bound
 #include "kernels.hpp"
+#include <hip/hip_ext.h>
 
 #include "field.hpp"
 #include "keccak.hpp"
@@ -192,12 +193,13 @@ __global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
         const size_t c = base + (size_t)u * TPB;
-        a[u] = c < chunks ? p[c] : make_uint4(0, 0, 0, 0);
+        a[u] = p[c < chunks ? c : chunks - 1];  // clamped, not branched: the UNROLL loads stay back to back
     }
 #pragma unroll
     for (int u = 0; u < UNROLL; u++) {
         const size_t c = base + (size_t)u * TPB;
-        unsigned long long v = wave_sum((unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w);
+        const unsigned long long mine = (unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w;
+        unsigned long long v = wave_sum(c < chunks ? mine : 0ull);
         if ((threadIdx.x & 63) == 0 && c < chunks && v) atomicAdd(&sums[(c * 4) >> log2_m], v);
     }
 }
@@ -213,8 +215,16 @@ void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned
 // m = 1024 and long row segments otherwise -- the HBM access pattern of k_bind_vec.  Each (row-group g, output i)
 // partial sum is written once as an exact u64 (part[col][g][i]; no atomics, no memset); k_radix_finalize adds the
 // G = nb/64 partials and reduces mod p.
+// The Montgomery reduction is deferred: 32-bit multiplies issue at under half the VALU rate on gfx950
+// (tools/fold_rate.hip), and four of them per term made this kernel multiplier-bound (41 us against a 33.5 us read
+// ceiling at v = 20).  The 64-bit products W[b]*T[..] are accumulated as two exact u64 sums of their 32-bit halves
+// (64 terms: each < 2^38); one reduction per output then gives  hi + lo * 2^-32  ==  sum_b w_b * T[b*m+i]  (mod p).
 constexpr int RB = 16;     // independent 16-byte loads in flight per lane
 constexpr int RLOOPS = 4;  // RB-chunks per thread: accumulators stay in registers
+// FULL: nb is a multiple of RB*RLOOPS (every launch but the late, small sumcheck stages): no row needs a bounds test
+// and the RB loads of a chunk are issued back to back.  Otherwise rows past nb are clamped to a valid row and given
+// weight 0 (per-row branches would make the compiler serialise the loads behind s_waitcnt vmcnt(0)).
+template <bool FULL>
 __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t in_stride, size_t m, size_t nb,
                                                     const uint32_t *__restrict__ w_m, size_t w_stride,
                                                     unsigned long long *__restrict__ part, size_t part_col_stride) {
@@ -224,35 +234,47 @@ __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__
     const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride) + q;
     const uint32_t *w = w_m + col * w_stride;
     const size_t mq = m / 4;
-    unsigned long long s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    unsigned long long lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
 #pragma unroll 1
     for (int l = 0; l < RLOOPS; l++) {
         const size_t b0 = ((size_t)blockIdx.y * RLOOPS + l) * RB;
-        if (b0 >= nb) break;
+        if (!FULL && b0 >= nb) break;
         uint4 v[RB];
 #pragma unroll
-        for (int j = 0; j < RB; j++) v[j] = (b0 + j < nb) ? p[(b0 + j) * mq] : make_uint4(0, 0, 0, 0);
+        for (int j = 0; j < RB; j++) v[j] = p[(FULL || b0 + j < nb ? b0 + j : nb - 1) * mq];
 #pragma unroll
         for (int j = 0; j < RB; j++) {
-            const uint32_t wj = (b0 + j < nb) ? w[b0 + j] : 0;  // wave-uniform
-            s0 += mont_mul(wj, v[j].x);
-            s1 += mont_mul(wj, v[j].y);
-            s2 += mont_mul(wj, v[j].z);
-            s3 += mont_mul(wj, v[j].w);
+            // wave-uniform, Montgomery form, < p
+            const uint32_t wj = FULL ? w[b0 + j] : (w[b0 + j < nb ? b0 + j : nb - 1] & (b0 + j < nb ? ~0u : 0u));
+            const uint32_t e[4] = {v[j].x, v[j].y, v[j].z, v[j].w};
+#pragma unroll
+            for (int c = 0; c < 4; c++) {
+                const unsigned long long pr = (unsigned long long)wj * e[c];
+                lo[c] += (uint32_t)pr;
+                hi[c] += pr >> 32;
+            }
         }
     }
+    unsigned long long s[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) s[c] = hi[c] + monty_reduce(lo[c]);  // lo < 2^38 < p * 2^32
     ulonglong2 *o = reinterpret_cast<ulonglong2 *>(part + col * part_col_stride + (size_t)blockIdx.y * m + q * 4);
-    o[0] = make_ulonglong2(s0, s1);
-    o[1] = make_ulonglong2(s2, s3);
+    o[0] = make_ulonglong2(s[0], s[1]);
+    o[1] = make_ulonglong2(s[2], s[3]);
 }
 
 size_t radix_fold_groups(size_t nb) { return (nb + RB * RLOOPS - 1) / (RB * RLOOPS); }
 
 void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
-                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s) {
+                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s,
+                       hipEvent_t t_start, hipEvent_t t_stop) {
     dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)radix_fold_groups(nb), (unsigned)ncols);
-    hipLaunchKernelGGL(k_radix_fold, grid, dim3(TPB), 0, s, d_in, in_stride, m, nb, d_w_m, w_stride, d_part,
-                       part_col_stride);
+    auto kern = nb % (RB * RLOOPS) == 0 ? k_radix_fold<true> : k_radix_fold<false>;
+    if (t_start && t_stop)  // kernel-exact timing for the roofline figure (an event pair around a launch adds the gaps)
+        hipExtLaunchKernelGGL(kern, grid, dim3(TPB), 0, s, t_start, t_stop, 0, d_in, in_stride, m, nb, d_w_m, w_stride,
+                              d_part, part_col_stride);
+    else
+        hipLaunchKernelGGL(kern, grid, dim3(TPB), 0, s, d_in, in_stride, m, nb, d_w_m, w_stride, d_part, part_col_stride);
 }
 
 __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ part, size_t part_col_stride,

@@ -42,8 +42,10 @@ void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned
 //  (2) part[c][g][i] = sum over the g-th group of 64 consecutive b of W[c][b] * in[c][b*m + i]   (exact u64; i < m,
 //      m % 4 == 0, column c < ncols; W in Montgomery form; G = radix_fold_groups(nb) groups; strides in elements)
 size_t radix_fold_groups(size_t nb);
+//      t_start/t_stop (both or neither): events stamped with the dispatch's own begin/end timestamps.
 void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
-                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s);
+                       size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s,
+                       hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);
 //  (3) out[c][i] = (sum_g part[c][g][i]) mod p; if d_sums (ncols == 1): sums[i >> log2_m2] += out[i]  (block sums of
 //      the next stage, m2 >= 256; must be zeroed by the caller)
 void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
