@@ -1,0 +1,54 @@
+// Per-launch timing of the Keccak Merkle kernels on the bench shape (43 columns x 2^20 leaves), outside the prover:
+// the numbers DESIGN.md quotes for K5/K6.  Builds the kernels from source, so kernel experiments (-D flags) need no
+// library rebuild.
+//   hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc -I include tools/merkle_rate.hip -o /tmp/merkle_rate && /tmp/merkle_rate
+#include "../zigz_amd/csrc/kernels.hip"
+
+#include <stdio.h>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
+
+int main(int argc, char **argv) {
+    const size_t ncols = 43;
+    const unsigned nv = argc > 1 ? (unsigned)atoi(argv[1]) : 20;
+    const size_t N = (size_t)1 << nv, nodes = 2 * N;
+    uint32_t *d_vals;
+    uint8_t *d_tree;
+    CK(hipMalloc(&d_vals, ncols * N * 4));
+    CK(hipMalloc(&d_tree, ncols * nodes * 32));
+    std::vector<uint32_t> h(ncols * N);
+    uint64_t s = 0x5A49475Aull;
+    for (auto &x : h) { s += 0x9E3779B97F4A7C15ull; uint64_t z = s; z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull; z = (z ^ (z >> 27)) * 0x94D049BB133111EBull; x = (uint32_t)((z ^ (z >> 31)) % zk::P); }
+    CK(hipMemcpy(d_vals, h.data(), h.size() * 4, hipMemcpyHostToDevice));
+    hipEvent_t ev[64];
+    for (auto &e : ev) CK(hipEventCreate(&e));
+    for (int rep = 0; rep < 3; rep++) {
+        int k = 0;
+        CK(hipEventRecord(ev[k++], 0));
+        zk::launch_keccak_leaves(d_vals, N, N, N, d_tree, nodes, ncols, 0);
+        CK(hipEventRecord(ev[k++], 0));
+        unsigned l = 0;
+        for (; l < nv; l++) {
+            const size_t n_out = N >> (l + 1);
+            if (n_out < 512) break;
+            zk::launch_keccak_level(d_tree, nodes, 2 * N - 2 * (N >> l), 2 * N - 2 * (N >> (l + 1)), n_out, ncols, 0);
+            CK(hipEventRecord(ev[k++], 0));
+        }
+        zk::launch_keccak_top(d_tree, nodes, N, l, nv, ncols, 0);
+        CK(hipEventRecord(ev[k++], 0));
+        CK(hipDeviceSynchronize());
+        if (rep == 0) continue;
+        float total = 0;
+        CK(hipEventElapsedTime(&total, ev[0], ev[k - 1]));
+        printf("rep %d: total %.3f ms = %.2f Gperm/s |", rep, total, (double)ncols * (2 * N - 1) / total / 1e6);
+        for (int j = 1; j < k; j++) {
+            float ms;
+            CK(hipEventElapsedTime(&ms, ev[j - 1], ev[j]));
+            const double perms = j == 1 ? (double)ncols * N : (j == k - 1 ? (double)ncols * ((N >> l) - 1) : (double)ncols * (N >> (j - 1)));
+            printf(" %s %.3f ms (%.2f G/s)", j == 1 ? "leaves" : (j == k - 1 ? "top" : "lvl"), ms, perms / ms / 1e6);
+        }
+        printf("\n");
+    }
+    return 0;
+}

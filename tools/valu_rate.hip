@@ -21,6 +21,11 @@ __global__ __launch_bounds__(256) void k(uint32_t *out, int iters) {
                 if (OP == 4) a[i] = (x & y) | (~x & z);                                // v_bfi_b32
                 if (OP == 5) a[i] = x + y;                                             // v_add_u32
                 if (OP == 6) a[i] = __builtin_amdgcn_alignbit(x, y, z);                // v_alignbit_b32 (reg shift)
+                // inline asm so the compiler cannot fold chains of rotations
+                if (OP == 7) asm volatile("v_alignbit_b32 %0, %1, %1, 13" : "=v"(a[i]) : "v"(y));          // rot32: one source register
+                if (OP == 8) asm volatile("v_alignbit_b32 %0, %1, %2, 13" : "=v"(a[i]) : "v"(x), "v"(y));  // funnel: two source registers
+                if (OP == 9) asm volatile("v_bitop3_b32 %0, %1, %2, %3 bitop3:0x96" : "=v"(a[i]) : "v"(x), "v"(y), "v"(z));
+                if (OP == 10) asm volatile("v_xor_b32 %0, %1, %2" : "=v"(a[i]) : "v"(x), "v"(y));
             }
         }
     }
@@ -57,5 +62,9 @@ int main() {
     run<6>("v_alignbit_b32 reg");
     run<4>("v_bfi_b32");
     run<5>("v_add_u32");
+    run<7>("asm v_alignbit rot32 (1 src)");
+    run<8>("asm v_alignbit funnel (2 src)");
+    run<9>("asm v_bitop3 (3 src)");
+    run<10>("asm v_xor (2 src)");
     return 0;
 }

@@ -912,8 +912,11 @@ extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values,
         HIPCHK(ctx, hipMalloc((void **)&t->d_tree, tree_nodes(npad) * 32));
         CHK(upload_u64(ctx, values, n, t->d_vals, false));
         CHK(build_trees(ctx, t->d_vals, n, n, npad, t->d_tree, 1));
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, t->d_tree + tree_level_offset(npad, t->height) * 32, 32,
-                                   hipMemcpyDeviceToHost, ctx->stream));
+        void *d_root;  // the root leaves the device through the gather kernel: tree form -> canonical SHA3 bytes
+        CHK(ws_get(ctx, WS_MISC, 64, &d_root));
+        launch_gather_nodes(t->d_tree, tree_nodes(npad), tree_level_offset(npad, t->height), (uint8_t *)d_root, 1, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_root, 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         memcpy(root, ctx->h_pin, 32);
         return ZIGZ_OK;

@@ -2,12 +2,12 @@
 // fit one rate block (136 B), i.e. exactly one permutation each:
 //   leaf  = SHA3-256(LE64(value))        src/core/hash.zig:135-147  (hashFieldElementSHA3)
 //   node  = SHA3-256(left || right)      src/core/hash.zig:187-195  (mergeHashesSHA3)
-// This work is integer-ALU bound.  The device permutation keeps the 25 lanes as 50 32-bit VGPRs and is
-// written for the gfx950 VALU: 3-input boolean ops through v_bitop3_b32 (XOR3 = 0x96, chi a^(~b&c) = 0xD2)
-// and 64-bit rotations as two v_alignbit_b32 -- 180 VALU ops per round, 4.3 k per permutation (hipcc's
-// own lowering of the 64-bit formulation needs 6.5 k: 2-input XORs, v_bfi+xor for chi, 64-bit shifts).
-// The same source builds on the host (plain C fallbacks for the three primitives) for unit tests, and
-// the 64-bit macro formulation below is what the host-side sponge uses.
+// This work is integer-ALU bound.  The device permutation keeps the 25 lanes as 50 32-bit VGPRs (bit-interleaved,
+// see below) and is written for the gfx950 VALU: 3-input boolean ops through v_bitop3_b32 (XOR3 = 0x96,
+// chi a^(~b&c) = 0xD2) and rotations as single-source v_alignbit_b32 -- about 172 VALU ops per round, 4.1 k per
+// permutation (hipcc's own lowering of the 64-bit formulation needs 6.5 k: 2-input XORs, v_bfi+xor for chi, 64-bit
+// shifts).  The same source builds on the host (plain C fallbacks for the three primitives) for unit tests
+// (tests/c_driver/keccak_forms.cpp), and the 64-bit macro formulation below is what the host-side sponge uses.
 #pragma once
 #include <stdint.h>
 #if defined(__HIPCC__)
@@ -70,161 +70,206 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) 
     } while (0)
 
 
-// ---- 32-bit formulation (device kernels) ----
+// ---- 32-bit bit-interleaved formulation (device kernels) ----
+// Lane L is held as two 32-bit words: e = its even bits (bit 2i of L -> bit i of e), o = its odd bits.  A 64-bit
+// rotation by 2k is then rot32(e,k), rot32(o,k); by 2k+1 it is e' = rot32(o,k+1), o' = rot32(e,k): theta's rot-by-1
+// and rho's rot-by-1 need one v_alignbit_b32 instead of two, i.e. 52 instead of 58 rotate instructions per round (the
+// rotate is the slow instruction: 35 T lane-ops/s against 55 T for v_bitop3_b32, tools/valu_rate.hip).  XOR3 / chi are
+// bitwise, so they are unchanged: v_bitop3_b32 0x96 / 0xD2.  Per round: 120 v_bitop3 + 52 v_alignbit + iota.
+// Measured against the lo/hi-halves form it replaces (tools/merkle_rate.hip, same box): the 1-hash-per-thread level
+// kernels run 13 % faster, the large kernels the same (~10.5 G permutations/s either way).
+// The round body below is generated by tools/gen_keccak_il.py.
+// Digests stay in this form inside the tree (node input = output of the children, no conversion); they are
+// converted to canonical SHA3 bytes only where they leave the device (roots, authentication paths).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_X3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define ZK_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2)
-#define ZK_ALIGN(hi, lo, s) __builtin_amdgcn_alignbit((hi), (lo), (s))
+#define ZK_ROT32(x, k) __builtin_amdgcn_alignbit((x), (x), 32 - (k))
 #else
 #define ZK_X3(a, b, c) ((a) ^ (b) ^ (c))
 #define ZK_CHI(a, b, c) ((a) ^ (~(b) & (c)))
-#define ZK_ALIGN(hi, lo, s) ((uint32_t)(((((uint64_t)(hi)) << 32) | (uint64_t)(lo)) >> (s)))
+#define ZK_ROT32(x, k) ((uint32_t)(((x) << (k)) | ((x) >> (32 - (k)))))
 #endif
 
+// round constants, even / odd bits
+__constant__ const uint32_t KECCAK_RC_E[24] = {0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0x00000001u, 0x00000001u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000001u, 0x00000000u, 0x00000001u, 0x00000001u, 0x00000001u, 0x00000001u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000000u, 0x00000001u, 0x00000000u, 0x00000001u, 0x00000000u};
+__constant__ const uint32_t KECCAK_RC_O[24] = {0x00000000u, 0x00000089u, 0x8000008bu, 0x80008080u, 0x0000008bu, 0x00008000u, 0x80008088u, 0x80000082u, 0x0000000bu, 0x0000000au, 0x00008082u, 0x00008003u, 0x0000808bu, 0x8000000bu, 0x8000008au, 0x80000081u, 0x80000081u, 0x80000008u, 0x00000083u, 0x80008003u, 0x80008088u, 0x80000088u, 0x00008000u, 0x80008082u};
+
+// e[i], o[i]: even / odd bits of lane i = x + 5y
 #ifndef ZK_KECCAK_UNROLL
 #define ZK_KECCAK_UNROLL 24
 #endif
-
-// l[i], h[i]: low / high 32 bits of lane i = x + 5y
-__device__ __forceinline__ void keccak_f1600_32(uint32_t l[25], uint32_t h[25]) {
+__device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) {
 #pragma unroll ZK_KECCAK_UNROLL
     for (int r = 0; r < 24; r++) {
-        uint32_t bl[25], bh[25];
-// theta: column parities (two 3-input XORs per half)
-        const uint32_t cl0 = ZK_X3(ZK_X3(l[0], l[5], l[10]), l[15], l[20]);
-        const uint32_t ch0 = ZK_X3(ZK_X3(h[0], h[5], h[10]), h[15], h[20]);
-        const uint32_t cl1 = ZK_X3(ZK_X3(l[1], l[6], l[11]), l[16], l[21]);
-        const uint32_t ch1 = ZK_X3(ZK_X3(h[1], h[6], h[11]), h[16], h[21]);
-        const uint32_t cl2 = ZK_X3(ZK_X3(l[2], l[7], l[12]), l[17], l[22]);
-        const uint32_t ch2 = ZK_X3(ZK_X3(h[2], h[7], h[12]), h[17], h[22]);
-        const uint32_t cl3 = ZK_X3(ZK_X3(l[3], l[8], l[13]), l[18], l[23]);
-        const uint32_t ch3 = ZK_X3(ZK_X3(h[3], h[8], h[13]), h[18], h[23]);
-        const uint32_t cl4 = ZK_X3(ZK_X3(l[4], l[9], l[14]), l[19], l[24]);
-        const uint32_t ch4 = ZK_X3(ZK_X3(h[4], h[9], h[14]), h[19], h[24]);
-        // rot(C[x], 1)
-        const uint32_t rl0 = ZK_ALIGN(cl0, ch0, 31), rh0 = ZK_ALIGN(ch0, cl0, 31);
-        const uint32_t rl1 = ZK_ALIGN(cl1, ch1, 31), rh1 = ZK_ALIGN(ch1, cl1, 31);
-        const uint32_t rl2 = ZK_ALIGN(cl2, ch2, 31), rh2 = ZK_ALIGN(ch2, cl2, 31);
-        const uint32_t rl3 = ZK_ALIGN(cl3, ch3, 31), rh3 = ZK_ALIGN(ch3, cl3, 31);
-        const uint32_t rl4 = ZK_ALIGN(cl4, ch4, 31), rh4 = ZK_ALIGN(ch4, cl4, 31);
-        // theta apply (A ^ C[x-1] ^ rot(C[x+1],1)) fused with rho (rotate) and pi (destination index)
-        { const uint32_t tl = ZK_X3(l[0], cl4, rl1), th = ZK_X3(h[0], ch4, rh1);
-          bl[0] = tl; bh[0] = th; }
-        { const uint32_t tl = ZK_X3(l[1], cl0, rl2), th = ZK_X3(h[1], ch0, rh2);
-          bh[10] = ZK_ALIGN(th, tl, 31); bl[10] = ZK_ALIGN(tl, th, 31); }
-        { const uint32_t tl = ZK_X3(l[2], cl1, rl3), th = ZK_X3(h[2], ch1, rh3);
-          bh[20] = ZK_ALIGN(tl, th, 2); bl[20] = ZK_ALIGN(th, tl, 2); }
-        { const uint32_t tl = ZK_X3(l[3], cl2, rl4), th = ZK_X3(h[3], ch2, rh4);
-          bh[5] = ZK_ALIGN(th, tl, 4); bl[5] = ZK_ALIGN(tl, th, 4); }
-        { const uint32_t tl = ZK_X3(l[4], cl3, rl0), th = ZK_X3(h[4], ch3, rh0);
-          bh[15] = ZK_ALIGN(th, tl, 5); bl[15] = ZK_ALIGN(tl, th, 5); }
-        { const uint32_t tl = ZK_X3(l[5], cl4, rl1), th = ZK_X3(h[5], ch4, rh1);
-          bh[16] = ZK_ALIGN(tl, th, 28); bl[16] = ZK_ALIGN(th, tl, 28); }
-        { const uint32_t tl = ZK_X3(l[6], cl0, rl2), th = ZK_X3(h[6], ch0, rh2);
-          bh[1] = ZK_ALIGN(tl, th, 20); bl[1] = ZK_ALIGN(th, tl, 20); }
-        { const uint32_t tl = ZK_X3(l[7], cl1, rl3), th = ZK_X3(h[7], ch1, rh3);
-          bh[11] = ZK_ALIGN(th, tl, 26); bl[11] = ZK_ALIGN(tl, th, 26); }
-        { const uint32_t tl = ZK_X3(l[8], cl2, rl4), th = ZK_X3(h[8], ch2, rh4);
-          bh[21] = ZK_ALIGN(tl, th, 9); bl[21] = ZK_ALIGN(th, tl, 9); }
-        { const uint32_t tl = ZK_X3(l[9], cl3, rl0), th = ZK_X3(h[9], ch3, rh0);
-          bh[6] = ZK_ALIGN(th, tl, 12); bl[6] = ZK_ALIGN(tl, th, 12); }
-        { const uint32_t tl = ZK_X3(l[10], cl4, rl1), th = ZK_X3(h[10], ch4, rh1);
-          bh[7] = ZK_ALIGN(th, tl, 29); bl[7] = ZK_ALIGN(tl, th, 29); }
-        { const uint32_t tl = ZK_X3(l[11], cl0, rl2), th = ZK_X3(h[11], ch0, rh2);
-          bh[17] = ZK_ALIGN(th, tl, 22); bl[17] = ZK_ALIGN(tl, th, 22); }
-        { const uint32_t tl = ZK_X3(l[12], cl1, rl3), th = ZK_X3(h[12], ch1, rh3);
-          bh[2] = ZK_ALIGN(tl, th, 21); bl[2] = ZK_ALIGN(th, tl, 21); }
-        { const uint32_t tl = ZK_X3(l[13], cl2, rl4), th = ZK_X3(h[13], ch2, rh4);
-          bh[12] = ZK_ALIGN(th, tl, 7); bl[12] = ZK_ALIGN(tl, th, 7); }
-        { const uint32_t tl = ZK_X3(l[14], cl3, rl0), th = ZK_X3(h[14], ch3, rh0);
-          bh[22] = ZK_ALIGN(tl, th, 25); bl[22] = ZK_ALIGN(th, tl, 25); }
-        { const uint32_t tl = ZK_X3(l[15], cl4, rl1), th = ZK_X3(h[15], ch4, rh1);
-          bh[23] = ZK_ALIGN(tl, th, 23); bl[23] = ZK_ALIGN(th, tl, 23); }
-        { const uint32_t tl = ZK_X3(l[16], cl0, rl2), th = ZK_X3(h[16], ch0, rh2);
-          bh[8] = ZK_ALIGN(tl, th, 19); bl[8] = ZK_ALIGN(th, tl, 19); }
-        { const uint32_t tl = ZK_X3(l[17], cl1, rl3), th = ZK_X3(h[17], ch1, rh3);
-          bh[18] = ZK_ALIGN(th, tl, 17); bl[18] = ZK_ALIGN(tl, th, 17); }
-        { const uint32_t tl = ZK_X3(l[18], cl2, rl4), th = ZK_X3(h[18], ch2, rh4);
-          bh[3] = ZK_ALIGN(th, tl, 11); bl[3] = ZK_ALIGN(tl, th, 11); }
-        { const uint32_t tl = ZK_X3(l[19], cl3, rl0), th = ZK_X3(h[19], ch3, rh0);
-          bh[13] = ZK_ALIGN(th, tl, 24); bl[13] = ZK_ALIGN(tl, th, 24); }
-        { const uint32_t tl = ZK_X3(l[20], cl4, rl1), th = ZK_X3(h[20], ch4, rh1);
-          bh[14] = ZK_ALIGN(th, tl, 14); bl[14] = ZK_ALIGN(tl, th, 14); }
-        { const uint32_t tl = ZK_X3(l[21], cl0, rl2), th = ZK_X3(h[21], ch0, rh2);
-          bh[24] = ZK_ALIGN(th, tl, 30); bl[24] = ZK_ALIGN(tl, th, 30); }
-        { const uint32_t tl = ZK_X3(l[22], cl1, rl3), th = ZK_X3(h[22], ch1, rh3);
-          bh[9] = ZK_ALIGN(tl, th, 3); bl[9] = ZK_ALIGN(th, tl, 3); }
-        { const uint32_t tl = ZK_X3(l[23], cl2, rl4), th = ZK_X3(h[23], ch2, rh4);
-          bh[19] = ZK_ALIGN(tl, th, 8); bl[19] = ZK_ALIGN(th, tl, 8); }
-        { const uint32_t tl = ZK_X3(l[24], cl3, rl0), th = ZK_X3(h[24], ch3, rh0);
-          bh[4] = ZK_ALIGN(th, tl, 18); bl[4] = ZK_ALIGN(tl, th, 18); }
-        // chi
-        l[0] = ZK_CHI(bl[0], bl[1], bl[2]); h[0] = ZK_CHI(bh[0], bh[1], bh[2]);
-        l[1] = ZK_CHI(bl[1], bl[2], bl[3]); h[1] = ZK_CHI(bh[1], bh[2], bh[3]);
-        l[2] = ZK_CHI(bl[2], bl[3], bl[4]); h[2] = ZK_CHI(bh[2], bh[3], bh[4]);
-        l[3] = ZK_CHI(bl[3], bl[4], bl[0]); h[3] = ZK_CHI(bh[3], bh[4], bh[0]);
-        l[4] = ZK_CHI(bl[4], bl[0], bl[1]); h[4] = ZK_CHI(bh[4], bh[0], bh[1]);
-        l[5] = ZK_CHI(bl[5], bl[6], bl[7]); h[5] = ZK_CHI(bh[5], bh[6], bh[7]);
-        l[6] = ZK_CHI(bl[6], bl[7], bl[8]); h[6] = ZK_CHI(bh[6], bh[7], bh[8]);
-        l[7] = ZK_CHI(bl[7], bl[8], bl[9]); h[7] = ZK_CHI(bh[7], bh[8], bh[9]);
-        l[8] = ZK_CHI(bl[8], bl[9], bl[5]); h[8] = ZK_CHI(bh[8], bh[9], bh[5]);
-        l[9] = ZK_CHI(bl[9], bl[5], bl[6]); h[9] = ZK_CHI(bh[9], bh[5], bh[6]);
-        l[10] = ZK_CHI(bl[10], bl[11], bl[12]); h[10] = ZK_CHI(bh[10], bh[11], bh[12]);
-        l[11] = ZK_CHI(bl[11], bl[12], bl[13]); h[11] = ZK_CHI(bh[11], bh[12], bh[13]);
-        l[12] = ZK_CHI(bl[12], bl[13], bl[14]); h[12] = ZK_CHI(bh[12], bh[13], bh[14]);
-        l[13] = ZK_CHI(bl[13], bl[14], bl[10]); h[13] = ZK_CHI(bh[13], bh[14], bh[10]);
-        l[14] = ZK_CHI(bl[14], bl[10], bl[11]); h[14] = ZK_CHI(bh[14], bh[10], bh[11]);
-        l[15] = ZK_CHI(bl[15], bl[16], bl[17]); h[15] = ZK_CHI(bh[15], bh[16], bh[17]);
-        l[16] = ZK_CHI(bl[16], bl[17], bl[18]); h[16] = ZK_CHI(bh[16], bh[17], bh[18]);
-        l[17] = ZK_CHI(bl[17], bl[18], bl[19]); h[17] = ZK_CHI(bh[17], bh[18], bh[19]);
-        l[18] = ZK_CHI(bl[18], bl[19], bl[15]); h[18] = ZK_CHI(bh[18], bh[19], bh[15]);
-        l[19] = ZK_CHI(bl[19], bl[15], bl[16]); h[19] = ZK_CHI(bh[19], bh[15], bh[16]);
-        l[20] = ZK_CHI(bl[20], bl[21], bl[22]); h[20] = ZK_CHI(bh[20], bh[21], bh[22]);
-        l[21] = ZK_CHI(bl[21], bl[22], bl[23]); h[21] = ZK_CHI(bh[21], bh[22], bh[23]);
-        l[22] = ZK_CHI(bl[22], bl[23], bl[24]); h[22] = ZK_CHI(bh[22], bh[23], bh[24]);
-        l[23] = ZK_CHI(bl[23], bl[24], bl[20]); h[23] = ZK_CHI(bh[23], bh[24], bh[20]);
-        l[24] = ZK_CHI(bl[24], bl[20], bl[21]); h[24] = ZK_CHI(bh[24], bh[20], bh[21]);
-        l[0] ^= (uint32_t)KECCAK_RC[r];
-        h[0] ^= (uint32_t)(KECCAK_RC[r] >> 32);
+        uint32_t be[25], bo[25];
+        const uint32_t ce0 = ZK_X3(ZK_X3(e[0], e[5], e[10]), e[15], e[20]);
+        const uint32_t co0 = ZK_X3(ZK_X3(o[0], o[5], o[10]), o[15], o[20]);
+        const uint32_t ce1 = ZK_X3(ZK_X3(e[1], e[6], e[11]), e[16], e[21]);
+        const uint32_t co1 = ZK_X3(ZK_X3(o[1], o[6], o[11]), o[16], o[21]);
+        const uint32_t ce2 = ZK_X3(ZK_X3(e[2], e[7], e[12]), e[17], e[22]);
+        const uint32_t co2 = ZK_X3(ZK_X3(o[2], o[7], o[12]), o[17], o[22]);
+        const uint32_t ce3 = ZK_X3(ZK_X3(e[3], e[8], e[13]), e[18], e[23]);
+        const uint32_t co3 = ZK_X3(ZK_X3(o[3], o[8], o[13]), o[18], o[23]);
+        const uint32_t ce4 = ZK_X3(ZK_X3(e[4], e[9], e[14]), e[19], e[24]);
+        const uint32_t co4 = ZK_X3(ZK_X3(o[4], o[9], o[14]), o[19], o[24]);
+        const uint32_t re0 = ZK_ROT32(co0, 1);  // rot64(C[0], 1): even <- rot32(odd, 1), odd <- even
+        const uint32_t re1 = ZK_ROT32(co1, 1);  // rot64(C[1], 1): even <- rot32(odd, 1), odd <- even
+        const uint32_t re2 = ZK_ROT32(co2, 1);  // rot64(C[2], 1): even <- rot32(odd, 1), odd <- even
+        const uint32_t re3 = ZK_ROT32(co3, 1);  // rot64(C[3], 1): even <- rot32(odd, 1), odd <- even
+        const uint32_t re4 = ZK_ROT32(co4, 1);  // rot64(C[4], 1): even <- rot32(odd, 1), odd <- even
+        { const uint32_t te = ZK_X3(e[0], ce4, re1), to = ZK_X3(o[0], co4, ce1);  // lane 0, rho 0 -> 0
+          be[0] = te; bo[0] = to; }
+        { const uint32_t te = ZK_X3(e[1], ce0, re2), to = ZK_X3(o[1], co0, ce2);  // lane 1, rho 1 -> 10
+          be[10] = ZK_ROT32(to, 1); bo[10] = te; }
+        { const uint32_t te = ZK_X3(e[2], ce1, re3), to = ZK_X3(o[2], co1, ce3);  // lane 2, rho 62 -> 20
+          be[20] = ZK_ROT32(te, 31); bo[20] = ZK_ROT32(to, 31); }
+        { const uint32_t te = ZK_X3(e[3], ce2, re4), to = ZK_X3(o[3], co2, ce4);  // lane 3, rho 28 -> 5
+          be[5] = ZK_ROT32(te, 14); bo[5] = ZK_ROT32(to, 14); }
+        { const uint32_t te = ZK_X3(e[4], ce3, re0), to = ZK_X3(o[4], co3, ce0);  // lane 4, rho 27 -> 15
+          be[15] = ZK_ROT32(to, 14); bo[15] = ZK_ROT32(te, 13); }
+        { const uint32_t te = ZK_X3(e[5], ce4, re1), to = ZK_X3(o[5], co4, ce1);  // lane 5, rho 36 -> 16
+          be[16] = ZK_ROT32(te, 18); bo[16] = ZK_ROT32(to, 18); }
+        { const uint32_t te = ZK_X3(e[6], ce0, re2), to = ZK_X3(o[6], co0, ce2);  // lane 6, rho 44 -> 1
+          be[1] = ZK_ROT32(te, 22); bo[1] = ZK_ROT32(to, 22); }
+        { const uint32_t te = ZK_X3(e[7], ce1, re3), to = ZK_X3(o[7], co1, ce3);  // lane 7, rho 6 -> 11
+          be[11] = ZK_ROT32(te, 3); bo[11] = ZK_ROT32(to, 3); }
+        { const uint32_t te = ZK_X3(e[8], ce2, re4), to = ZK_X3(o[8], co2, ce4);  // lane 8, rho 55 -> 21
+          be[21] = ZK_ROT32(to, 28); bo[21] = ZK_ROT32(te, 27); }
+        { const uint32_t te = ZK_X3(e[9], ce3, re0), to = ZK_X3(o[9], co3, ce0);  // lane 9, rho 20 -> 6
+          be[6] = ZK_ROT32(te, 10); bo[6] = ZK_ROT32(to, 10); }
+        { const uint32_t te = ZK_X3(e[10], ce4, re1), to = ZK_X3(o[10], co4, ce1);  // lane 10, rho 3 -> 7
+          be[7] = ZK_ROT32(to, 2); bo[7] = ZK_ROT32(te, 1); }
+        { const uint32_t te = ZK_X3(e[11], ce0, re2), to = ZK_X3(o[11], co0, ce2);  // lane 11, rho 10 -> 17
+          be[17] = ZK_ROT32(te, 5); bo[17] = ZK_ROT32(to, 5); }
+        { const uint32_t te = ZK_X3(e[12], ce1, re3), to = ZK_X3(o[12], co1, ce3);  // lane 12, rho 43 -> 2
+          be[2] = ZK_ROT32(to, 22); bo[2] = ZK_ROT32(te, 21); }
+        { const uint32_t te = ZK_X3(e[13], ce2, re4), to = ZK_X3(o[13], co2, ce4);  // lane 13, rho 25 -> 12
+          be[12] = ZK_ROT32(to, 13); bo[12] = ZK_ROT32(te, 12); }
+        { const uint32_t te = ZK_X3(e[14], ce3, re0), to = ZK_X3(o[14], co3, ce0);  // lane 14, rho 39 -> 22
+          be[22] = ZK_ROT32(to, 20); bo[22] = ZK_ROT32(te, 19); }
+        { const uint32_t te = ZK_X3(e[15], ce4, re1), to = ZK_X3(o[15], co4, ce1);  // lane 15, rho 41 -> 23
+          be[23] = ZK_ROT32(to, 21); bo[23] = ZK_ROT32(te, 20); }
+        { const uint32_t te = ZK_X3(e[16], ce0, re2), to = ZK_X3(o[16], co0, ce2);  // lane 16, rho 45 -> 8
+          be[8] = ZK_ROT32(to, 23); bo[8] = ZK_ROT32(te, 22); }
+        { const uint32_t te = ZK_X3(e[17], ce1, re3), to = ZK_X3(o[17], co1, ce3);  // lane 17, rho 15 -> 18
+          be[18] = ZK_ROT32(to, 8); bo[18] = ZK_ROT32(te, 7); }
+        { const uint32_t te = ZK_X3(e[18], ce2, re4), to = ZK_X3(o[18], co2, ce4);  // lane 18, rho 21 -> 3
+          be[3] = ZK_ROT32(to, 11); bo[3] = ZK_ROT32(te, 10); }
+        { const uint32_t te = ZK_X3(e[19], ce3, re0), to = ZK_X3(o[19], co3, ce0);  // lane 19, rho 8 -> 13
+          be[13] = ZK_ROT32(te, 4); bo[13] = ZK_ROT32(to, 4); }
+        { const uint32_t te = ZK_X3(e[20], ce4, re1), to = ZK_X3(o[20], co4, ce1);  // lane 20, rho 18 -> 14
+          be[14] = ZK_ROT32(te, 9); bo[14] = ZK_ROT32(to, 9); }
+        { const uint32_t te = ZK_X3(e[21], ce0, re2), to = ZK_X3(o[21], co0, ce2);  // lane 21, rho 2 -> 24
+          be[24] = ZK_ROT32(te, 1); bo[24] = ZK_ROT32(to, 1); }
+        { const uint32_t te = ZK_X3(e[22], ce1, re3), to = ZK_X3(o[22], co1, ce3);  // lane 22, rho 61 -> 9
+          be[9] = ZK_ROT32(to, 31); bo[9] = ZK_ROT32(te, 30); }
+        { const uint32_t te = ZK_X3(e[23], ce2, re4), to = ZK_X3(o[23], co2, ce4);  // lane 23, rho 56 -> 19
+          be[19] = ZK_ROT32(te, 28); bo[19] = ZK_ROT32(to, 28); }
+        { const uint32_t te = ZK_X3(e[24], ce3, re0), to = ZK_X3(o[24], co3, ce0);  // lane 24, rho 14 -> 4
+          be[4] = ZK_ROT32(te, 7); bo[4] = ZK_ROT32(to, 7); }
+        e[0] = ZK_CHI(be[0], be[1], be[2]); o[0] = ZK_CHI(bo[0], bo[1], bo[2]);
+        e[1] = ZK_CHI(be[1], be[2], be[3]); o[1] = ZK_CHI(bo[1], bo[2], bo[3]);
+        e[2] = ZK_CHI(be[2], be[3], be[4]); o[2] = ZK_CHI(bo[2], bo[3], bo[4]);
+        e[3] = ZK_CHI(be[3], be[4], be[0]); o[3] = ZK_CHI(bo[3], bo[4], bo[0]);
+        e[4] = ZK_CHI(be[4], be[0], be[1]); o[4] = ZK_CHI(bo[4], bo[0], bo[1]);
+        e[5] = ZK_CHI(be[5], be[6], be[7]); o[5] = ZK_CHI(bo[5], bo[6], bo[7]);
+        e[6] = ZK_CHI(be[6], be[7], be[8]); o[6] = ZK_CHI(bo[6], bo[7], bo[8]);
+        e[7] = ZK_CHI(be[7], be[8], be[9]); o[7] = ZK_CHI(bo[7], bo[8], bo[9]);
+        e[8] = ZK_CHI(be[8], be[9], be[5]); o[8] = ZK_CHI(bo[8], bo[9], bo[5]);
+        e[9] = ZK_CHI(be[9], be[5], be[6]); o[9] = ZK_CHI(bo[9], bo[5], bo[6]);
+        e[10] = ZK_CHI(be[10], be[11], be[12]); o[10] = ZK_CHI(bo[10], bo[11], bo[12]);
+        e[11] = ZK_CHI(be[11], be[12], be[13]); o[11] = ZK_CHI(bo[11], bo[12], bo[13]);
+        e[12] = ZK_CHI(be[12], be[13], be[14]); o[12] = ZK_CHI(bo[12], bo[13], bo[14]);
+        e[13] = ZK_CHI(be[13], be[14], be[10]); o[13] = ZK_CHI(bo[13], bo[14], bo[10]);
+        e[14] = ZK_CHI(be[14], be[10], be[11]); o[14] = ZK_CHI(bo[14], bo[10], bo[11]);
+        e[15] = ZK_CHI(be[15], be[16], be[17]); o[15] = ZK_CHI(bo[15], bo[16], bo[17]);
+        e[16] = ZK_CHI(be[16], be[17], be[18]); o[16] = ZK_CHI(bo[16], bo[17], bo[18]);
+        e[17] = ZK_CHI(be[17], be[18], be[19]); o[17] = ZK_CHI(bo[17], bo[18], bo[19]);
+        e[18] = ZK_CHI(be[18], be[19], be[15]); o[18] = ZK_CHI(bo[18], bo[19], bo[15]);
+        e[19] = ZK_CHI(be[19], be[15], be[16]); o[19] = ZK_CHI(bo[19], bo[15], bo[16]);
+        e[20] = ZK_CHI(be[20], be[21], be[22]); o[20] = ZK_CHI(bo[20], bo[21], bo[22]);
+        e[21] = ZK_CHI(be[21], be[22], be[23]); o[21] = ZK_CHI(bo[21], bo[22], bo[23]);
+        e[22] = ZK_CHI(be[22], be[23], be[24]); o[22] = ZK_CHI(bo[22], bo[23], bo[24]);
+        e[23] = ZK_CHI(be[23], be[24], be[20]); o[23] = ZK_CHI(bo[23], bo[24], bo[20]);
+        e[24] = ZK_CHI(be[24], be[20], be[21]); o[24] = ZK_CHI(bo[24], bo[20], bo[21]);
+        e[0] ^= KECCAK_RC_E[r];
+        o[0] ^= KECCAK_RC_O[r];
     }
 }
 
+// even bits of x -> low 16 bits
+__device__ __forceinline__ uint32_t compress_even(uint32_t x) {
+    x &= 0x55555555u;
+    x = (x | (x >> 1)) & 0x33333333u;
+    x = (x | (x >> 2)) & 0x0f0f0f0fu;
+    x = (x | (x >> 4)) & 0x00ff00ffu;
+    x = (x | (x >> 8)) & 0x0000ffffu;
+    return x;
+}
+// low 16 bits of x -> even bit positions
+__device__ __forceinline__ uint32_t expand_even(uint32_t x) {
+    x &= 0x0000ffffu;
+    x = (x | (x << 8)) & 0x00ff00ffu;
+    x = (x | (x << 4)) & 0x0f0f0f0fu;
+    x = (x | (x << 2)) & 0x33333333u;
+    x = (x | (x << 1)) & 0x55555555u;
+    return x;
+}
+
+// A SHA3-256 digest.  Inside the tree ("tree form"): w[i] = (odd bits of lane i) << 32 | (even bits of lane i).
+// canonical_digest() gives the 4 little-endian lanes of the standard byte string.
 struct Digest {
     uint64_t w[4];
 };
 
-__device__ __forceinline__ Digest digest_of(const uint32_t l[25], const uint32_t h[25]) {
-    return Digest{{((uint64_t)h[0] << 32) | l[0], ((uint64_t)h[1] << 32) | l[1], ((uint64_t)h[2] << 32) | l[2],
-                   ((uint64_t)h[3] << 32) | l[3]}};
+__device__ __forceinline__ Digest digest_of(const uint32_t e[25], const uint32_t o[25]) {
+    return Digest{{((uint64_t)o[0] << 32) | e[0], ((uint64_t)o[1] << 32) | e[1], ((uint64_t)o[2] << 32) | e[2],
+                   ((uint64_t)o[3] << 32) | e[3]}};
 }
 
-// SHA3-256 of the 8 LE bytes of a canonical field element (pad: 0x06 at byte 8, 0x80 at byte 135)
-__device__ __forceinline__ Digest sha3_leaf(uint64_t value) {
-    uint32_t l[25], h[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) { l[i] = 0; h[i] = 0; }
-    l[0] = (uint32_t)value;
-    h[0] = (uint32_t)(value >> 32);
-    l[1] = 0x06u;
-    h[16] = 0x80000000u;
-    keccak_f1600_32(l, h);
-    return digest_of(l, h);
-}
-
-// SHA3-256 of left || right (64 bytes; pad: 0x06 at byte 64, 0x80 at byte 135)
-__device__ __forceinline__ Digest sha3_node(const Digest &a, const Digest &b) {
-    uint32_t l[25], h[25];
-#pragma unroll
-    for (int i = 0; i < 25; i++) { l[i] = 0; h[i] = 0; }
+__device__ __forceinline__ Digest canonical_digest(const Digest &t) {
+    Digest c;
 #pragma unroll
     for (int i = 0; i < 4; i++) {
-        l[i] = (uint32_t)a.w[i]; h[i] = (uint32_t)(a.w[i] >> 32);
-        l[4 + i] = (uint32_t)b.w[i]; h[4 + i] = (uint32_t)(b.w[i] >> 32);
+        const uint32_t e = (uint32_t)t.w[i], o = (uint32_t)(t.w[i] >> 32);
+        const uint32_t lo = expand_even(e) | (expand_even(o) << 1);
+        const uint32_t hi = expand_even(e >> 16) | (expand_even(o >> 16) << 1);
+        c.w[i] = ((uint64_t)hi << 32) | lo;
     }
-    l[8] = 0x06u;
-    h[16] = 0x80000000u;
-    keccak_f1600_32(l, h);
-    return digest_of(l, h);
+    return c;
+}
+
+// SHA3-256 of the 8 LE bytes of a canonical field element (pad: 0x06 at byte 8, 0x80 at byte 135), tree form
+__device__ __forceinline__ Digest sha3_leaf(uint64_t value) {
+    uint32_t e[25], o[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) { e[i] = 0; o[i] = 0; }
+    const uint32_t lo = (uint32_t)value, hi = (uint32_t)(value >> 32);
+    e[0] = compress_even(lo) | (compress_even(hi) << 16);
+    o[0] = compress_even(lo >> 1) | (compress_even(hi >> 1) << 16);
+    e[1] = 0x2u;  // lane 1 = 0x06: bit 1 (odd bit 0), bit 2 (even bit 1)
+    o[1] = 0x1u;
+    o[16] = 0x80000000u;  // lane 16 = 1 << 63: odd bit 31
+    keccak_f1600_il(e, o);
+    return digest_of(e, o);
+}
+
+// SHA3-256 of left || right (64 bytes; pad: 0x06 at byte 64, 0x80 at byte 135); inputs and output in tree form
+__device__ __forceinline__ Digest sha3_node(const Digest &a, const Digest &b) {
+    uint32_t e[25], o[25];
+#pragma unroll
+    for (int i = 0; i < 25; i++) { e[i] = 0; o[i] = 0; }
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        e[i] = (uint32_t)a.w[i]; o[i] = (uint32_t)(a.w[i] >> 32);
+        e[4 + i] = (uint32_t)b.w[i]; o[4 + i] = (uint32_t)(b.w[i] >> 32);
+    }
+    e[8] = 0x2u;
+    o[8] = 0x1u;
+    o[16] = 0x80000000u;
+    keccak_f1600_il(e, o);
+    return digest_of(e, o);
 }
 
 }  // namespace zk

@@ -434,6 +434,8 @@ void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream
 }
 
 // ------------------------------------------------------------------ K5/K6: Keccak Merkle
+// Tree nodes are stored in the bit-interleaved "tree form" of keccak.hpp (32 B per node, the same size as the SHA3
+// byte string); k_paths / k_gather_nodes convert to canonical bytes on the way out.
 __device__ __forceinline__ void store_digest(uint8_t *tree, size_t node, const Digest &d) {
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(tree + node * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
@@ -447,7 +449,10 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
 
 // HPT hashes per thread (strided by the workgroup size so loads/stores stay coalesced): amortises wave launch
 // and set-up over several ~4.2 k-instruction permutations.
-constexpr int HPT = 4;
+#ifndef ZK_HPT
+#define ZK_HPT 4
+#endif
+constexpr int HPT = ZK_HPT;
 __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                        size_t tree_stride_nodes) {
@@ -674,7 +679,7 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
     const uint8_t *t = tree + col * tree_stride_nodes * 32;
     const size_t off = 2 * npad - 2 * (npad >> l);
-    Digest d = load_digest(t, off + (ci ^ 1));
+    const Digest d = canonical_digest(load_digest(t, off + (ci ^ 1)));  // tree form -> SHA3 bytes at the boundary
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
@@ -692,7 +697,7 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
                                uint8_t *__restrict__ out, size_t ncols) {
     size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= ncols) return;
-    Digest d = load_digest(tree + c * tree_stride_nodes * 32, node);
+    const Digest d = canonical_digest(load_digest(tree + c * tree_stride_nodes * 32, node));  // tree form -> SHA3 bytes
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + c * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
