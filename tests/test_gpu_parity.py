@@ -362,9 +362,9 @@ def test_witness_from_rows(ctx, ns):
 
 
 # ---------------------------------------------------------------- A5: both sumcheck forms agree
-@pytest.mark.parametrize("nv", [14, 15, 16, 18, 19, 21, 24])
+@pytest.mark.parametrize("nv", [10, 11, 12, 13, 14, 15, 16, 18, 19, 21, 24])
 def test_sumcheck_radix_equals_per_round(ctx, nv):
-    """Tables >= 2^14 take the radix-2^k form (k rounds per pass from block sums); it must reproduce the
+    """Tables >= 2^11 take the radix-2^k form (k rounds per pass from block sums); it must reproduce the
     one-launch-per-round form bit for bit, with Fiat-Shamir and with fixed challenges, and the oracle where
     the oracle is affordable."""
     n = 1 << nv

@@ -45,7 +45,7 @@ struct zigz_ctx {
 };
 static const size_t SUMS_SLOTS = 4096;
 constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck stage
-constexpr size_t RADIX_MIN_N = 1 << 14;  // smaller tables use the per-round form (everything on the GPU)
+constexpr size_t RADIX_MIN_N = 1 << 11;  // smaller tables use the per-round form (one launch + read-back per round)
 constexpr size_t HOST_TAIL_MAX = 1024;
 static const size_t PIN_WORDS = 1 << 16;
 
