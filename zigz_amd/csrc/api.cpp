@@ -65,6 +65,14 @@ static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
             return e_ == hipErrorOutOfMemory ? ZIGZ_ERR_OUT_OF_MEMORY : ZIGZ_ERR_HIP;            \
         }                                                                                        \
     } while (0)
+// host-side std::vector / std::string allocations must not throw through the C ABI
+#define ZIGZ_NOTHROW_BEGIN try {
+#define ZIGZ_NOTHROW_END(ctx)                                         \
+    }                                                                 \
+    catch (const std::bad_alloc &) {                                  \
+        set_err(ctx, "host allocation failed");                       \
+        return ZIGZ_ERR_OUT_OF_MEMORY;                                \
+    }
 #define CHK(expr)                          \
     do {                                   \
         zigz_status s_ = (expr);           \
@@ -640,6 +648,7 @@ inline uint64_t h_mul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __i
 
 static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *fixed, uint64_t *rounds,
                                   uint64_t *point, uint64_t *final_eval) {
+    ZIGZ_NOTHROW_BEGIN
     const unsigned nv = log2_floor(n);
     Transcript tr;  // fresh transcript per sumcheck, sumcheck_protocol.zig:161
     size_t round = 0;
@@ -735,6 +744,7 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
     if (round != nv) return ZIGZ_ERR_PROTOCOL_ERROR;  // sumcheck_prover.zig:80-82
     *final_eval = tail[0];
     return ZIGZ_OK;
+    ZIGZ_NOTHROW_END(ctx)
 }
 
 extern "C" zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
@@ -935,6 +945,7 @@ extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values,
 static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad, unsigned height, const uint32_t *d_vals,
                               size_t val_stride, const uint64_t *h_idx, size_t ncols, uint8_t *siblings, uint8_t *dirs,
                               uint64_t *leaves) {
+    ZIGZ_NOTHROW_BEGIN
     // device scratch layout: idx[ncols] u64 | sib[ncols*h*32] | leaf[ncols] u32 | dirs[ncols*h]
     const size_t sib_b = ncols * height * 32, idx_b = ncols * 8, leaf_b = ncols * 4, dir_b = ncols * height;
     void *w;
@@ -955,6 +966,7 @@ static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad,
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
     for (size_t c = 0; c < ncols; c++) leaves[c] = hl[c];
     return ZIGZ_OK;
+    ZIGZ_NOTHROW_END(ctx)
 }
 
 extern "C" zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *t, size_t index, uint8_t *siblings,
@@ -1097,6 +1109,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
 
 extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, uint64_t *values,
                                             uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs) {
+    ZIGZ_NOTHROW_BEGIN
     if (job) ZIGZ_ENTER(job->ctx);
     if (!job || !values || !indices || !leaves) return ZIGZ_ERR_INVALID_ARGUMENT;
     zigz_ctx *ctx = job->ctx;
@@ -1121,6 +1134,7 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
     CHK(bind_pool_collect(ctx));
     job->state = 2;
     return ZIGZ_OK;
+    ZIGZ_NOTHROW_END(job->ctx)
 }
 
 extern "C" void zigz_commit_end(zigz_commit_job *job) {
@@ -1158,6 +1172,7 @@ extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, si
                                         size_t n_queries, size_t n_in, size_t n_out, size_t *nv_out, uint64_t *rounds,
                                         uint64_t *point, uint64_t *final_eval, uint8_t query_commitment[32],
                                         uint8_t table_commitment[32]) {
+    ZIGZ_NOTHROW_BEGIN
     ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_queries == 0) return ZIGZ_ERR_NO_QUERIES;  // :108-110
@@ -1191,6 +1206,7 @@ extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, si
     flat_commit(hq.data(), padded, query_commitment);
     flat_commit(ht.data(), table_rows, table_commitment);
     return ZIGZ_OK;
+    ZIGZ_NOTHROW_END(ctx)
 }
 
 extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64_t *table, size_t table_rows,
@@ -1199,6 +1215,7 @@ extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64
                                                      size_t *nv_out, uint64_t *rounds, uint64_t *point,
                                                      uint64_t *final_eval, uint8_t query_commitment[32],
                                                      uint8_t table_commitment[32]) {
+    ZIGZ_NOTHROW_BEGIN
     ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_queries != n_mapping) return ZIGZ_ERR_MAPPING_LENGTH_MISMATCH;  // :185-187
@@ -1211,6 +1228,7 @@ extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64
     }
     return zigz_lasso_prove(ctx, table, table_rows, queries, n_queries, n_in, n_out, nv_out, rounds, point, final_eval,
                             query_commitment, table_commitment);
+    ZIGZ_NOTHROW_END(ctx)
 }
 
 // ------------------------------------------------------------------ host transcript
