@@ -67,3 +67,23 @@ class FakeOps:
             cur = self.bind(cur, n, ch)
             n //= 2
         return rounds, point, int(cur[0])
+
+
+class FakeTreeOps:
+    """Local subtree work of shard.RowShardedMerkle on the oracle."""
+
+    def commit(self, values):
+        v = np.ascontiguousarray(values, dtype=np.uint64)
+        return O.merkle_build(v)[0], v
+
+    def open(self, v, index):
+        h = (len(v) - 1).bit_length()
+        sib, dirs, leaf = O.merkle_open(v, index)
+        return (np.frombuffer(sib, dtype=np.uint8).reshape(h, 32), np.frombuffer(dirs, dtype=np.uint8), leaf)
+
+    def sha3(self, data):
+        import hashlib
+        return hashlib.sha3_256(data).digest()
+
+    def destroy(self, v):
+        pass

@@ -35,8 +35,16 @@ def _worker(rank, world, port, q):
         local = ops.upload(shard.interleave_rows(table, rank, world))
         r, p, fe = shard.sumcheck_prove_row_sharded(ops, local, 1 << 16, dist, zigz_amd.Transcript)
         ops.close()
+        nm = 1 << 14
+        vals = O.splitmix64_field(199, nm)
+        t = shard.RowShardedMerkle(shard.GpuTreeOps(ctx), vals[rank * nm // world:(rank + 1) * nm // world], nm, dist)
+        opens = []
+        for idx in (0, nm // 2 - 1, nm // 2, nm - 1, 12345):
+            sib, dirs, leaf = t.open(idx)
+            opens.append((idx, sib.tobytes().hex(), dirs.tobytes().hex(), int(leaf)))
+        t.close()
         q.put((rank, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()},
-               dict(rounds=r.tolist(), point=p.tolist(), fe=fe)))
+               dict(rounds=r.tolist(), point=p.tolist(), fe=fe), dict(root=t.root.hex(), height=t.height, opens=opens)))
     finally:
         ctx.close()
         dist.destroy_process_group()
@@ -59,7 +67,13 @@ def test_sharded_paths_world2_on_gpu():
     nxt = tr.challenge(P)
     table = O.splitmix64_field(188, 1 << 16)
     r, p, fe = O.sumcheck_prove(P, table)
-    for rank, got, sc in outs:
+    vals = O.splitmix64_field(199, 1 << 14)
+    mroot, mheight = O.merkle_build(vals)
+    for rank, got, sc, mk in outs:
+        assert mk["root"] == mroot.hex() and mk["height"] == mheight
+        for idx, sib, dirs, leaf in mk["opens"]:
+            esib, edirs, eleaf = O.merkle_open(vals, idx)
+            assert (sib, dirs, leaf) == (esib.hex(), edirs.hex(), eleaf), (rank, idx)
         for k in ("roots", "points", "values", "indices", "leaves", "siblings", "dirs"):
             assert np.array_equal(np.array(got[k], dtype=exp[k].dtype), exp[k]), (rank, k)
         assert got["next_challenge"] == nxt

@@ -43,6 +43,17 @@ def _worker(rank, world, port, kind, q):
             res = shard.generate_commitments_sharded(fake_engine.FakeEngine(), tr, cols[c0:c1], nv, dist)
             res["next_challenge"] = tr.challenge()
             q.put((rank, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()}))
+        elif kind.startswith("merkle"):
+            n = int(kind.split(":")[1])
+            vals = O.splitmix64_field(99, n)
+            nl = n // world
+            t = shard.RowShardedMerkle(fake_engine.FakeTreeOps(), vals[rank * nl:(rank + 1) * nl], n, dist)
+            opens = []
+            for idx in sorted({0, 1, n // 2, n - 1, (n * 5) // 7}):
+                sib, dirs, leaf = t.open(idx)
+                opens.append((idx, sib.tobytes().hex(), dirs.tobytes().hex(), leaf))
+            t.close()
+            q.put((rank, dict(root=t.root.hex(), height=t.height, opens=opens)))
         else:
             nv = 9
             table = O.splitmix64_field(88, 1 << nv)
@@ -96,3 +107,19 @@ def test_row_sharded_sumcheck_gloo(world):
     r, p, fe = O.sumcheck_prove(P, table)
     for rank in range(world):
         assert out[rank]["rounds"] == [int(x) for x in r] and out[rank]["point"] == [int(x) for x in p] and out[rank]["fe"] == fe
+
+
+@pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (4, 4), (2, 2)])
+def test_row_sharded_merkle_gloo(world, n):
+    """Contiguous row ownership: subtree per rank, G roots all-gathered, top levels on every rank; root and openings
+    equal the unsharded SimpleMerkleTree's (also when a rank holds a single leaf)."""
+    out = _run(world, "merkle:%d" % n)
+    vals = O.splitmix64_field(99, n)
+    root, height = O.merkle_build(vals)
+    for rank in range(world):
+        got = out[rank]
+        assert got["root"] == root.hex() and got["height"] == height
+        for idx, sib, dirs, leaf in got["opens"]:
+            esib, edirs, eleaf = O.merkle_open(vals, idx)
+            assert (sib, dirs, leaf) == (esib.hex(), edirs.hex(), eleaf), (rank, idx)
+            assert O.merkle_verify(root, leaf, bytes.fromhex(sib), bytes.fromhex(dirs))

@@ -11,6 +11,12 @@ over xGMI on a node, "gloo" in the CPU tests).  SURVEY.md s8(e):
   rounds; each round costs ONE all-reduce(sum) of the two partial half sums (16 bytes), the last log2(G)
   rounds run on the all-gathered G-element table.
 
+* rows (Merkle) -- `RowShardedMerkle`: one large column owned by CONTIGUOUS slices (top log2 G index bits), the
+  layout a Merkle tree prefers: each rank builds the subtree over its slice, the G subtree roots (G x 32 B) are
+  all-gathered, and every rank finishes the top log2 G levels itself (G - 1 host SHA3 calls).  An opening is the
+  owner's local path (all-gathered, only the owner contributes) followed by the siblings of the top levels.
+  Both row layouts coexist because the committed columns and the sumcheck table are different buffers.
+
 Messages are 16 B - a few KiB: latency-bound, far below xGMI link bandwidth.  The compute is delegated to an
 `ops` object (GpuOps below = libzigz_hip.so; the CPU tests inject an oracle-backed stand-in), so this file
 holds only the partitioning and exchange logic.
@@ -148,6 +154,62 @@ def sumcheck_prove_row_sharded(ops, local_table, n_global, dist, transcript_fact
     return np.array(rounds, dtype=np.uint64), np.array(point, dtype=np.uint64), int(fe)
 
 
+class RowShardedMerkle:
+    """SimpleMerkleTree.build / open (src/commitments/merkle_tree.zig:283-360) of ONE column sharded by contiguous
+    rows: rank r holds values[r*n/G : (r+1)*n/G] (n and G powers of two, n >= G).  `tree_ops` supplies the local
+    work: commit(values) -> (root32 bytes, handle), open(handle, index) -> (siblings[h,32], dirs[h], leaf),
+    sha3(bytes) -> 32 bytes (GpuTreeOps below = libzigz_hip.so).  Root and openings equal the unsharded tree's."""
+
+    def __init__(self, tree_ops, local_values, n_global, dist):
+        self.ops, self.dist = tree_ops, dist
+        self.rank, self.world = dist.get_rank(), dist.get_world_size()
+        assert n_global & (n_global - 1) == 0 and self.world & (self.world - 1) == 0 and n_global >= self.world
+        self.n, self.n_local = n_global, n_global // self.world
+        assert len(local_values) == self.n_local
+        self.h_local = self.n_local.bit_length() - 1
+        self.h_top = self.world.bit_length() - 1
+        sub_root, self.handle = self.ops.commit(local_values)
+        gathered = _all_gather_bytes(dist, bytes(sub_root), 32)                      # exchange: G subtree roots
+        level = [g.tobytes() for g in gathered]
+        self.top = [level]                                                          # top[0] = subtree roots ... top[-1] = [root]
+        while len(level) > 1:
+            level = [self.ops.sha3(level[2 * i] + level[2 * i + 1]) for i in range(len(level) // 2)]
+            self.top.append(level)
+        self.root = level[0]
+
+    @property
+    def height(self):
+        return self.h_local + self.h_top
+
+    def open(self, index):
+        """-> (siblings[height,32] uint8, dirs[height] uint8, leaf value); IndexError like error.IndexOutOfBounds."""
+        if not 0 <= index < self.n:
+            raise IndexError("IndexOutOfBounds")
+        owner, local = divmod(index, self.n_local)
+        rec = 8 + 33 * self.h_local
+        payload = b""
+        if self.rank == owner:
+            sib, dirs, leaf = self.ops.open(self.handle, local)
+            payload = (np.array([leaf], dtype="<u8").tobytes() + np.ascontiguousarray(sib, dtype=np.uint8).tobytes() +
+                       np.ascontiguousarray(dirs, dtype=np.uint8).tobytes())
+        chunk = _all_gather_bytes(self.dist, payload, rec)[owner]                   # exchange: the owner's local path
+        leaf = int(np.frombuffer(chunk[:8].tobytes(), dtype="<u8")[0])
+        siblings = np.zeros((self.height, 32), dtype=np.uint8)
+        dirs = np.zeros(self.height, dtype=np.uint8)
+        siblings[: self.h_local] = chunk[8:8 + 32 * self.h_local].reshape(self.h_local, 32)
+        dirs[: self.h_local] = chunk[8 + 32 * self.h_local:rec]
+        pos = owner
+        for l in range(self.h_top):                                                 # top levels: known to every rank
+            siblings[self.h_local + l] = np.frombuffer(self.top[l][pos ^ 1], dtype=np.uint8)
+            dirs[self.h_local + l] = pos & 1
+            pos >>= 1
+        return siblings, dirs, leaf
+
+    def close(self):
+        self.ops.destroy(self.handle)
+        self.handle = None
+
+
 def _all_gather_u64(dist, value):
     import torch
     dev = _dist_device(dist)
@@ -169,6 +231,31 @@ class GpuEngine:
             d_ptr, stride = local_cols
             return CommitJob(self.ctx, d_cols=d_ptr, ncols=ncols, nv=nv, col_stride=stride)
         return CommitJob(self.ctx, cols=np.ascontiguousarray(local_cols, dtype=np.uint64))
+
+
+class GpuTreeOps:
+    """Local subtree work of RowShardedMerkle on libzigz_hip.so."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def commit(self, values):
+        from .hip import SimpleMerkleTree
+        t = SimpleMerkleTree(self.ctx, np.ascontiguousarray(values, dtype=np.uint64))
+        return t.getRoot(), t
+
+    def open(self, tree, index):
+        o = tree.open(index)
+        h = tree.height
+        return (np.frombuffer(o["siblings"], dtype=np.uint8).reshape(h, 32), np.frombuffer(o["directions"], dtype=np.uint8),
+                o["value"])
+
+    def sha3(self, data):
+        from .hip import sha3_256
+        return sha3_256(data)
+
+    def destroy(self, tree):
+        tree.deinit()
 
 
 class GpuOps:
