@@ -436,10 +436,16 @@ void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream
 // ------------------------------------------------------------------ K5/K6: Keccak Merkle
 // Tree nodes are stored in the bit-interleaved "tree form" of keccak.hpp (32 B per node, the same size as the SHA3
 // byte string); k_paths / k_gather_nodes convert to canonical bytes on the way out.
+// Non-temporal stores: a level's 1-3 GiB of digests are read back once by the next level, from HBM either way; kept out
+// of the caches they do not leave the L2 / 256 MB Infinity Cache full of dirty lines whose write-back would compete
+// with the next reader of the witness columns (the eval pass right after the build runs at 33 us instead of 37 us,
+// tools/merkle_rate.hip; the build itself is unchanged).
 __device__ __forceinline__ void store_digest(uint8_t *tree, size_t node, const Digest &d) {
-    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(tree + node * 32);
-    q[0] = make_ulonglong2(d.w[0], d.w[1]);
-    q[1] = make_ulonglong2(d.w[2], d.w[3]);
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
+    __builtin_nontemporal_store(d.w[0], q + 0);  // merged into two global_store_dwordx4 ... nt
+    __builtin_nontemporal_store(d.w[1], q + 1);
+    __builtin_nontemporal_store(d.w[2], q + 2);
+    __builtin_nontemporal_store(d.w[3], q + 3);
 }
 __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) {
     const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(tree + node * 32);
