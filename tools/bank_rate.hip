@@ -497,6 +497,45 @@ __global__ __launch_bounds__(256) void k_vary(uint32_t *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+__global__ __launch_bounds__(256) void k_dep(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_bitop3_b32 v40, v48, v47, v45 bitop3:0x96\n"
+                     "v_bitop3_b32 v41, v49, v48, v46 bitop3:0x96\n"
+                     "v_bitop3_b32 v42, v50, v49, v47 bitop3:0x96\n"
+                     "v_bitop3_b32 v43, v51, v50, v48 bitop3:0x96\n"
+                     "v_bitop3_b32 v44, v52, v51, v49 bitop3:0x96\n"
+                     "v_bitop3_b32 v45, v53, v52, v50 bitop3:0x96\n"
+                     "v_bitop3_b32 v46, v54, v53, v51 bitop3:0x96\n"
+                     "v_bitop3_b32 v47, v55, v54, v52 bitop3:0x96\n"
+                     "v_bitop3_b32 v48, v40, v55, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v49, v41, v40, v54 bitop3:0x96\n"
+                     "v_bitop3_b32 v50, v42, v41, v55 bitop3:0x96\n"
+                     "v_bitop3_b32 v51, v43, v42, v40 bitop3:0x96\n"
+                     "v_bitop3_b32 v52, v44, v43, v41 bitop3:0x96\n"
+                     "v_bitop3_b32 v53, v45, v44, v42 bitop3:0x96\n"
+                     "v_bitop3_b32 v54, v46, v45, v43 bitop3:0x96\n"
+                     "v_bitop3_b32 v55, v47, v46, v44 bitop3:0x96\n"
+                     "v_bitop3_b32 v40, v48, v47, v45 bitop3:0x96\n"
+                     "v_bitop3_b32 v41, v49, v48, v46 bitop3:0x96\n"
+                     "v_bitop3_b32 v42, v50, v49, v47 bitop3:0x96\n"
+                     "v_bitop3_b32 v43, v51, v50, v48 bitop3:0x96\n"
+                     "v_bitop3_b32 v44, v52, v51, v49 bitop3:0x96\n"
+                     "v_bitop3_b32 v45, v53, v52, v50 bitop3:0x96\n"
+                     "v_bitop3_b32 v46, v54, v53, v51 bitop3:0x96\n"
+                     "v_bitop3_b32 v47, v55, v54, v52 bitop3:0x96\n"
+                     "v_bitop3_b32 v48, v40, v55, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v49, v41, v40, v54 bitop3:0x96\n"
+                     "v_bitop3_b32 v50, v42, v41, v55 bitop3:0x96\n"
+                     "v_bitop3_b32 v51, v43, v42, v40 bitop3:0x96\n"
+                     "v_bitop3_b32 v52, v44, v43, v41 bitop3:0x96\n"
+                     "v_bitop3_b32 v53, v45, v44, v42 bitop3:0x96\n"
+                     "v_bitop3_b32 v54, v46, v45, v43 bitop3:0x96\n"
+                     "v_bitop3_b32 v55, v47, v46, v44 bitop3:0x96\n"
+                     : "+v"(acc) : : CLOB, "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55");
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 __global__ __launch_bounds__(256) void k_mix(uint32_t *out, int iters) {
     uint32_t acc = threadIdx.x;
     for (int it = 0; it < iters; it++)
@@ -588,6 +627,26 @@ int main() {
         float ms;
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("%-56s %8.2f T lane-ops/s\n", "bitop3, different conflict-free sources each time", (double)blocks * 256 * iters * 32 / ms / 1e9);
+    }
+    for (int blocks : {256, 512, 1024, 2048}) {  // occupancy: 1, 2, 4, 8 waves per SIMD
+        const int iters = 4000;
+        uint32_t *d;
+        (void)hipMalloc(&d, blocks * 256 * 4);
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        for (int which = 0; which < 2; which++) {
+            if (which == 0) k_vary<<<blocks, 256>>>(d, 10); else k_dep<<<blocks, 256>>>(d, 10);
+            (void)hipDeviceSynchronize();
+            (void)hipEventRecord(e0);
+            if (which == 0) k_vary<<<blocks, 256>>>(d, iters); else k_dep<<<blocks, 256>>>(d, iters);
+            (void)hipEventRecord(e1);
+            (void)hipEventSynchronize(e1);
+            float ms;
+            (void)hipEventElapsedTime(&ms, e0, e1);
+            printf("%d waves/SIMD, bitop3 %-34s %8.2f T lane-ops/s\n", blocks / 256, which == 0 ? "independent" : "reading results 8-11 instrs back", (double)blocks * 256 * iters * 32 / ms / 1e9);
+        }
+        (void)hipFree(d);
     }
     {   // the Keccak mix (24 bitop3 : 10 alignbit), independent and conflict-free: what the issue logic allows at best
         const int blocks = 256 * 8, iters = 4000;
