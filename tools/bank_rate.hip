@@ -577,6 +577,482 @@ __global__ __launch_bounds__(256) void k_mix(uint32_t *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+__global__ __launch_bounds__(256) void k_one0(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_lshlrev_b32 v40, 13, v21\n"
+                     "v_lshlrev_b32 v41, 13, v21\n"
+                     "v_lshlrev_b32 v42, 13, v21\n"
+                     "v_lshlrev_b32 v43, 13, v21\n"
+                     "v_lshlrev_b32 v44, 13, v21\n"
+                     "v_lshlrev_b32 v45, 13, v21\n"
+                     "v_lshlrev_b32 v46, 13, v21\n"
+                     "v_lshlrev_b32 v47, 13, v21\n"
+                     "v_lshlrev_b32 v40, 13, v21\n"
+                     "v_lshlrev_b32 v41, 13, v21\n"
+                     "v_lshlrev_b32 v42, 13, v21\n"
+                     "v_lshlrev_b32 v43, 13, v21\n"
+                     "v_lshlrev_b32 v44, 13, v21\n"
+                     "v_lshlrev_b32 v45, 13, v21\n"
+                     "v_lshlrev_b32 v46, 13, v21\n"
+                     "v_lshlrev_b32 v47, 13, v21\n"
+                     "v_lshlrev_b32 v40, 13, v21\n"
+                     "v_lshlrev_b32 v41, 13, v21\n"
+                     "v_lshlrev_b32 v42, 13, v21\n"
+                     "v_lshlrev_b32 v43, 13, v21\n"
+                     "v_lshlrev_b32 v44, 13, v21\n"
+                     "v_lshlrev_b32 v45, 13, v21\n"
+                     "v_lshlrev_b32 v46, 13, v21\n"
+                     "v_lshlrev_b32 v47, 13, v21\n"
+                     "v_lshlrev_b32 v40, 13, v21\n"
+                     "v_lshlrev_b32 v41, 13, v21\n"
+                     "v_lshlrev_b32 v42, 13, v21\n"
+                     "v_lshlrev_b32 v43, 13, v21\n"
+                     "v_lshlrev_b32 v44, 13, v21\n"
+                     "v_lshlrev_b32 v45, 13, v21\n"
+                     "v_lshlrev_b32 v46, 13, v21\n"
+                     "v_lshlrev_b32 v47, 13, v21\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one1(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_lshrrev_b32 v40, 19, v21\n"
+                     "v_lshrrev_b32 v41, 19, v21\n"
+                     "v_lshrrev_b32 v42, 19, v21\n"
+                     "v_lshrrev_b32 v43, 19, v21\n"
+                     "v_lshrrev_b32 v44, 19, v21\n"
+                     "v_lshrrev_b32 v45, 19, v21\n"
+                     "v_lshrrev_b32 v46, 19, v21\n"
+                     "v_lshrrev_b32 v47, 19, v21\n"
+                     "v_lshrrev_b32 v40, 19, v21\n"
+                     "v_lshrrev_b32 v41, 19, v21\n"
+                     "v_lshrrev_b32 v42, 19, v21\n"
+                     "v_lshrrev_b32 v43, 19, v21\n"
+                     "v_lshrrev_b32 v44, 19, v21\n"
+                     "v_lshrrev_b32 v45, 19, v21\n"
+                     "v_lshrrev_b32 v46, 19, v21\n"
+                     "v_lshrrev_b32 v47, 19, v21\n"
+                     "v_lshrrev_b32 v40, 19, v21\n"
+                     "v_lshrrev_b32 v41, 19, v21\n"
+                     "v_lshrrev_b32 v42, 19, v21\n"
+                     "v_lshrrev_b32 v43, 19, v21\n"
+                     "v_lshrrev_b32 v44, 19, v21\n"
+                     "v_lshrrev_b32 v45, 19, v21\n"
+                     "v_lshrrev_b32 v46, 19, v21\n"
+                     "v_lshrrev_b32 v47, 19, v21\n"
+                     "v_lshrrev_b32 v40, 19, v21\n"
+                     "v_lshrrev_b32 v41, 19, v21\n"
+                     "v_lshrrev_b32 v42, 19, v21\n"
+                     "v_lshrrev_b32 v43, 19, v21\n"
+                     "v_lshrrev_b32 v44, 19, v21\n"
+                     "v_lshrrev_b32 v45, 19, v21\n"
+                     "v_lshrrev_b32 v46, 19, v21\n"
+                     "v_lshrrev_b32 v47, 19, v21\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one2(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_lshl_or_b32 v40, v20, 13, v21\n"
+                     "v_lshl_or_b32 v41, v20, 13, v21\n"
+                     "v_lshl_or_b32 v42, v20, 13, v21\n"
+                     "v_lshl_or_b32 v43, v20, 13, v21\n"
+                     "v_lshl_or_b32 v44, v20, 13, v21\n"
+                     "v_lshl_or_b32 v45, v20, 13, v21\n"
+                     "v_lshl_or_b32 v46, v20, 13, v21\n"
+                     "v_lshl_or_b32 v47, v20, 13, v21\n"
+                     "v_lshl_or_b32 v40, v20, 13, v21\n"
+                     "v_lshl_or_b32 v41, v20, 13, v21\n"
+                     "v_lshl_or_b32 v42, v20, 13, v21\n"
+                     "v_lshl_or_b32 v43, v20, 13, v21\n"
+                     "v_lshl_or_b32 v44, v20, 13, v21\n"
+                     "v_lshl_or_b32 v45, v20, 13, v21\n"
+                     "v_lshl_or_b32 v46, v20, 13, v21\n"
+                     "v_lshl_or_b32 v47, v20, 13, v21\n"
+                     "v_lshl_or_b32 v40, v20, 13, v21\n"
+                     "v_lshl_or_b32 v41, v20, 13, v21\n"
+                     "v_lshl_or_b32 v42, v20, 13, v21\n"
+                     "v_lshl_or_b32 v43, v20, 13, v21\n"
+                     "v_lshl_or_b32 v44, v20, 13, v21\n"
+                     "v_lshl_or_b32 v45, v20, 13, v21\n"
+                     "v_lshl_or_b32 v46, v20, 13, v21\n"
+                     "v_lshl_or_b32 v47, v20, 13, v21\n"
+                     "v_lshl_or_b32 v40, v20, 13, v21\n"
+                     "v_lshl_or_b32 v41, v20, 13, v21\n"
+                     "v_lshl_or_b32 v42, v20, 13, v21\n"
+                     "v_lshl_or_b32 v43, v20, 13, v21\n"
+                     "v_lshl_or_b32 v44, v20, 13, v21\n"
+                     "v_lshl_or_b32 v45, v20, 13, v21\n"
+                     "v_lshl_or_b32 v46, v20, 13, v21\n"
+                     "v_lshl_or_b32 v47, v20, 13, v21\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one3(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_lshl_add_u32 v40, v20, 13, v21\n"
+                     "v_lshl_add_u32 v41, v20, 13, v21\n"
+                     "v_lshl_add_u32 v42, v20, 13, v21\n"
+                     "v_lshl_add_u32 v43, v20, 13, v21\n"
+                     "v_lshl_add_u32 v44, v20, 13, v21\n"
+                     "v_lshl_add_u32 v45, v20, 13, v21\n"
+                     "v_lshl_add_u32 v46, v20, 13, v21\n"
+                     "v_lshl_add_u32 v47, v20, 13, v21\n"
+                     "v_lshl_add_u32 v40, v20, 13, v21\n"
+                     "v_lshl_add_u32 v41, v20, 13, v21\n"
+                     "v_lshl_add_u32 v42, v20, 13, v21\n"
+                     "v_lshl_add_u32 v43, v20, 13, v21\n"
+                     "v_lshl_add_u32 v44, v20, 13, v21\n"
+                     "v_lshl_add_u32 v45, v20, 13, v21\n"
+                     "v_lshl_add_u32 v46, v20, 13, v21\n"
+                     "v_lshl_add_u32 v47, v20, 13, v21\n"
+                     "v_lshl_add_u32 v40, v20, 13, v21\n"
+                     "v_lshl_add_u32 v41, v20, 13, v21\n"
+                     "v_lshl_add_u32 v42, v20, 13, v21\n"
+                     "v_lshl_add_u32 v43, v20, 13, v21\n"
+                     "v_lshl_add_u32 v44, v20, 13, v21\n"
+                     "v_lshl_add_u32 v45, v20, 13, v21\n"
+                     "v_lshl_add_u32 v46, v20, 13, v21\n"
+                     "v_lshl_add_u32 v47, v20, 13, v21\n"
+                     "v_lshl_add_u32 v40, v20, 13, v21\n"
+                     "v_lshl_add_u32 v41, v20, 13, v21\n"
+                     "v_lshl_add_u32 v42, v20, 13, v21\n"
+                     "v_lshl_add_u32 v43, v20, 13, v21\n"
+                     "v_lshl_add_u32 v44, v20, 13, v21\n"
+                     "v_lshl_add_u32 v45, v20, 13, v21\n"
+                     "v_lshl_add_u32 v46, v20, 13, v21\n"
+                     "v_lshl_add_u32 v47, v20, 13, v21\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one4(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_and_or_b32 v40, v20, v21, v22\n"
+                     "v_and_or_b32 v41, v20, v21, v22\n"
+                     "v_and_or_b32 v42, v20, v21, v22\n"
+                     "v_and_or_b32 v43, v20, v21, v22\n"
+                     "v_and_or_b32 v44, v20, v21, v22\n"
+                     "v_and_or_b32 v45, v20, v21, v22\n"
+                     "v_and_or_b32 v46, v20, v21, v22\n"
+                     "v_and_or_b32 v47, v20, v21, v22\n"
+                     "v_and_or_b32 v40, v20, v21, v22\n"
+                     "v_and_or_b32 v41, v20, v21, v22\n"
+                     "v_and_or_b32 v42, v20, v21, v22\n"
+                     "v_and_or_b32 v43, v20, v21, v22\n"
+                     "v_and_or_b32 v44, v20, v21, v22\n"
+                     "v_and_or_b32 v45, v20, v21, v22\n"
+                     "v_and_or_b32 v46, v20, v21, v22\n"
+                     "v_and_or_b32 v47, v20, v21, v22\n"
+                     "v_and_or_b32 v40, v20, v21, v22\n"
+                     "v_and_or_b32 v41, v20, v21, v22\n"
+                     "v_and_or_b32 v42, v20, v21, v22\n"
+                     "v_and_or_b32 v43, v20, v21, v22\n"
+                     "v_and_or_b32 v44, v20, v21, v22\n"
+                     "v_and_or_b32 v45, v20, v21, v22\n"
+                     "v_and_or_b32 v46, v20, v21, v22\n"
+                     "v_and_or_b32 v47, v20, v21, v22\n"
+                     "v_and_or_b32 v40, v20, v21, v22\n"
+                     "v_and_or_b32 v41, v20, v21, v22\n"
+                     "v_and_or_b32 v42, v20, v21, v22\n"
+                     "v_and_or_b32 v43, v20, v21, v22\n"
+                     "v_and_or_b32 v44, v20, v21, v22\n"
+                     "v_and_or_b32 v45, v20, v21, v22\n"
+                     "v_and_or_b32 v46, v20, v21, v22\n"
+                     "v_and_or_b32 v47, v20, v21, v22\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one5(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_or3_b32 v40, v20, v21, v22\n"
+                     "v_or3_b32 v41, v20, v21, v22\n"
+                     "v_or3_b32 v42, v20, v21, v22\n"
+                     "v_or3_b32 v43, v20, v21, v22\n"
+                     "v_or3_b32 v44, v20, v21, v22\n"
+                     "v_or3_b32 v45, v20, v21, v22\n"
+                     "v_or3_b32 v46, v20, v21, v22\n"
+                     "v_or3_b32 v47, v20, v21, v22\n"
+                     "v_or3_b32 v40, v20, v21, v22\n"
+                     "v_or3_b32 v41, v20, v21, v22\n"
+                     "v_or3_b32 v42, v20, v21, v22\n"
+                     "v_or3_b32 v43, v20, v21, v22\n"
+                     "v_or3_b32 v44, v20, v21, v22\n"
+                     "v_or3_b32 v45, v20, v21, v22\n"
+                     "v_or3_b32 v46, v20, v21, v22\n"
+                     "v_or3_b32 v47, v20, v21, v22\n"
+                     "v_or3_b32 v40, v20, v21, v22\n"
+                     "v_or3_b32 v41, v20, v21, v22\n"
+                     "v_or3_b32 v42, v20, v21, v22\n"
+                     "v_or3_b32 v43, v20, v21, v22\n"
+                     "v_or3_b32 v44, v20, v21, v22\n"
+                     "v_or3_b32 v45, v20, v21, v22\n"
+                     "v_or3_b32 v46, v20, v21, v22\n"
+                     "v_or3_b32 v47, v20, v21, v22\n"
+                     "v_or3_b32 v40, v20, v21, v22\n"
+                     "v_or3_b32 v41, v20, v21, v22\n"
+                     "v_or3_b32 v42, v20, v21, v22\n"
+                     "v_or3_b32 v43, v20, v21, v22\n"
+                     "v_or3_b32 v44, v20, v21, v22\n"
+                     "v_or3_b32 v45, v20, v21, v22\n"
+                     "v_or3_b32 v46, v20, v21, v22\n"
+                     "v_or3_b32 v47, v20, v21, v22\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one6(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_perm_b32 v40, v20, v21, v22\n"
+                     "v_perm_b32 v41, v20, v21, v22\n"
+                     "v_perm_b32 v42, v20, v21, v22\n"
+                     "v_perm_b32 v43, v20, v21, v22\n"
+                     "v_perm_b32 v44, v20, v21, v22\n"
+                     "v_perm_b32 v45, v20, v21, v22\n"
+                     "v_perm_b32 v46, v20, v21, v22\n"
+                     "v_perm_b32 v47, v20, v21, v22\n"
+                     "v_perm_b32 v40, v20, v21, v22\n"
+                     "v_perm_b32 v41, v20, v21, v22\n"
+                     "v_perm_b32 v42, v20, v21, v22\n"
+                     "v_perm_b32 v43, v20, v21, v22\n"
+                     "v_perm_b32 v44, v20, v21, v22\n"
+                     "v_perm_b32 v45, v20, v21, v22\n"
+                     "v_perm_b32 v46, v20, v21, v22\n"
+                     "v_perm_b32 v47, v20, v21, v22\n"
+                     "v_perm_b32 v40, v20, v21, v22\n"
+                     "v_perm_b32 v41, v20, v21, v22\n"
+                     "v_perm_b32 v42, v20, v21, v22\n"
+                     "v_perm_b32 v43, v20, v21, v22\n"
+                     "v_perm_b32 v44, v20, v21, v22\n"
+                     "v_perm_b32 v45, v20, v21, v22\n"
+                     "v_perm_b32 v46, v20, v21, v22\n"
+                     "v_perm_b32 v47, v20, v21, v22\n"
+                     "v_perm_b32 v40, v20, v21, v22\n"
+                     "v_perm_b32 v41, v20, v21, v22\n"
+                     "v_perm_b32 v42, v20, v21, v22\n"
+                     "v_perm_b32 v43, v20, v21, v22\n"
+                     "v_perm_b32 v44, v20, v21, v22\n"
+                     "v_perm_b32 v45, v20, v21, v22\n"
+                     "v_perm_b32 v46, v20, v21, v22\n"
+                     "v_perm_b32 v47, v20, v21, v22\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one7(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_alignbyte_b32 v40, v20, v21, 1\n"
+                     "v_alignbyte_b32 v41, v20, v21, 1\n"
+                     "v_alignbyte_b32 v42, v20, v21, 1\n"
+                     "v_alignbyte_b32 v43, v20, v21, 1\n"
+                     "v_alignbyte_b32 v44, v20, v21, 1\n"
+                     "v_alignbyte_b32 v45, v20, v21, 1\n"
+                     "v_alignbyte_b32 v46, v20, v21, 1\n"
+                     "v_alignbyte_b32 v47, v20, v21, 1\n"
+                     "v_alignbyte_b32 v40, v20, v21, 1\n"
+                     "v_alignbyte_b32 v41, v20, v21, 1\n"
+                     "v_alignbyte_b32 v42, v20, v21, 1\n"
+                     "v_alignbyte_b32 v43, v20, v21, 1\n"
+                     "v_alignbyte_b32 v44, v20, v21, 1\n"
+                     "v_alignbyte_b32 v45, v20, v21, 1\n"
+                     "v_alignbyte_b32 v46, v20, v21, 1\n"
+                     "v_alignbyte_b32 v47, v20, v21, 1\n"
+                     "v_alignbyte_b32 v40, v20, v21, 1\n"
+                     "v_alignbyte_b32 v41, v20, v21, 1\n"
+                     "v_alignbyte_b32 v42, v20, v21, 1\n"
+                     "v_alignbyte_b32 v43, v20, v21, 1\n"
+                     "v_alignbyte_b32 v44, v20, v21, 1\n"
+                     "v_alignbyte_b32 v45, v20, v21, 1\n"
+                     "v_alignbyte_b32 v46, v20, v21, 1\n"
+                     "v_alignbyte_b32 v47, v20, v21, 1\n"
+                     "v_alignbyte_b32 v40, v20, v21, 1\n"
+                     "v_alignbyte_b32 v41, v20, v21, 1\n"
+                     "v_alignbyte_b32 v42, v20, v21, 1\n"
+                     "v_alignbyte_b32 v43, v20, v21, 1\n"
+                     "v_alignbyte_b32 v44, v20, v21, 1\n"
+                     "v_alignbyte_b32 v45, v20, v21, 1\n"
+                     "v_alignbyte_b32 v46, v20, v21, 1\n"
+                     "v_alignbyte_b32 v47, v20, v21, 1\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one8(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_bfe_u32 v40, v20, 5, 13\n"
+                     "v_bfe_u32 v41, v20, 5, 13\n"
+                     "v_bfe_u32 v42, v20, 5, 13\n"
+                     "v_bfe_u32 v43, v20, 5, 13\n"
+                     "v_bfe_u32 v44, v20, 5, 13\n"
+                     "v_bfe_u32 v45, v20, 5, 13\n"
+                     "v_bfe_u32 v46, v20, 5, 13\n"
+                     "v_bfe_u32 v47, v20, 5, 13\n"
+                     "v_bfe_u32 v40, v20, 5, 13\n"
+                     "v_bfe_u32 v41, v20, 5, 13\n"
+                     "v_bfe_u32 v42, v20, 5, 13\n"
+                     "v_bfe_u32 v43, v20, 5, 13\n"
+                     "v_bfe_u32 v44, v20, 5, 13\n"
+                     "v_bfe_u32 v45, v20, 5, 13\n"
+                     "v_bfe_u32 v46, v20, 5, 13\n"
+                     "v_bfe_u32 v47, v20, 5, 13\n"
+                     "v_bfe_u32 v40, v20, 5, 13\n"
+                     "v_bfe_u32 v41, v20, 5, 13\n"
+                     "v_bfe_u32 v42, v20, 5, 13\n"
+                     "v_bfe_u32 v43, v20, 5, 13\n"
+                     "v_bfe_u32 v44, v20, 5, 13\n"
+                     "v_bfe_u32 v45, v20, 5, 13\n"
+                     "v_bfe_u32 v46, v20, 5, 13\n"
+                     "v_bfe_u32 v47, v20, 5, 13\n"
+                     "v_bfe_u32 v40, v20, 5, 13\n"
+                     "v_bfe_u32 v41, v20, 5, 13\n"
+                     "v_bfe_u32 v42, v20, 5, 13\n"
+                     "v_bfe_u32 v43, v20, 5, 13\n"
+                     "v_bfe_u32 v44, v20, 5, 13\n"
+                     "v_bfe_u32 v45, v20, 5, 13\n"
+                     "v_bfe_u32 v46, v20, 5, 13\n"
+                     "v_bfe_u32 v47, v20, 5, 13\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one9(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_bfi_b32 v40, v20, v21, v22\n"
+                     "v_bfi_b32 v41, v20, v21, v22\n"
+                     "v_bfi_b32 v42, v20, v21, v22\n"
+                     "v_bfi_b32 v43, v20, v21, v22\n"
+                     "v_bfi_b32 v44, v20, v21, v22\n"
+                     "v_bfi_b32 v45, v20, v21, v22\n"
+                     "v_bfi_b32 v46, v20, v21, v22\n"
+                     "v_bfi_b32 v47, v20, v21, v22\n"
+                     "v_bfi_b32 v40, v20, v21, v22\n"
+                     "v_bfi_b32 v41, v20, v21, v22\n"
+                     "v_bfi_b32 v42, v20, v21, v22\n"
+                     "v_bfi_b32 v43, v20, v21, v22\n"
+                     "v_bfi_b32 v44, v20, v21, v22\n"
+                     "v_bfi_b32 v45, v20, v21, v22\n"
+                     "v_bfi_b32 v46, v20, v21, v22\n"
+                     "v_bfi_b32 v47, v20, v21, v22\n"
+                     "v_bfi_b32 v40, v20, v21, v22\n"
+                     "v_bfi_b32 v41, v20, v21, v22\n"
+                     "v_bfi_b32 v42, v20, v21, v22\n"
+                     "v_bfi_b32 v43, v20, v21, v22\n"
+                     "v_bfi_b32 v44, v20, v21, v22\n"
+                     "v_bfi_b32 v45, v20, v21, v22\n"
+                     "v_bfi_b32 v46, v20, v21, v22\n"
+                     "v_bfi_b32 v47, v20, v21, v22\n"
+                     "v_bfi_b32 v40, v20, v21, v22\n"
+                     "v_bfi_b32 v41, v20, v21, v22\n"
+                     "v_bfi_b32 v42, v20, v21, v22\n"
+                     "v_bfi_b32 v43, v20, v21, v22\n"
+                     "v_bfi_b32 v44, v20, v21, v22\n"
+                     "v_bfi_b32 v45, v20, v21, v22\n"
+                     "v_bfi_b32 v46, v20, v21, v22\n"
+                     "v_bfi_b32 v47, v20, v21, v22\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one10(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_mov_b32 v40, v20\n"
+                     "v_mov_b32 v41, v20\n"
+                     "v_mov_b32 v42, v20\n"
+                     "v_mov_b32 v43, v20\n"
+                     "v_mov_b32 v44, v20\n"
+                     "v_mov_b32 v45, v20\n"
+                     "v_mov_b32 v46, v20\n"
+                     "v_mov_b32 v47, v20\n"
+                     "v_mov_b32 v40, v20\n"
+                     "v_mov_b32 v41, v20\n"
+                     "v_mov_b32 v42, v20\n"
+                     "v_mov_b32 v43, v20\n"
+                     "v_mov_b32 v44, v20\n"
+                     "v_mov_b32 v45, v20\n"
+                     "v_mov_b32 v46, v20\n"
+                     "v_mov_b32 v47, v20\n"
+                     "v_mov_b32 v40, v20\n"
+                     "v_mov_b32 v41, v20\n"
+                     "v_mov_b32 v42, v20\n"
+                     "v_mov_b32 v43, v20\n"
+                     "v_mov_b32 v44, v20\n"
+                     "v_mov_b32 v45, v20\n"
+                     "v_mov_b32 v46, v20\n"
+                     "v_mov_b32 v47, v20\n"
+                     "v_mov_b32 v40, v20\n"
+                     "v_mov_b32 v41, v20\n"
+                     "v_mov_b32 v42, v20\n"
+                     "v_mov_b32 v43, v20\n"
+                     "v_mov_b32 v44, v20\n"
+                     "v_mov_b32 v45, v20\n"
+                     "v_mov_b32 v46, v20\n"
+                     "v_mov_b32 v47, v20\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+__global__ __launch_bounds__(256) void k_one11(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_add_u32 v40, v20, v21\n"
+                     "v_add_u32 v41, v20, v21\n"
+                     "v_add_u32 v42, v20, v21\n"
+                     "v_add_u32 v43, v20, v21\n"
+                     "v_add_u32 v44, v20, v21\n"
+                     "v_add_u32 v45, v20, v21\n"
+                     "v_add_u32 v46, v20, v21\n"
+                     "v_add_u32 v47, v20, v21\n"
+                     "v_add_u32 v40, v20, v21\n"
+                     "v_add_u32 v41, v20, v21\n"
+                     "v_add_u32 v42, v20, v21\n"
+                     "v_add_u32 v43, v20, v21\n"
+                     "v_add_u32 v44, v20, v21\n"
+                     "v_add_u32 v45, v20, v21\n"
+                     "v_add_u32 v46, v20, v21\n"
+                     "v_add_u32 v47, v20, v21\n"
+                     "v_add_u32 v40, v20, v21\n"
+                     "v_add_u32 v41, v20, v21\n"
+                     "v_add_u32 v42, v20, v21\n"
+                     "v_add_u32 v43, v20, v21\n"
+                     "v_add_u32 v44, v20, v21\n"
+                     "v_add_u32 v45, v20, v21\n"
+                     "v_add_u32 v46, v20, v21\n"
+                     "v_add_u32 v47, v20, v21\n"
+                     "v_add_u32 v40, v20, v21\n"
+                     "v_add_u32 v41, v20, v21\n"
+                     "v_add_u32 v42, v20, v21\n"
+                     "v_add_u32 v43, v20, v21\n"
+                     "v_add_u32 v44, v20, v21\n"
+                     "v_add_u32 v45, v20, v21\n"
+                     "v_add_u32 v46, v20, v21\n"
+                     "v_add_u32 v47, v20, v21\n"
+                     : "+v"(acc) : : CLOB);
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+static void run_kernel(const char *name, void (*kern)(uint32_t *, int)) {
+    const int blocks = 256 * 8, iters = 4000;
+    uint32_t *d;
+    (void)hipMalloc(&d, blocks * 256 * 4);
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0);
+    (void)hipEventCreate(&e1);
+    kern<<<blocks, 256>>>(d, 10);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kern<<<blocks, 256>>>(d, iters);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("%-56s %8.2f T lane-ops/s\n", name, (double)blocks * 256 * iters * 32 / ms / 1e9);
+    (void)hipFree(d);
+}
+
 template <int V>
 static void run(const char *name) {
     const int blocks = 256 * 8, iters = 4000;
@@ -628,6 +1104,18 @@ int main() {
         (void)hipEventElapsedTime(&ms, e0, e1);
         printf("%-56s %8.2f T lane-ops/s\n", "bitop3, different conflict-free sources each time", (double)blocks * 256 * iters * 32 / ms / 1e9);
     }
+    run_kernel("v_lshlrev_b32 (shift by constant)", k_one0);
+    run_kernel("v_lshrrev_b32 (shift by constant)", k_one1);
+    run_kernel("v_lshl_or_b32", k_one2);
+    run_kernel("v_lshl_add_u32", k_one3);
+    run_kernel("v_and_or_b32", k_one4);
+    run_kernel("v_or3_b32", k_one5);
+    run_kernel("v_perm_b32", k_one6);
+    run_kernel("v_alignbyte_b32", k_one7);
+    run_kernel("v_bfe_u32", k_one8);
+    run_kernel("v_bfi_b32", k_one9);
+    run_kernel("v_mov_b32", k_one10);
+    run_kernel("v_add_u32", k_one11);
     for (int blocks : {256, 512, 1024, 2048}) {  // occupancy: 1, 2, 4, 8 waves per SIMD
         const int iters = 4000;
         uint32_t *d;
