@@ -32,7 +32,7 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
 # 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (max clock) int32 VALU lane-ops/s
 VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9
-KECCAK_OPS = 4170.0  # VALU instructions per permutation in k_keccak_* (2746 v_bitop3 + 1342 v_alignbit + misc)
+KECCAK_OPS = 4020.0  # VALU instructions per permutation in k_keccak_* (2756 v_bitop3 + 1204 v_alignbit + misc)
 
 
 def cpu_baseline(nv, program, num_lookups, sample_cols):
@@ -66,14 +66,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=6, help="independent traces proven concurrently per GPU per step "
-                    "(one proof alone is bound by its sequential host transcript; 4 lanes saturate the GPU, 6 leave "
-                    "margin for slower all-core host clocks)")
+    ap.add_argument("--batch", type=int, default=4, help="independent traces proven concurrently per GPU per step "
+                    "(one proof alone is bound by its sequential host transcript; 4 lanes saturate the GPU; 6 give +2 %% "
+                    "but the MLE kernel then waits for CU slots behind other proofs' Keccak workgroups, which distorts "
+                    "the per-launch roofline figure)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
                     "the headline is measured with the dense, data-independent build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-cols", type=int, default=2)
+    ap.add_argument("--cpu-sample-cols", type=int, default=12, help="columns of the CPU baseline sample (~1.1 s each)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

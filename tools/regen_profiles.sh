@@ -7,6 +7,7 @@ rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/fin_
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/fin_pmc_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --batch 1 --no-cpu-baseline > gpurun_out/fin_pmc_WRITE_SIZE.log 2>&1
 python bench.py > gpurun_out/fin_bench.json 2> gpurun_out/fin_bench.err
 python bench.py --batch 1 --no-cpu-baseline > gpurun_out/fin_bench_b1.json 2>> gpurun_out/fin_bench.err
+python bench.py --batch 6 --no-cpu-baseline > gpurun_out/fin_bench_b6.json 2>> gpurun_out/fin_bench.err
 python bench.py --dedup --batch 8 --no-cpu-baseline > gpurun_out/fin_bench_dedup8.json 2>> gpurun_out/fin_bench.err
 python tools/measure_extra.py > gpurun_out/fin_extra.json 2>> gpurun_out/fin_bench.err
 hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc -I include tools/merkle_rate.hip -o /tmp/merkle_rate 2>/dev/null && /tmp/merkle_rate > gpurun_out/fin_merkle_rate.txt
