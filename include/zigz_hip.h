@@ -220,9 +220,10 @@ typedef struct zigz_kernel_stats {
     double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch, or all binds of the last sumcheck */
     uint64_t bind_launches;
     uint64_t keccak_permutations;
-    /* the bulk MLE-bind launches of the last eval / sumcheck / bind call, each timed with its own HIP event pair:
-     * total device time, launch count, algorithmic bytes.  Kernel k_radix_fold (one pass binding v-10 variables,
-     * 4 B read per element) for evals of tables >= 2^14, k_bind_vec (6 B per table element) otherwise. */
+    /* the bulk MLE-bind launches of the last eval / sumcheck / bind call, each timed on its own: total device time,
+     * launch count, algorithmic bytes.  Kernel k_radix_fold (one pass binding v-10 variables, 4 B read per element;
+     * timed with the dispatch's own begin/end timestamps) for evals of tables >= 2^14, k_bind_vec (6 B per table
+     * element; HIP event pair around the launch) otherwise. */
     double bind_vec_us;
     uint64_t bind_vec_launches;
     uint64_t bind_vec_bytes;

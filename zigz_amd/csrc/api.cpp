@@ -37,7 +37,7 @@ struct zigz_ctx {
     bool merkle_dedup;        // run-aware Merkle build (uniform 256-leaf blocks are chained, not hashed densely)
     unsigned long long *d_dedup_count;
     hipEvent_t ev[6];
-    hipEvent_t pool[2 * 64];  // per-launch event pairs for k_bind_vec timing
+    hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
     int pool_used;
     uint64_t pool_bytes;
     zigz_kernel_stats stats;
