@@ -213,3 +213,29 @@ def test_prove_with_merkle_dedup_is_byte_identical(ctx):
         ctx.set_option("merkle_dedup", 0)
     assert a == b and st["merkle_uniform_blocks"] > st["merkle_blocks"] // 2
     assert host.verify(b, prog) == "Accept"
+
+
+def _run_config(config, timeout):
+    """tests/run_config.py in its own process (frees the 10-45 GB of HBM it uses when it exits)."""
+    import json
+    import subprocess
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    r = subprocess.run([sys.executable, os.path.join(here, "run_config.py"), "--config", str(config), "--check-cols", "1"],
+                       capture_output=True, text=True, timeout=timeout)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return json.loads(r.stdout.strip().splitlines()[-1])
+
+
+def test_config4_mixed_rv64im_2_22_full_size():
+    """BASELINE config 4 at full size (RV64IM mixed loop with MUL/DIV/REM/LD/SD, 2^22 trace) on one GPU: both
+    verifiers accept, exact proof size, and for a sampled column the oracle re-derives root, opened leaf and value."""
+    out = _run_config(4, 600)
+    assert out["nv"] == 22 and out["checked_columns_vs_oracle"] == 1
+    assert out["proof_bytes"] == O.proof_size(22, 0, 0, out["lookups"])
+
+
+@pytest.mark.skipif(os.environ.get("ZIGZ_TEST_FULL") != "1", reason="2^24 run (45 GB HBM, ~2 min): set ZIGZ_TEST_FULL=1")
+def test_config5_fibonacci_2_24_full_size():
+    out = _run_config(5, 1200)
+    assert out["nv"] == 24 and out["checked_columns_vs_oracle"] == 1
