@@ -235,7 +235,8 @@ def test_config4_mixed_rv64im_2_22_full_size():
     assert out["proof_bytes"] == O.proof_size(22, 0, 0, out["lookups"])
 
 
-@pytest.mark.skipif(os.environ.get("ZIGZ_TEST_FULL") != "1", reason="2^24 run (45 GB HBM, ~2 min): set ZIGZ_TEST_FULL=1")
+@pytest.mark.skipif(os.environ.get("ZIGZ_TEST_SKIP_FULL") == "1", reason="2^24 run (45 GB HBM, 12 GB host, ~25 s) skipped by request")
 def test_config5_fibonacci_2_24_full_size():
+    """BASELINE config 5 at full size (fibonacci guest semantics, 2^24 trace, 403 MB proof), same checks as config 4."""
     out = _run_config(5, 1200)
     assert out["nv"] == 24 and out["checked_columns_vs_oracle"] == 1
