@@ -16,10 +16,10 @@ static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
 
-static size_t log2_int_ceil(size_t n) {  // std.math.log2_int_ceil
+static size_t log2_int_ceil(size_t n) {  // std.math.log2_int_ceil; n may come from an untrusted proof header
     size_t l = 0;
-    while (((size_t)1 << l) < n) l++;
-    return l;
+    while (l < 63 && ((size_t)1 << l) < n) l++;
+    return (l == 63 && ((size_t)1 << 63) < n) ? 64 : l;
 }
 
 // ---------------------------------------------------------------- witness (witness.zig:29-270)
