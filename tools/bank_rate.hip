@@ -1642,6 +1642,189 @@ __global__ __launch_bounds__(256) void k_runs120(uint32_t *out, int iters) {
     out[blockIdx.x * 256 + threadIdx.x] = acc;
 }
 
+// runs of 12 bitop3 + 5 alignbit with operands spread over 64 source and 16 destination registers (as in the real kernel)
+__global__ __launch_bounds__(256) void k_spread(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_bitop3_b32 v85, v61, v39, v70 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v29, v32, v66 bitop3:0x96\n"
+                     "v_bitop3_b32 v91, v75, v73, v28 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v73, v38, v35 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v43, v33, v44 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v60, v79, v78 bitop3:0x96\n"
+                     "v_bitop3_b32 v97, v56, v29, v35 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v29, v60, v63 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v83, v78, v28 bitop3:0x96\n"
+                     "v_bitop3_b32 v89, v22, v79, v65 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v82, v43, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v20, v38, v73 bitop3:0x96\n"
+                     "v_alignbit_b32 v88, v60, v60, 13\n"
+                     "v_alignbit_b32 v98, v26, v26, 13\n"
+                     "v_alignbit_b32 v96, v70, v70, 13\n"
+                     "v_alignbit_b32 v96, v71, v71, 13\n"
+                     "v_alignbit_b32 v99, v33, v33, 13\n"
+                     "v_bitop3_b32 v85, v40, v34, v63 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v33, v20, v39 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v66, v23, v29 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v58, v31, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v50, v71, v49 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v77, v64, v66 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v80, v45, v63 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v30, v35, v69 bitop3:0x96\n"
+                     "v_bitop3_b32 v94, v81, v42, v75 bitop3:0x96\n"
+                     "v_bitop3_b32 v89, v71, v30, v40 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v79, v38, v80 bitop3:0x96\n"
+                     "v_bitop3_b32 v84, v39, v36, v22 bitop3:0x96\n"
+                     "v_alignbit_b32 v88, v33, v33, 13\n"
+                     "v_alignbit_b32 v90, v75, v75, 13\n"
+                     "v_alignbit_b32 v84, v47, v47, 13\n"
+                     "v_alignbit_b32 v90, v52, v52, 13\n"
+                     "v_alignbit_b32 v91, v57, v57, 13\n"
+                     "v_bitop3_b32 v98, v36, v27, v65 bitop3:0x96\n"
+                     "v_bitop3_b32 v84, v73, v36, v39 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v55, v25, v32 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v29, v47, v58 bitop3:0x96\n"
+                     "v_bitop3_b32 v91, v52, v37, v79 bitop3:0x96\n"
+                     "v_bitop3_b32 v84, v63, v78, v76 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v28, v34, v49 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v25, v43, v54 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v74, v53, v71 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v22, v31, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v94, v35, v78, v21 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v73, v54, v36 bitop3:0x96\n"
+                     "v_alignbit_b32 v87, v50, v50, 13\n"
+                     "v_alignbit_b32 v92, v40, v40, 13\n"
+                     "v_alignbit_b32 v89, v26, v26, 13\n"
+                     "v_alignbit_b32 v93, v45, v45, 13\n"
+                     "v_alignbit_b32 v90, v59, v59, 13\n"
+                     "v_bitop3_b32 v88, v71, v64, v26 bitop3:0x96\n"
+                     "v_bitop3_b32 v92, v78, v43, v40 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v30, v80, v55 bitop3:0x96\n"
+                     "v_bitop3_b32 v96, v53, v31, v38 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v30, v23, v25 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v66, v33, v68 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v82, v53, v20 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v78, v83, v68 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v32, v47, v82 bitop3:0x96\n"
+                     "v_bitop3_b32 v99, v45, v59, v30 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v31, v38, v53 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v36, v55, v34 bitop3:0x96\n"
+                     "v_alignbit_b32 v99, v49, v49, 13\n"
+                     "v_alignbit_b32 v96, v82, v82, 13\n"
+                     "v_alignbit_b32 v89, v23, v23, 13\n"
+                     "v_alignbit_b32 v99, v20, v20, 13\n"
+                     "v_alignbit_b32 v96, v77, v77, 13\n"
+                     "v_bitop3_b32 v94, v35, v62, v20 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v26, v55, v33 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v54, v75, v60 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v26, v72, v77 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v73, v63, v56 bitop3:0x96\n"
+                     "v_bitop3_b32 v91, v52, v53, v71 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v35, v41, v40 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v46, v83, v48 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v37, v44, v51 bitop3:0x96\n"
+                     "v_bitop3_b32 v92, v60, v50, v67 bitop3:0x96\n"
+                     "v_bitop3_b32 v96, v45, v22, v72 bitop3:0x96\n"
+                     "v_bitop3_b32 v96, v54, v51, v69 bitop3:0x96\n"
+                     "v_alignbit_b32 v97, v77, v77, 13\n"
+                     "v_alignbit_b32 v84, v59, v59, 13\n"
+                     "v_alignbit_b32 v85, v36, v36, 13\n"
+                     "v_alignbit_b32 v99, v74, v74, 13\n"
+                     "v_alignbit_b32 v84, v82, v82, 13\n"
+                     "v_bitop3_b32 v98, v29, v70, v79 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v51, v33, v48 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v39, v33, v78 bitop3:0x96\n"
+                     "v_bitop3_b32 v88, v49, v24, v58 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v52, v75, v34 bitop3:0x96\n"
+                     "v_bitop3_b32 v96, v29, v58, v44 bitop3:0x96\n"
+                     "v_bitop3_b32 v84, v80, v50, v51 bitop3:0x96\n"
+                     "v_bitop3_b32 v97, v22, v44, v83 bitop3:0x96\n"
+                     "v_bitop3_b32 v97, v30, v52, v49 bitop3:0x96\n"
+                     "v_bitop3_b32 v95, v24, v63, v73 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v70, v45, v20 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v28, v46, v83 bitop3:0x96\n"
+                     "v_alignbit_b32 v90, v59, v59, 13\n"
+                     "v_alignbit_b32 v98, v49, v49, 13\n"
+                     "v_alignbit_b32 v92, v48, v48, 13\n"
+                     "v_alignbit_b32 v87, v57, v57, 13\n"
+                     "v_alignbit_b32 v89, v83, v83, 13\n"
+                     "v_bitop3_b32 v85, v48, v82, v73 bitop3:0x96\n"
+                     "v_bitop3_b32 v89, v73, v26, v27 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v70, v77, v60 bitop3:0x96\n"
+                     "v_bitop3_b32 v89, v67, v62, v76 bitop3:0x96\n"
+                     "v_bitop3_b32 v92, v33, v20, v30 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v30, v64, v73 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v46, v68, v65 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v80, v45, v67 bitop3:0x96\n"
+                     "v_bitop3_b32 v99, v44, v61, v66 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v71, v25, v68 bitop3:0x96\n"
+                     "v_bitop3_b32 v84, v60, v55, v58 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v28, v23, v49 bitop3:0x96\n"
+                     "v_alignbit_b32 v98, v80, v80, 13\n"
+                     "v_alignbit_b32 v92, v69, v69, 13\n"
+                     "v_alignbit_b32 v99, v75, v75, 13\n"
+                     "v_alignbit_b32 v99, v36, v36, 13\n"
+                     "v_alignbit_b32 v84, v43, v43, 13\n"
+                     "v_bitop3_b32 v95, v61, v60, v78 bitop3:0x96\n"
+                     "v_bitop3_b32 v87, v61, v40, v74 bitop3:0x96\n"
+                     "v_bitop3_b32 v99, v46, v32, v73 bitop3:0x96\n"
+                     "v_bitop3_b32 v93, v50, v35, v57 bitop3:0x96\n"
+                     "v_bitop3_b32 v98, v51, v49, v32 bitop3:0x96\n"
+                     "v_bitop3_b32 v90, v49, v35, v26 bitop3:0x96\n"
+                     "v_bitop3_b32 v89, v44, v29, v67 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v33, v64, v47 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v25, v46, v52 bitop3:0x96\n"
+                     "v_bitop3_b32 v85, v59, v29, v46 bitop3:0x96\n"
+                     "v_bitop3_b32 v97, v83, v81, v28 bitop3:0x96\n"
+                     "v_bitop3_b32 v86, v32, v70, v39 bitop3:0x96\n"
+                     "v_alignbit_b32 v96, v40, v40, 13\n"
+                     "v_alignbit_b32 v97, v54, v54, 13\n"
+                     "v_alignbit_b32 v93, v56, v56, 13\n"
+                     "v_alignbit_b32 v85, v73, v73, 13\n"
+                     "v_alignbit_b32 v95, v59, v59, 13\n"
+                     : "+v"(acc) : : "v20", "v21", "v22", "v23", "v24", "v25", "v26", "v27", "v28", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37", "v38", "v39", "v40", "v41", "v42", "v43", "v44", "v45", "v46", "v47", "v48", "v49", "v50", "v51", "v52", "v53", "v54", "v55", "v56", "v57", "v58", "v59", "v60", "v61", "v62", "v63", "v64", "v65", "v66", "v67", "v68", "v69", "v70", "v71", "v72", "v73", "v74", "v75", "v76", "v77", "v78", "v79", "v80", "v81", "v82", "v83", "v84", "v85", "v86", "v87", "v88", "v89", "v90", "v91", "v92", "v93", "v94", "v95", "v96", "v97", "v98", "v99");
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
+__global__ __launch_bounds__(256) void k_aonly(uint32_t *out, int iters) {
+    uint32_t acc = threadIdx.x;
+    for (int it = 0; it < iters; it++)
+        asm volatile("v_alignbit_b32 v40, v20, v20, 13\n"
+                     "v_alignbit_b32 v41, v23, v23, 13\n"
+                     "v_alignbit_b32 v42, v26, v26, 13\n"
+                     "v_alignbit_b32 v43, v29, v29, 13\n"
+                     "v_alignbit_b32 v44, v32, v32, 13\n"
+                     "v_alignbit_b32 v45, v35, v35, 13\n"
+                     "v_alignbit_b32 v46, v22, v22, 13\n"
+                     "v_alignbit_b32 v47, v25, v25, 13\n"
+                     "v_alignbit_b32 v40, v28, v28, 13\n"
+                     "v_alignbit_b32 v41, v31, v31, 13\n"
+                     "v_alignbit_b32 v42, v34, v34, 13\n"
+                     "v_alignbit_b32 v43, v21, v21, 13\n"
+                     "v_alignbit_b32 v44, v24, v24, 13\n"
+                     "v_alignbit_b32 v45, v27, v27, 13\n"
+                     "v_alignbit_b32 v46, v30, v30, 13\n"
+                     "v_alignbit_b32 v47, v33, v33, 13\n"
+                     "v_alignbit_b32 v40, v20, v20, 13\n"
+                     "v_alignbit_b32 v41, v23, v23, 13\n"
+                     "v_alignbit_b32 v42, v26, v26, 13\n"
+                     "v_alignbit_b32 v43, v29, v29, 13\n"
+                     "v_alignbit_b32 v44, v32, v32, 13\n"
+                     "v_alignbit_b32 v45, v35, v35, 13\n"
+                     "v_alignbit_b32 v46, v22, v22, 13\n"
+                     "v_alignbit_b32 v47, v25, v25, 13\n"
+                     "v_alignbit_b32 v40, v28, v28, 13\n"
+                     "v_alignbit_b32 v41, v31, v31, 13\n"
+                     "v_alignbit_b32 v42, v34, v34, 13\n"
+                     "v_alignbit_b32 v43, v21, v21, 13\n"
+                     "v_alignbit_b32 v44, v24, v24, 13\n"
+                     "v_alignbit_b32 v45, v27, v27, 13\n"
+                     "v_alignbit_b32 v46, v30, v30, 13\n"
+                     "v_alignbit_b32 v47, v33, v33, 13\n"
+                     : "+v"(acc) : : CLOB, "v23", "v25", "v26", "v27", "v29", "v30", "v31", "v32", "v33", "v34", "v35", "v36", "v37");
+    out[blockIdx.x * 256 + threadIdx.x] = acc;
+}
+
 static void run_kernel_n(const char *name, void (*kern)(uint32_t *, int), int per_iter) {
     const int blocks = 256 * 8, iters = 128000 / per_iter;
     uint32_t *d;
@@ -1754,24 +1937,33 @@ int main() {
     run_kernel_n("runs of 24 bitop3 then 10 alignbit", k_runs24, 34);
     run_kernel_n("runs of 48 bitop3 then 20 alignbit", k_runs48, 68);
     run_kernel_n("runs of 120 bitop3 then 52 alignbit", k_runs120, 172);
-    for (int blocks : {256, 512, 1024, 2048}) {  // occupancy: 1, 2, 4, 8 waves per SIMD
-        const int iters = 4000;
+    run_kernel_n("runs of 12 bitop3 + 5 alignbit, 80 registers in use", k_spread, 136);
+    for (int w : {1, 2, 3, 4, 5, 6, 7, 8}) {  // resident waves per SIMD (256-thread workgroups: one wave per SIMD each)
+        const int blocks = 256 * w;
         uint32_t *d;
         (void)hipMalloc(&d, blocks * 256 * 4);
         hipEvent_t e0, e1;
         (void)hipEventCreate(&e0);
         (void)hipEventCreate(&e1);
-        for (int which = 0; which < 2; which++) {
-            if (which == 0) k_vary<<<blocks, 256>>>(d, 10); else k_dep<<<blocks, 256>>>(d, 10);
+        double rate[3];
+        for (int which = 0; which < 3; which++) {
+            const int per = which == 2 ? 17 : 32, iters = 128000 / per;
+            auto launch = [&](int it) {
+                if (which == 0) k_vary<<<blocks, 256>>>(d, it);
+                else if (which == 1) k_aonly<<<blocks, 256>>>(d, it);
+                else k_runs12<<<blocks, 256>>>(d, it);
+            };
+            launch(10);
             (void)hipDeviceSynchronize();
             (void)hipEventRecord(e0);
-            if (which == 0) k_vary<<<blocks, 256>>>(d, iters); else k_dep<<<blocks, 256>>>(d, iters);
+            launch(iters);
             (void)hipEventRecord(e1);
             (void)hipEventSynchronize(e1);
             float ms;
             (void)hipEventElapsedTime(&ms, e0, e1);
-            printf("%d waves/SIMD, bitop3 %-34s %8.2f T lane-ops/s\n", blocks / 256, which == 0 ? "independent" : "reading results 8-11 instrs back", (double)blocks * 256 * iters * 32 / ms / 1e9);
+            rate[which] = (double)blocks * 256 * iters * per / ms / 1e9;
         }
+        printf("%d waves/SIMD: bitop3 %6.2f   alignbit %6.2f   runs of 12 bitop3 + 5 alignbit %6.2f  T lane-ops/s\n", w, rate[0], rate[1], rate[2]);
         (void)hipFree(d);
     }
     {   // two single-class streams sharing every SIMD

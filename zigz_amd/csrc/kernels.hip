@@ -455,6 +455,13 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
 
 // HPT hashes per thread (strided by the workgroup size so loads/stores stay coalesced): amortises wave launch
 // and set-up over several ~4.2 k-instruction permutations.
+// occupancy experiments (tools/merkle_rate.hip): unused dynamic LDS per workgroup caps the workgroups per CU
+#ifndef ZK_LEAVES_DYN_LDS
+#define ZK_LEAVES_DYN_LDS 0
+#endif
+#ifndef ZK_LEVEL_DYN_LDS
+#define ZK_LEVEL_DYN_LDS 0
+#endif
 #ifndef ZK_HPT
 #define ZK_HPT 4
 #endif
@@ -650,7 +657,7 @@ void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                           size_t tree_stride_nodes, size_t ncols, hipStream_t s) {
     dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_keccak_leaves, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+    hipLaunchKernelGGL(k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
                        tree_stride_nodes);
 }
 
@@ -659,10 +666,10 @@ void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_of
     // several hashes per thread only while that still leaves >= 16 workgroups per CU (small levels need the waves)
     if (n_out * ncols >= (size_t)TPB * HPT * 4096) {
         dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-        hipLaunchKernelGGL(k_keccak_level<HPT>, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+        hipLaunchKernelGGL(k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
     } else {
         dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
-        hipLaunchKernelGGL(k_keccak_level<1>, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+        hipLaunchKernelGGL(k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
     }
 }
 
