@@ -70,6 +70,11 @@ def main():
                     "(one proof alone is bound by its sequential host transcript; 4 lanes saturate the GPU; 6 give +2 %% "
                     "but the MLE kernel then waits for CU slots behind other proofs' Keccak workgroups, which distorts "
                     "the per-launch roofline figure)")
+    ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
+                    help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
+                    "scaling.  shard: ONE proof per step, its 43 columns sharded over the GPUs (two all-gathers of 43 x "
+                    "32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the sequential host transcript "
+                    "that every rank replays (DESIGN.md s7)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
                     "the headline is measured with the dense, data-independent build")
@@ -104,7 +109,8 @@ def main():
 
     nv = args.nv
     N = 1 << nv
-    B = max(1, args.batch)
+    shard = args.mode == "shard"
+    B = 1 if shard else max(1, args.batch)
 
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
         def __init__(self, k):
@@ -112,7 +118,7 @@ def main():
             if args.dedup:
                 self.ctx.set_option("merkle_dedup", 1)
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
-            self.prog = programs.add_xor_loop((N - 3) // 4 - (rank * B + k))
+            self.prog = programs.add_xor_loop((N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
             self.trace = host.Trace(self.prog, 0x1000, None, 2 * N)  # [1/6] VM execution: outside the timed region
             assert self.trace.num_vars == nv, (self.trace.num_vars, nv)
             self.d_cols = self.ctx.dev_alloc(43 * N * 4)
@@ -121,9 +127,13 @@ def main():
             self.proof = None
 
         def prove(self):
-            self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
+            if shard and dist is not None:
+                self.proof = self.trace.prove_sharded(self.ctx, self.d_cols, N, dist, allgather_hook)
+            else:
+                self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
 
+    allgather_hook = host.make_allgather(dist) if (shard and dist is not None) else None
     lanes = [Lane(k) for k in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
 
@@ -171,7 +181,7 @@ def main():
         dt = float(t.item())
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
-        total_steps = float(s.item())
+        total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
     else:
         total_steps = local_steps
 
@@ -192,7 +202,7 @@ def main():
             "unit": "trace steps/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
             "config": {"workload": "synthetic RV64I ADD/XOR loop, 2^%d trace, 43 witness columns resident in HBM; full "
                                    "Prover.prove hot path incl. Fiat-Shamir transcript and ZIGZ v1 serialisation; "
@@ -200,7 +210,8 @@ def main():
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
                        "merkle_build": "run-aware (merkle_dedup)" if args.dedup else "dense",
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
-                       "parallelism": "independent traces: %d GPU x %d concurrent proofs" % (world, B)},
+                       "parallelism": ("one proof per step, 43 columns sharded over %d GPU(s)" % world) if shard else
+                                      "independent traces: %d GPU x %d concurrent proofs" % (world, B)},
             "roofline": {"kernel": "k_radix_fold (MLE bind of the top v-10 variables of all 43 columns in one pass: the bulk "
                                    "of the 43 evals inside the timed region; 4 B read per element + partial sums)",
                          "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -54,6 +54,18 @@ int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_col
 int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int want_bytes,
                       uint8_t **proof_out, size_t *proof_len);
 
+/* One proof over `world` GPUs, sharded by column: every rank calls this with the SAME trace and its own
+ * context / resident copy of the 43 columns; rank r builds, commits and opens only its contiguous block of columns
+ * (43 over 8 -> 6,6,6,5,5,5,5,5).  The two exchanges of Prover.generateCommitments (prover.zig:366-467) -- 43 roots
+ * before the transcript absorbs them, 43 openings after -- go through `allgather`: every rank contributes `bytes` from
+ * `send`; `recv` gets world*bytes in rank order; return 0 on success (bind it to RCCL, MPI or torch.distributed).
+ * Transcripts run in lockstep, so every rank returns the same complete proof, byte-identical to the unsharded one, in
+ * a thread-local buffer the caller BORROWS (valid until the next prove on this thread; do not free). */
+typedef int (*zigzh_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+int zigzh_prove_trace_sharded(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int rank,
+                              int world, zigzh_allgather_fn allgather, void *user, uint8_t **proof_out,
+                              size_t *proof_len);
+
 /* VMState.init + run(max_steps)   src/vm/state.zig:72-93,172-184 (VM known-answer tests) */
 int zigzh_vm_run(const uint8_t *program, size_t program_len, uint64_t entry_pc, size_t max_steps,
                  uint64_t final_regs[32], uint64_t *final_pc, size_t *steps);

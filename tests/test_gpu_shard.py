@@ -43,8 +43,20 @@ def _worker(rank, world, port, q):
             sib, dirs, leaf = t.open(idx)
             opens.append((idx, sib.tobytes().hex(), dirs.tobytes().hex(), int(leaf)))
         t.close()
+        # one whole proof, sharded by column through the C++ host mirror (zigzh_prove_trace_sharded)
+        import hashlib
+        import programs
+        from zigz_amd import host
+        prog, inp = programs.fibonacci(700)
+        tr = host.Trace(prog, 0x1000, None, 1 << 14, inp)
+        N = 1 << tr.num_vars
+        d = ctx.dev_alloc(43 * N * 4)
+        tr.witness_to_device(ctx, d, N)
+        sharded = tr.prove_sharded(ctx, d, N, dist).tobytes()
+        ctx.dev_free(d)
         q.put((rank, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()},
-               dict(rounds=r.tolist(), point=p.tolist(), fe=fe), dict(root=t.root.hex(), height=t.height, opens=opens)))
+               dict(rounds=r.tolist(), point=p.tolist(), fe=fe), dict(root=t.root.hex(), height=t.height, opens=opens),
+               dict(sha3=hashlib.sha3_256(sharded).hexdigest(), n=len(sharded), nv=tr.num_vars)))
     finally:
         ctx.close()
         dist.destroy_process_group()
@@ -69,7 +81,12 @@ def test_sharded_paths_world2_on_gpu():
     r, p, fe = O.sumcheck_prove(P, table)
     vals = O.splitmix64_field(199, 1 << 14)
     mroot, mheight = O.merkle_build(vals)
-    for rank, got, sc, mk in outs:
+    import hashlib
+    import programs
+    prog, inp = programs.fibonacci(700)
+    oproof, _ = O.prove(P, prog, 0x1000, None, 1 << 14, inp)
+    for rank, got, sc, mk, pr in outs:
+        assert pr["nv"] >= 11 and pr["n"] == len(oproof) and pr["sha3"] == hashlib.sha3_256(oproof).hexdigest(), rank
         assert mk["root"] == mroot.hex() and mk["height"] == mheight
         for idx, sib, dirs, leaf in mk["opens"]:
             esib, edirs, eleaf = O.merkle_open(vals, idx)

@@ -179,6 +179,28 @@ extern "C" int zigzh_reserialize(const uint8_t *proof, size_t proof_len, uint8_t
     });
 }
 
+extern "C" int zigzh_prove_trace_sharded(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int rank,
+                                         int world, zigzh_allgather_fn allgather, void *user, uint8_t **proof_out,
+                                         size_t *proof_len) {
+    return guard([&] {
+        if (!t || !ctx || !d_cols || !proof_out || !proof_len) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "null argument");
+        if (t->trace.stepCount() == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+        Prover prover(ctx, 0);
+        ShardSpec sp;
+        sp.rank = rank;
+        sp.world = world;
+        sp.allgather = allgather;
+        sp.user = user;
+        prover.setShard(sp);
+        const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
+        // serialisation overlapped with the transcript, into the thread-local buffer the caller borrows
+        prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
+        memcpy(g_timings, prover.timings, sizeof(g_timings));
+        *proof_out = g_proof.data();
+        *proof_len = g_proof.size();
+    });
+}
+
 extern "C" int zigzh_vm_run(const uint8_t *program, size_t program_len, uint64_t entry_pc, size_t max_steps,
                             uint64_t final_regs[32], uint64_t *final_pc, size_t *steps) {
     std::unique_ptr<VMState> vm;

@@ -110,9 +110,31 @@ void Prover::generateLassoProofs(Proof &proof, size_t num_lookups) {  // :292-36
 
 void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) {  // :366-467
     const size_t NC = ZIGZ_NUM_COLUMNS;
+    const int world = shard_.world > 1 ? shard_.world : 1;
+    size_t c0 = 0, c1 = NC;
+    if (world > 1) columnBlock(NC, world, shard_.rank, c0, c1);  // the job holds this rank's columns [c0, c1)
+    const size_t nloc = c1 - c0, nmax = (NC + (size_t)world - 1) / (size_t)world;
+    auto exchange = [&](const std::vector<uint8_t> &send, size_t rec, std::vector<uint8_t> &all) {
+        // send: nmax records of `rec` bytes (zero padded); all: the NC records in column order
+        std::vector<uint8_t> recv((size_t)world * nmax * rec);
+        if (!shard_.allgather || shard_.allgather(shard_.user, send.data(), nmax * rec, recv.data()) != 0)
+            throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "sharded prove: the all-gather hook failed");
+        all.resize(NC * rec);
+        for (int r = 0; r < world; r++) {
+            size_t a, b;
+            columnBlock(NC, world, r, a, b);
+            memcpy(all.data() + a * rec, recv.data() + (size_t)r * nmax * rec, (b - a) * rec);
+        }
+    };
     std::vector<uint8_t> roots(NC * 32);
     double t0 = now_s();
-    check(ctx_, zigz_commit_roots(job, roots.data()));                 // PHASE 1 results
+    if (world == 1) {
+        check(ctx_, zigz_commit_roots(job, roots.data()));             // PHASE 1 results
+    } else {
+        std::vector<uint8_t> mine(nmax * 32, 0);
+        check(ctx_, zigz_commit_roots(job, mine.data()));
+        exchange(mine, 32, roots);                                     // exchange 1: 43 x 32 B
+    }
     timings[3] = now_s() - t0;
     t0 = now_s();
     transcript_.appendBytes("POLY_COMMITMENTS");                       // PHASE 2, :413-416
@@ -127,8 +149,28 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
     std::vector<uint8_t> sib(NC * nv * 32 + 1), dirs(NC * nv + 1);
     timings[4] = now_s() - t0;
     t0 = now_s();
-    check(ctx_, zigz_commit_open_all(job, points.data(), values.data(), indices.data(), leaves.data(), sib.data(),
-                                     dirs.data()));                    // :427-431
+    check(ctx_, zigz_commit_open_all(job, points.data() + c0 * nv, values.data() + c0, indices.data() + c0, leaves.data() + c0,
+                                     sib.data() + c0 * nv * 32, dirs.data() + c0 * nv));  // :427-431
+    if (world > 1) {                                                   // exchange 2: value, index, leaf, path per column
+        const size_t rec = 24 + 33 * nv;
+        std::vector<uint8_t> mine(nmax * rec, 0), all;
+        for (size_t k = 0; k < nloc; k++) {
+            uint8_t *q = mine.data() + k * rec;
+            const uint64_t head[3] = {values[c0 + k], indices[c0 + k], leaves[c0 + k]};
+            memcpy(q, head, 24);
+            memcpy(q + 24, sib.data() + (c0 + k) * nv * 32, nv * 32);
+            memcpy(q + 24 + nv * 32, dirs.data() + (c0 + k) * nv, nv);
+        }
+        exchange(mine, rec, all);
+        for (size_t c = 0; c < NC; c++) {
+            const uint8_t *q = all.data() + c * rec;
+            uint64_t head[3];
+            memcpy(head, q, 24);
+            values[c] = head[0]; indices[c] = head[1]; leaves[c] = head[2];
+            memcpy(sib.data() + c * nv * 32, q + 24, nv * 32);
+            memcpy(dirs.data() + c * nv, q + 24 + nv * 32, nv);
+        }
+    }
     timings[5] = now_s() - t0;
     t0 = now_s();
     for (size_t c = 0; c < NC; c++) {
@@ -175,10 +217,17 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     // the GPU, so they run underneath the sequential host absorption of steps 4 and 5.
     zigz_commit_job *job = nullptr;
     double t0 = now_s();
+    size_t c0 = 0, c1 = ZIGZ_NUM_COLUMNS;  // sharded: this rank commits its block of columns only
+    if (shard_.world > 1) {
+        if (shard_.rank < 0 || shard_.rank >= shard_.world || shard_.world > (int)ZIGZ_NUM_COLUMNS)
+            throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "sharded prove: bad rank / world");
+        columnBlock(ZIGZ_NUM_COLUMNS, shard_.world, shard_.rank, c0, c1);
+    }
     if (witness)
-        check(ctx_, zigz_commit_begin(ctx_, witness->columns.data(), ZIGZ_NUM_COLUMNS, (size_t)1 << num_vars, num_vars, &job));
+        check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
+                                      (size_t)1 << num_vars, num_vars, &job));
     else
-        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols, ZIGZ_NUM_COLUMNS, d_col_stride, num_vars, &job));
+        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols + c0 * d_col_stride, c1 - c0, d_col_stride, num_vars, &job));
     timings[0] = now_s() - t0;
     // packagePublicIO (:514-559) only copies VM results; doing it here lets the serialiser start early
     proof.public_io = io;

@@ -249,9 +249,28 @@ struct Proof {  // :194-314
 enum class VerificationResult { Accept = 0, RejectInvalidSumcheck, RejectInvalidLookup, RejectInvalidCommitment, RejectInvalidPublicIO };  // :335-341
 
 // ---------------------------------------------------------------- Prover / serializer / verifier
+// One proof over several GPUs ("by column"): rank r commits and opens a contiguous block of the 43 columns;
+// the two exchanges of generateCommitments -- the 43 roots before the transcript absorbs them, the 43 openings after --
+// go through an all-gather hook supplied by the host (RCCL / MPI / torch.distributed): every rank contributes `bytes`
+// from `send`, `recv` receives world * bytes in rank order; returns 0 on success.  Transcripts run in lockstep, so every
+// rank ends with the same, complete proof.
+typedef int (*AllGatherFn)(void *user, const void *send, size_t bytes, void *recv);
+struct ShardSpec {
+    int rank = 0, world = 1;
+    AllGatherFn allgather = nullptr;
+    void *user = nullptr;
+};
+// contiguous blocks, sizes differing by at most one: 43 over 8 -> 6,6,6,5,5,5,5,5
+inline void columnBlock(size_t ncols, int world, int rank, size_t &c0, size_t &c1) {
+    const size_t base = ncols / (size_t)world, extra = ncols % (size_t)world, r = (size_t)rank;
+    c0 = r * base + (r < extra ? r : extra);
+    c1 = c0 + base + (r < extra ? 1 : 0);
+}
+
 class Prover {  // src/prover/prover.zig
   public:
     Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
+    void setShard(const ShardSpec &s) { shard_ = s; }
     // prove(program, entry_pc, initial_regs, max_steps, segments, input), :73-226
     Proof prove(const std::vector<uint8_t> &program, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs,
                 size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input);
@@ -280,6 +299,7 @@ class Prover {  // src/prover/prover.zig
     zigz_ctx *ctx_;
     uint64_t seed_;
     FiatShamirTranscript transcript_;
+    ShardSpec shard_;
 };
 
 struct BinarySerializer {  // src/prover/serialization.zig

@@ -35,6 +35,7 @@ SIGNATURES = {
     "zigzh_trace_witness": (C.c_int, [vp, u64p]),
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
+    "zigzh_prove_trace_sharded": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.POINTER(u8p), szp]),
     "zigzh_vm_run": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, szp]),
     "zigzh_sumcheck_prove_bytes": (C.c_int, [vp, u64p, C.c_size_t, u8p, szp]),
     "zigzh_lasso_prove_table": (C.c_int, [vp, C.c_int, C.c_size_t, u64p, C.c_size_t, u64p, C.c_size_t, u8p, szp, u8p,
@@ -153,6 +154,41 @@ class Trace:
         if mode == 2:
             return BorrowedProof(out, n.value)
         return _take(out, n) if want_bytes else None
+
+    def prove_sharded(self, ctx, d_cols, stride, dist, allgather=None):
+        """ONE proof over dist.get_world_size() GPUs, sharded by column (zigzh_prove_trace_sharded): every rank holds
+        the same trace and a resident copy of the 43 columns, commits / opens its own block, and returns the complete
+        proof (BorrowedProof; identical on every rank and to the unsharded proof)."""
+        cb = allgather or make_allgather(dist)
+        out, n = u8p(), C.c_size_t()
+        _check(lib.zigzh_prove_trace_sharded(self.h, ctx.h, vp(d_cols), stride, dist.get_rank(), dist.get_world_size(),
+                                             C.cast(cb, vp), None, C.byref(out), C.byref(n)))
+        return BorrowedProof(out, n.value)
+
+
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, vp)  # zigzh_allgather_fn
+
+
+def make_allgather(dist):
+    """zigzh_allgather_fn on torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the tests): every rank
+    contributes `nbytes` from `send`, `recv` receives world * nbytes in rank order."""
+    import torch
+    world = dist.get_world_size()
+    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
+
+    def hook(_user, send, nbytes, recv):
+        try:
+            src = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).to(dev)
+            outs = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(outs, src)
+            dst = (C.c_uint8 * (world * nbytes)).from_address(recv)
+            for r, o in enumerate(outs):
+                C.memmove(C.addressof(dst) + r * nbytes, o.cpu().numpy().ctypes.data, nbytes)
+            return 0
+        except Exception:  # never unwind into C
+            return 1
+
+    return ALLGATHER_FN(hook)
 
 
 class BorrowedProof:
