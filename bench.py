@@ -148,6 +148,7 @@ def main():
     def run_step():
         return [f.result() for f in [pool.submit(l.prove) for l in lanes]]
 
+    run_step()  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
     for _ in range(args.warmup):
         run_step()
     for l in lanes:
