@@ -2,7 +2,8 @@
 // 12 v_bitop3 + 5 v_alignbit runs whose operands are drawn from register sets of different sizes / layouts, all
 // kernels with the same VGPR allocation (same occupancy).  Run under
 //   rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 --kernel-trace -- /tmp/valu2_rate
-// and plain for the rates.  Generated body: tools/gen_valu2_rate.py (kept next to this file).
+// and plain for the rates.  The kernels are generated: python3 tools/gen_valu2_rate.py writes valu2_rate_kernels.inc /
+// valu2_rate_calls.inc next to this file (not committed).
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdint.h>

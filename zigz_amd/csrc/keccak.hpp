@@ -76,16 +76,45 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) 
 // and rho's rot-by-1 need one v_alignbit_b32 instead of two, i.e. 52 instead of 58 rotate instructions per round (the
 // rotate is the slow instruction: 35 T lane-ops/s against 55 T for v_bitop3_b32, tools/valu_rate.hip).  XOR3 / chi are
 // bitwise, so they are unchanged: v_bitop3_b32 0x96 / 0xD2.  Per round: 120 v_bitop3 + 52 v_alignbit + iota.
-// Measured against the lo/hi-halves form it replaces (tools/merkle_rate.hip, same box): the 1-hash-per-thread level
-// kernels run 13 % faster, the large kernels the same (~10.5 G permutations/s either way).
-// The round body below is generated by tools/gen_keccak_il.py.
+// The round is emitted phase by phase (tools/gen_keccak_il.py generates the body) -- 20 XOR3 | 5 rotates | 50 XOR3 |
+// 47 rotates | 50 chi -- with scheduling barriers so each phase stays one instruction class, and the wave sleeps ~100
+// cycles (s_sleep 2) after each rotate phase: v_bitop3_b32 can issue on both VALU pipes (every second one on the second
+// pipe) but a wave that has just issued rotates keeps its following v_bitop3 on one pipe; the pause restores the pairing
+// (SQ_ACTIVE_INST_VALU2 / SQ_INSTS_VALU 0.12 -> 0.27, 10.2 -> 11.4 G permutations/s).
 // Digests stay in this form inside the tree (node input = output of the children, no conversion); they are
 // converted to canonical SHA3 bytes only where they leave the device (roots, authentication paths).
 #if defined(__HIP_DEVICE_COMPILE__)
 #define ZK_X3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
 #define ZK_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2)
 #define ZK_ROT32(x, k) __builtin_amdgcn_alignbit((x), (x), 32 - (k))
+#ifndef ZK_REARM_A_ASM
+#define ZK_REARM_A_ASM "s_sleep 2"  // after the 5 rotates of theta
+#endif
+#ifndef ZK_REARM_B_ASM
+#define ZK_REARM_B_ASM "s_sleep 2"  // after the 47 rotates of rho
+#endif
+#ifndef ZK_KECCAK_PHASED
+#define ZK_KECCAK_PHASED 1  // 0 = leave the instruction order to the compiler (A/B experiments)
+#endif
+#if ZK_KECCAK_PHASED
+#define ZK_PHASE() __builtin_amdgcn_sched_barrier(0)
+#define ZK_REARM_(text)                             \
+    do {                                            \
+        __builtin_amdgcn_sched_barrier(0);          \
+        asm volatile(text);                         \
+        __builtin_amdgcn_sched_barrier(0);          \
+    } while (0)
+#define ZK_REARM_A() ZK_REARM_(ZK_REARM_A_ASM)
+#define ZK_REARM_B() ZK_REARM_(ZK_REARM_B_ASM)
 #else
+#define ZK_PHASE()
+#define ZK_REARM_A()
+#define ZK_REARM_B()
+#endif
+#else
+#define ZK_PHASE()
+#define ZK_REARM_A()
+#define ZK_REARM_B()
 #define ZK_X3(a, b, c) ((a) ^ (b) ^ (c))
 #define ZK_CHI(a, b, c) ((a) ^ (~(b) & (c)))
 #define ZK_ROT32(x, k) ((uint32_t)(((x) << (k)) | ((x) >> (32 - (k)))))
@@ -102,7 +131,9 @@ __constant__ const uint32_t KECCAK_RC_O[24] = {0x00000000u, 0x00000089u, 0x80000
 __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) {
 #pragma unroll ZK_KECCAK_UNROLL
     for (int r = 0; r < 24; r++) {
-        uint32_t be[25], bo[25];
+        uint32_t te[25], to[25], be[25], bo[25];
+        // <generated by tools/gen_keccak_il.py>
+        // phase 1: column parities
         const uint32_t ce0 = ZK_X3(ZK_X3(e[0], e[5], e[10]), e[15], e[20]);
         const uint32_t co0 = ZK_X3(ZK_X3(o[0], o[5], o[10]), o[15], o[20]);
         const uint32_t ce1 = ZK_X3(ZK_X3(e[1], e[6], e[11]), e[16], e[21]);
@@ -113,61 +144,65 @@ __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) 
         const uint32_t co3 = ZK_X3(ZK_X3(o[3], o[8], o[13]), o[18], o[23]);
         const uint32_t ce4 = ZK_X3(ZK_X3(e[4], e[9], e[14]), e[19], e[24]);
         const uint32_t co4 = ZK_X3(ZK_X3(o[4], o[9], o[14]), o[19], o[24]);
-        const uint32_t re0 = ZK_ROT32(co0, 1);  // rot64(C[0], 1): even <- rot32(odd, 1), odd <- even
-        const uint32_t re1 = ZK_ROT32(co1, 1);  // rot64(C[1], 1): even <- rot32(odd, 1), odd <- even
-        const uint32_t re2 = ZK_ROT32(co2, 1);  // rot64(C[2], 1): even <- rot32(odd, 1), odd <- even
-        const uint32_t re3 = ZK_ROT32(co3, 1);  // rot64(C[3], 1): even <- rot32(odd, 1), odd <- even
-        const uint32_t re4 = ZK_ROT32(co4, 1);  // rot64(C[4], 1): even <- rot32(odd, 1), odd <- even
-        { const uint32_t te = ZK_X3(e[0], ce4, re1), to = ZK_X3(o[0], co4, ce1);  // lane 0, rho 0 -> 0
-          be[0] = te; bo[0] = to; }
-        { const uint32_t te = ZK_X3(e[1], ce0, re2), to = ZK_X3(o[1], co0, ce2);  // lane 1, rho 1 -> 10
-          be[10] = ZK_ROT32(to, 1); bo[10] = te; }
-        { const uint32_t te = ZK_X3(e[2], ce1, re3), to = ZK_X3(o[2], co1, ce3);  // lane 2, rho 62 -> 20
-          be[20] = ZK_ROT32(te, 31); bo[20] = ZK_ROT32(to, 31); }
-        { const uint32_t te = ZK_X3(e[3], ce2, re4), to = ZK_X3(o[3], co2, ce4);  // lane 3, rho 28 -> 5
-          be[5] = ZK_ROT32(te, 14); bo[5] = ZK_ROT32(to, 14); }
-        { const uint32_t te = ZK_X3(e[4], ce3, re0), to = ZK_X3(o[4], co3, ce0);  // lane 4, rho 27 -> 15
-          be[15] = ZK_ROT32(to, 14); bo[15] = ZK_ROT32(te, 13); }
-        { const uint32_t te = ZK_X3(e[5], ce4, re1), to = ZK_X3(o[5], co4, ce1);  // lane 5, rho 36 -> 16
-          be[16] = ZK_ROT32(te, 18); bo[16] = ZK_ROT32(to, 18); }
-        { const uint32_t te = ZK_X3(e[6], ce0, re2), to = ZK_X3(o[6], co0, ce2);  // lane 6, rho 44 -> 1
-          be[1] = ZK_ROT32(te, 22); bo[1] = ZK_ROT32(to, 22); }
-        { const uint32_t te = ZK_X3(e[7], ce1, re3), to = ZK_X3(o[7], co1, ce3);  // lane 7, rho 6 -> 11
-          be[11] = ZK_ROT32(te, 3); bo[11] = ZK_ROT32(to, 3); }
-        { const uint32_t te = ZK_X3(e[8], ce2, re4), to = ZK_X3(o[8], co2, ce4);  // lane 8, rho 55 -> 21
-          be[21] = ZK_ROT32(to, 28); bo[21] = ZK_ROT32(te, 27); }
-        { const uint32_t te = ZK_X3(e[9], ce3, re0), to = ZK_X3(o[9], co3, ce0);  // lane 9, rho 20 -> 6
-          be[6] = ZK_ROT32(te, 10); bo[6] = ZK_ROT32(to, 10); }
-        { const uint32_t te = ZK_X3(e[10], ce4, re1), to = ZK_X3(o[10], co4, ce1);  // lane 10, rho 3 -> 7
-          be[7] = ZK_ROT32(to, 2); bo[7] = ZK_ROT32(te, 1); }
-        { const uint32_t te = ZK_X3(e[11], ce0, re2), to = ZK_X3(o[11], co0, ce2);  // lane 11, rho 10 -> 17
-          be[17] = ZK_ROT32(te, 5); bo[17] = ZK_ROT32(to, 5); }
-        { const uint32_t te = ZK_X3(e[12], ce1, re3), to = ZK_X3(o[12], co1, ce3);  // lane 12, rho 43 -> 2
-          be[2] = ZK_ROT32(to, 22); bo[2] = ZK_ROT32(te, 21); }
-        { const uint32_t te = ZK_X3(e[13], ce2, re4), to = ZK_X3(o[13], co2, ce4);  // lane 13, rho 25 -> 12
-          be[12] = ZK_ROT32(to, 13); bo[12] = ZK_ROT32(te, 12); }
-        { const uint32_t te = ZK_X3(e[14], ce3, re0), to = ZK_X3(o[14], co3, ce0);  // lane 14, rho 39 -> 22
-          be[22] = ZK_ROT32(to, 20); bo[22] = ZK_ROT32(te, 19); }
-        { const uint32_t te = ZK_X3(e[15], ce4, re1), to = ZK_X3(o[15], co4, ce1);  // lane 15, rho 41 -> 23
-          be[23] = ZK_ROT32(to, 21); bo[23] = ZK_ROT32(te, 20); }
-        { const uint32_t te = ZK_X3(e[16], ce0, re2), to = ZK_X3(o[16], co0, ce2);  // lane 16, rho 45 -> 8
-          be[8] = ZK_ROT32(to, 23); bo[8] = ZK_ROT32(te, 22); }
-        { const uint32_t te = ZK_X3(e[17], ce1, re3), to = ZK_X3(o[17], co1, ce3);  // lane 17, rho 15 -> 18
-          be[18] = ZK_ROT32(to, 8); bo[18] = ZK_ROT32(te, 7); }
-        { const uint32_t te = ZK_X3(e[18], ce2, re4), to = ZK_X3(o[18], co2, ce4);  // lane 18, rho 21 -> 3
-          be[3] = ZK_ROT32(to, 11); bo[3] = ZK_ROT32(te, 10); }
-        { const uint32_t te = ZK_X3(e[19], ce3, re0), to = ZK_X3(o[19], co3, ce0);  // lane 19, rho 8 -> 13
-          be[13] = ZK_ROT32(te, 4); bo[13] = ZK_ROT32(to, 4); }
-        { const uint32_t te = ZK_X3(e[20], ce4, re1), to = ZK_X3(o[20], co4, ce1);  // lane 20, rho 18 -> 14
-          be[14] = ZK_ROT32(te, 9); bo[14] = ZK_ROT32(to, 9); }
-        { const uint32_t te = ZK_X3(e[21], ce0, re2), to = ZK_X3(o[21], co0, ce2);  // lane 21, rho 2 -> 24
-          be[24] = ZK_ROT32(te, 1); bo[24] = ZK_ROT32(to, 1); }
-        { const uint32_t te = ZK_X3(e[22], ce1, re3), to = ZK_X3(o[22], co1, ce3);  // lane 22, rho 61 -> 9
-          be[9] = ZK_ROT32(to, 31); bo[9] = ZK_ROT32(te, 30); }
-        { const uint32_t te = ZK_X3(e[23], ce2, re4), to = ZK_X3(o[23], co2, ce4);  // lane 23, rho 56 -> 19
-          be[19] = ZK_ROT32(te, 28); bo[19] = ZK_ROT32(to, 28); }
-        { const uint32_t te = ZK_X3(e[24], ce3, re0), to = ZK_X3(o[24], co3, ce0);  // lane 24, rho 14 -> 4
-          be[4] = ZK_ROT32(te, 7); bo[4] = ZK_ROT32(to, 7); }
+        ZK_PHASE();  // phase 2: rot64(C[x], 1): even <- rot32(odd, 1), odd <- even
+        const uint32_t re0 = ZK_ROT32(co0, 1);
+        const uint32_t re1 = ZK_ROT32(co1, 1);
+        const uint32_t re2 = ZK_ROT32(co2, 1);
+        const uint32_t re3 = ZK_ROT32(co3, 1);
+        const uint32_t re4 = ZK_ROT32(co4, 1);
+        ZK_REARM_A();  // phase 3: theta applied, t = a ^ C[x-1] ^ rot(C[x+1], 1)
+        te[0] = ZK_X3(e[0], ce4, re1); to[0] = ZK_X3(o[0], co4, ce1);
+        te[1] = ZK_X3(e[1], ce0, re2); to[1] = ZK_X3(o[1], co0, ce2);
+        te[2] = ZK_X3(e[2], ce1, re3); to[2] = ZK_X3(o[2], co1, ce3);
+        te[3] = ZK_X3(e[3], ce2, re4); to[3] = ZK_X3(o[3], co2, ce4);
+        te[4] = ZK_X3(e[4], ce3, re0); to[4] = ZK_X3(o[4], co3, ce0);
+        te[5] = ZK_X3(e[5], ce4, re1); to[5] = ZK_X3(o[5], co4, ce1);
+        te[6] = ZK_X3(e[6], ce0, re2); to[6] = ZK_X3(o[6], co0, ce2);
+        te[7] = ZK_X3(e[7], ce1, re3); to[7] = ZK_X3(o[7], co1, ce3);
+        te[8] = ZK_X3(e[8], ce2, re4); to[8] = ZK_X3(o[8], co2, ce4);
+        te[9] = ZK_X3(e[9], ce3, re0); to[9] = ZK_X3(o[9], co3, ce0);
+        te[10] = ZK_X3(e[10], ce4, re1); to[10] = ZK_X3(o[10], co4, ce1);
+        te[11] = ZK_X3(e[11], ce0, re2); to[11] = ZK_X3(o[11], co0, ce2);
+        te[12] = ZK_X3(e[12], ce1, re3); to[12] = ZK_X3(o[12], co1, ce3);
+        te[13] = ZK_X3(e[13], ce2, re4); to[13] = ZK_X3(o[13], co2, ce4);
+        te[14] = ZK_X3(e[14], ce3, re0); to[14] = ZK_X3(o[14], co3, ce0);
+        te[15] = ZK_X3(e[15], ce4, re1); to[15] = ZK_X3(o[15], co4, ce1);
+        te[16] = ZK_X3(e[16], ce0, re2); to[16] = ZK_X3(o[16], co0, ce2);
+        te[17] = ZK_X3(e[17], ce1, re3); to[17] = ZK_X3(o[17], co1, ce3);
+        te[18] = ZK_X3(e[18], ce2, re4); to[18] = ZK_X3(o[18], co2, ce4);
+        te[19] = ZK_X3(e[19], ce3, re0); to[19] = ZK_X3(o[19], co3, ce0);
+        te[20] = ZK_X3(e[20], ce4, re1); to[20] = ZK_X3(o[20], co4, ce1);
+        te[21] = ZK_X3(e[21], ce0, re2); to[21] = ZK_X3(o[21], co0, ce2);
+        te[22] = ZK_X3(e[22], ce1, re3); to[22] = ZK_X3(o[22], co1, ce3);
+        te[23] = ZK_X3(e[23], ce2, re4); to[23] = ZK_X3(o[23], co2, ce4);
+        te[24] = ZK_X3(e[24], ce3, re0); to[24] = ZK_X3(o[24], co3, ce0);
+        ZK_PHASE();  // phase 4: rho (rotate) and pi (destination index)
+        be[0] = te[0]; bo[0] = to[0];  // lane 0, rho 0
+        be[10] = ZK_ROT32(to[1], 1); bo[10] = te[1];  // lane 1, rho 1
+        be[20] = ZK_ROT32(te[2], 31); bo[20] = ZK_ROT32(to[2], 31);  // lane 2, rho 62
+        be[5] = ZK_ROT32(te[3], 14); bo[5] = ZK_ROT32(to[3], 14);  // lane 3, rho 28
+        be[15] = ZK_ROT32(to[4], 14); bo[15] = ZK_ROT32(te[4], 13);  // lane 4, rho 27
+        be[16] = ZK_ROT32(te[5], 18); bo[16] = ZK_ROT32(to[5], 18);  // lane 5, rho 36
+        be[1] = ZK_ROT32(te[6], 22); bo[1] = ZK_ROT32(to[6], 22);  // lane 6, rho 44
+        be[11] = ZK_ROT32(te[7], 3); bo[11] = ZK_ROT32(to[7], 3);  // lane 7, rho 6
+        be[21] = ZK_ROT32(to[8], 28); bo[21] = ZK_ROT32(te[8], 27);  // lane 8, rho 55
+        be[6] = ZK_ROT32(te[9], 10); bo[6] = ZK_ROT32(to[9], 10);  // lane 9, rho 20
+        be[7] = ZK_ROT32(to[10], 2); bo[7] = ZK_ROT32(te[10], 1);  // lane 10, rho 3
+        be[17] = ZK_ROT32(te[11], 5); bo[17] = ZK_ROT32(to[11], 5);  // lane 11, rho 10
+        be[2] = ZK_ROT32(to[12], 22); bo[2] = ZK_ROT32(te[12], 21);  // lane 12, rho 43
+        be[12] = ZK_ROT32(to[13], 13); bo[12] = ZK_ROT32(te[13], 12);  // lane 13, rho 25
+        be[22] = ZK_ROT32(to[14], 20); bo[22] = ZK_ROT32(te[14], 19);  // lane 14, rho 39
+        be[23] = ZK_ROT32(to[15], 21); bo[23] = ZK_ROT32(te[15], 20);  // lane 15, rho 41
+        be[8] = ZK_ROT32(to[16], 23); bo[8] = ZK_ROT32(te[16], 22);  // lane 16, rho 45
+        be[18] = ZK_ROT32(to[17], 8); bo[18] = ZK_ROT32(te[17], 7);  // lane 17, rho 15
+        be[3] = ZK_ROT32(to[18], 11); bo[3] = ZK_ROT32(te[18], 10);  // lane 18, rho 21
+        be[13] = ZK_ROT32(te[19], 4); bo[13] = ZK_ROT32(to[19], 4);  // lane 19, rho 8
+        be[14] = ZK_ROT32(te[20], 9); bo[14] = ZK_ROT32(to[20], 9);  // lane 20, rho 18
+        be[24] = ZK_ROT32(te[21], 1); bo[24] = ZK_ROT32(to[21], 1);  // lane 21, rho 2
+        be[9] = ZK_ROT32(to[22], 31); bo[9] = ZK_ROT32(te[22], 30);  // lane 22, rho 61
+        be[19] = ZK_ROT32(te[23], 28); bo[19] = ZK_ROT32(to[23], 28);  // lane 23, rho 56
+        be[4] = ZK_ROT32(te[24], 7); bo[4] = ZK_ROT32(to[24], 7);  // lane 24, rho 14
+        ZK_REARM_B();  // phase 5: chi
         e[0] = ZK_CHI(be[0], be[1], be[2]); o[0] = ZK_CHI(bo[0], bo[1], bo[2]);
         e[1] = ZK_CHI(be[1], be[2], be[3]); o[1] = ZK_CHI(bo[1], bo[2], bo[3]);
         e[2] = ZK_CHI(be[2], be[3], be[4]); o[2] = ZK_CHI(bo[2], bo[3], bo[4]);
@@ -193,6 +228,7 @@ __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) 
         e[22] = ZK_CHI(be[22], be[23], be[24]); o[22] = ZK_CHI(bo[22], bo[23], bo[24]);
         e[23] = ZK_CHI(be[23], be[24], be[20]); o[23] = ZK_CHI(bo[23], bo[24], bo[20]);
         e[24] = ZK_CHI(be[24], be[20], be[21]); o[24] = ZK_CHI(bo[24], bo[20], bo[21]);
+        // </generated>
         e[0] ^= KECCAK_RC_E[r];
         o[0] ^= KECCAK_RC_O[r];
     }
