@@ -49,16 +49,17 @@ def main():
     shutil.copy(newest("gpurun_out/fin_b1/*/*kernel_stats.csv"), "profiles/%s_b1_kernel_stats.csv" % ROUND)
     shutil.copy(newest("gpurun_out/fin_bdef/*/*kernel_stats.csv"), "profiles/%s_bdef_kernel_stats.csv" % ROUND)
     for src, dst in (("fin_bench.json", "final_bench.json"), ("fin_bench_b1.json", "final_bench_b1.json"),
-                     ("fin_bench_b6.json", "final_bench_b6.json"), ("fin_bench_dedup8.json", "final_bench_dedup_b8.json"),
+                     ("fin_bench_b6.json", "final_bench_b6.json"), ("fin_bench_b8.json", "final_bench_b8.json"), ("fin_bench_dedup8.json", "final_bench_dedup_b8.json"),
                      ("fin_extra.json", "extra.json"), ("fin_configs.jsonl", "configs.jsonl"),
                      ("fin_merkle_rate.txt", "merkle_rate.txt"), ("fin_fold_rate.txt", "fold_rate.txt"),
-                     ("fin_valu_rate.txt", "valu_rate.txt"), ("fin_bank_rate.txt", "bank_rate.txt")):
+                     ("fin_valu_rate.txt", "valu_rate.txt"), ("fin_bank_rate.txt", "bank_rate.txt"),
+                     ("fin_valu2_rate.txt", "valu2_rate.txt")):
         shutil.copy(os.path.join("gpurun_out", src), "profiles/%s_%s" % (ROUND, dst))
     for tag in ("b1", "bdef"):
         print(tag)
         for r in list(csv.DictReader(open("profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))))[:6]:
             print("  %-55s calls=%5s avg_us=%10.2f" % (r["Name"][:55], r["Calls"], float(r["AverageNs"]) / 1e3))
-    for name in ("final_bench", "final_bench_b1", "final_bench_b6", "final_bench_dedup_b8"):
+    for name in ("final_bench", "final_bench_b1", "final_bench_b6", "final_bench_b8", "final_bench_dedup_b8"):
         d = json.load(open("profiles/%s_%s.json" % (ROUND, name)))
         r = d["roofline"]
         print("%-22s %6.1f M steps/s  %.2f ms/proof  roofline %.3f (uncontended %.3f, %.1f us)  merkle %.2f ms" %

@@ -5,6 +5,7 @@
 #include "../zigz_amd/csrc/kernels.hip"
 
 #include <stdio.h>
+#include <chrono>
 #include <vector>
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("HIP error %s at %d\n", hipGetErrorString(e_), __LINE__); return 1; } } while (0)
@@ -33,6 +34,20 @@ int main(int argc, char **argv) {
     CK(hipEventCreate(&f1));
     hipEvent_t ev[64];
     for (auto &e : ev) CK(hipEventCreate(&e));
+    {   // the fold issued 1 ms into another stream's leaves kernel (what an eval meets when other proofs are in flight)
+        hipStream_t s2;
+        CK(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+        for (int rep = 0; rep < 4; rep++) {
+            zk::launch_keccak_leaves(d_vals, N, N, N, d_tree, nodes, ncols, 0);
+            const auto t0 = std::chrono::steady_clock::now();
+            while (std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count() < 1e-3 * (1 + rep % 2)) {}
+            zk::launch_radix_fold(d_vals, N, fm, fnb, d_w, fnb, d_part, fgroups * fm, ncols, s2, f0, f1);
+            CK(hipDeviceSynchronize());
+            float ms = 0;
+            CK(hipEventElapsedTime(&ms, f0, f1));
+            printf("fold inside a running leaves kernel: %.1f us\n", ms * 1e3);
+        }
+    }
     for (int rep = 0; rep < 3; rep++) {
         int k = 0;
         CK(hipEventRecord(ev[k++], 0));

@@ -14,6 +14,8 @@ hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc -I include tools/merkle_rate.hi
 hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc tools/fold_rate.hip -o /tmp/fold_rate 2>/dev/null && /tmp/fold_rate > gpurun_out/fin_fold_rate.txt
 hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > gpurun_out/fin_valu_rate.txt
 hipcc --offload-arch=gfx950 -O3 tools/bank_rate.hip -o /tmp/bank_rate 2>/dev/null && /tmp/bank_rate > gpurun_out/fin_bank_rate.txt
+python3 tools/gen_valu2_rate.py && hipcc --offload-arch=gfx950 -O3 -I tools tools/valu2_rate.hip -o /tmp/valu2_rate 2>/dev/null && /tmp/valu2_rate > gpurun_out/fin_valu2_rate.txt
+python bench.py --batch 8 --no-cpu-baseline > gpurun_out/fin_bench_b8.json 2>> gpurun_out/fin_bench.err
 rm -f gpurun_out/fin_configs.jsonl
 for c in 2 3 4 5; do python tests/run_config.py --config $c --check-cols 1 >> gpurun_out/fin_configs.jsonl 2>> gpurun_out/fin_bench.err; done
 tail -c 600 gpurun_out/fin_bench.json
