@@ -104,6 +104,13 @@ def test_host_hashes_and_transcript():
     assert [a.challenge() for _ in range(4)] == [b.challenge(P) for _ in range(4)]
     t = Transcript(); t.append_field(3); t.append_field(4)
     assert [str(t.challenge()), str(t.challenge())] == G["transcript_kat"]["challenges_babybear"]
+    # the bulk form keeps (start + k) mod p incrementally: wrap-around at p, long tags, chunk boundaries
+    for tag, start, count in ((b"LASSO_TABLE", P - 3, 7), (b"T" * 30, 5, 40), (b"", P - 1, 3), (b"LASSO_TABLE", 0, 4000)):
+        a, b = Transcript(), O.Transcript()
+        a.append_tagged_counter(tag, start, count)
+        for i in range(count):
+            b.append_bytes(tag); b.append_field((start + i) % P)
+        assert a.challenge() == b.challenge(P), (tag, start, count)
 
 
 def test_host_keccak_dispatch_matches_portable_code():

@@ -146,16 +146,26 @@ void Transcript::append_tagged_counter(const uint8_t *tag, size_t tag_len, uint6
         for (uint64_t k = 0; k < count; k++) { h_.update(tag, tag_len); h_.update_le64((start + k) % (uint64_t)P); }
         return;
     }
-    uint8_t buf[CHUNK * 256 > 0 ? CHUNK * 64 : 1];
-    const size_t per = sizeof(buf) / rec;
-    uint64_t k = 0;
+    uint8_t buf[CHUNK * 64 + 32];  // + slack: every record is written as one 32-byte template copy
+    const size_t per = (sizeof(buf) - 32) / rec;
+    uint8_t tmpl[32] = {0};
+    memcpy(tmpl, tag, tag_len < 24 ? tag_len : 24);
+    uint64_t k = 0, v = start % (uint64_t)P;  // (start + k) mod p kept incrementally
     while (k < count) {
         size_t m = count - k < per ? (size_t)(count - k) : per;
         uint8_t *q = buf;
-        for (size_t j = 0; j < m; j++, q += rec) {
-            memcpy(q, tag, tag_len);
-            uint64_t v = (start + k + j) % (uint64_t)P;
-            memcpy(q + tag_len, &v, 8);
+        if (tag_len <= 24) {
+            for (size_t j = 0; j < m; j++, q += rec) {
+                memcpy(q, tmpl, 32);  // tag (the tail is overwritten by the counter and the next record)
+                memcpy(q + tag_len, &v, 8);
+                if (++v == (uint64_t)P) v = 0;
+            }
+        } else {
+            for (size_t j = 0; j < m; j++, q += rec) {
+                memcpy(q, tag, tag_len);
+                memcpy(q + tag_len, &v, 8);
+                if (++v == (uint64_t)P) v = 0;
+            }
         }
         h_.update(buf, m * rec);
         k += m;
