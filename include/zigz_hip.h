@@ -138,9 +138,10 @@ zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols,
 zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
                                   size_t nv, zigz_commit_job **out);
 /* waits for the Merkle builds; roots: ncols*32 bytes (prover.zig:405-410).
- * One job per context at a time, and between zigz_commit_begin* and zigz_commit_roots make no other call on the
- * same context (the roots travel through the context's staging buffer underneath the caller's transcript work);
- * host-only entry points (zigz_transcript_*, zigz_sha3_256, ...) are free to use. */
+ * One job per context at a time (a second begin returns ZIGZ_ERR_BAD_STATE).  Other calls on the same context
+ * between begin and end are allowed -- e.g. a Zig host evaluating one MLE while the trees build: they queue behind
+ * the builds on the context's stream, and the job's roots travel through a pinned buffer of their own, so they
+ * arrive intact (tests/test_gpu_parity.py::test_commit_job_survives_interleaved_calls). */
 zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots);
 /* points: ncols*nv challenges (row c = point of column c).  Outputs per column: value = eval(point)
  * (prover.zig:427), index = point[0] mod 2^nv, leaf = evaluations[index], siblings ncols*nv*32 B,

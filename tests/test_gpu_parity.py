@@ -227,6 +227,40 @@ def test_commit_job_vs_oracle(ctx, nv):
     assert tg.challenge() == to.challenge(P)
 
 
+@pytest.mark.parametrize("nv", [3, 11, 15])
+def test_commit_job_survives_interleaved_calls(ctx, nv):
+    """A host that uses the context between zigz_commit_begin and zigz_commit_roots / open_all (prover.zig:405-424:
+    the reference evaluates and hashes freely while it owns the trees) still gets the oracle's roots and openings:
+    every staging path of the context (pinned words, workspaces) is exercised in between."""
+    import zigz_amd
+    N = 1 << nv
+    cols = rnd(0xC0117 + nv, 43 * N).reshape(43, N)
+    exp = O.generate_commitments(P, O.Transcript(), cols, fast=(nv > 10))
+    other = rnd(77 + nv, 1 << 15)
+    pt = rnd(78 + nv, 15)
+    job = zigz_amd.CommitJob(ctx, cols=cols)
+    # all of these stage data through the context while the job's roots are in flight
+    assert ctx.mle_eval(other, pt) == O.mle_eval(P, other, pt)
+    assert ctx.mle_round_poly(other) == O.mle_round_poly(P, other)
+    r, p_, fe = ctx.sumcheck_prove(other[: 1 << 12])
+    r0, p0, fe0 = O.sumcheck_prove(P, other[: 1 << 12])
+    assert np.array_equal(r, r0) and fe == fe0
+    t = zigz_amd.SimpleMerkleTree(ctx, other[:1000])
+    lv, _ = O.merkle_levels(other[:1000])
+    assert t.root_hash == lv[(2 * 1024 - 2) * 32:(2 * 1024 - 1) * 32].tobytes()
+    t.deinit()
+    with pytest.raises(zigz_amd.errors.ZigzError) as err:  # a second job on the same context is refused, not corrupted
+        zigz_amd.CommitJob(ctx, cols=cols)
+    assert err.value.code == zigz_amd.errors.BAD_STATE
+    roots = job.roots()
+    assert np.array_equal(roots, exp["roots"])
+    assert ctx.mle_eval(other, pt) == O.mle_eval(P, other, pt)  # ... and between roots and open_all
+    got = job.open_all(exp["points"])
+    job.end()
+    for k in ("values", "indices", "leaves", "siblings", "dirs"):
+        assert np.array_equal(got[k], exp[k]), k
+
+
 def test_commit_job_large_properties(ctx):
     """43 x 2^18 columns (BASELINE-scale shape): every opening verifies against its root through the
     oracle's Merkle verifier; values match the oracle's fold-eval on sampled columns."""

@@ -31,6 +31,8 @@ struct zigz_ctx {
     unsigned long long *d_sums;  // SUMS_SLOTS u64
     uint32_t *d_flag;
     uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
+    uint8_t *h_roots;  // pinned, ROOTS_MAX_COLS * 32 B: the active commit job's roots travel through this buffer ONLY, so any
+                       // other call on the context between zigz_commit_begin* and zigz_commit_roots leaves them intact
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
@@ -48,6 +50,7 @@ constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck s
 constexpr size_t RADIX_MIN_N = 1 << 11;  // smaller tables use the per-round form (one launch + read-back per round)
 constexpr size_t HOST_TAIL_MAX = 1024;
 static const size_t PIN_WORDS = 1 << 16;
+static const size_t ROOTS_MAX_COLS = 4096;
 
 static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
     if (!ctx) return;
@@ -175,7 +178,8 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
         fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_dedup_count, 64)) ||
-        fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)))
+        fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
+        fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
@@ -201,6 +205,7 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_dedup_count) (void)hipFree(ctx->d_dedup_count);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
+    if (ctx->h_roots) (void)hipHostFree(ctx->h_roots);
     for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 128; i++)
@@ -1039,7 +1044,7 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         launch_gather_nodes(job->d_tree, tree_nodes(job->N), tree_level_offset(job->N, (unsigned)nv), (uint8_t *)d_roots,
                             ncols, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
         return ZIGZ_OK;
     };
@@ -1059,7 +1064,7 @@ extern "C" zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_co
                                              size_t nv, zigz_commit_job **out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !d_cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
-    if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ncols > ROOTS_MAX_COLS) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (col_stride < ((size_t)1 << nv)) return ZIGZ_ERR_INVALID_ARGUMENT;
     return job_begin(ctx, d_cols, ncols, col_stride, nv, out);
 }
@@ -1068,7 +1073,7 @@ extern "C" zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, si
                                          size_t nv, zigz_commit_job **out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !cols || !out || ncols == 0 || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
-    if (ncols * 32 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ncols > ROOTS_MAX_COLS) return ZIGZ_ERR_INVALID_ARGUMENT;
     const size_t N = (size_t)1 << nv;
     if (col_stride < N) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;
@@ -1090,7 +1095,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     zigz_ctx *ctx = job->ctx;
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
     HIPCHK(ctx, hipEventSynchronize(job->built));
-    memcpy(roots, ctx->h_pin, job->ncols * 32);
+    memcpy(roots, ctx->h_roots, job->ncols * 32);
     if (ctx->stats.merkle_blocks) {
         unsigned long long cnt = 0;
         HIPCHK(ctx, hipMemcpy(&cnt, ctx->d_dedup_count, 8, hipMemcpyDeviceToHost));

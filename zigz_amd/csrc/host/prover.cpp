@@ -105,7 +105,9 @@ void Prover::generateLassoProofs(Proof &proof, size_t num_lookups) {  // :292-36
     transcript_.appendBytes("LASSO_BEGIN");
     // per lookup constraint i: appendBytes("LASSO_TABLE"); appendFieldElement(F.init(i))  (:311-312)
     transcript_.appendTaggedCounter("LASSO_TABLE", 0, num_lookups);
-    proof.lookup_placeholders = num_lookups;  // placeholder proofs; the rng fill loops run zero times
+    // placeholder proofs (the rng fill loops run zero times): proof.lookup_placeholders was set by the
+    // caller BEFORE the serialiser thread started reading it; it is not written again here (no concurrent store)
+    (void)proof;
 }
 
 void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) {  // :366-467
@@ -215,7 +217,12 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     if (proof.metadata.num_vars != num_vars) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "witness num_vars != log2_int_ceil(num_steps)");
     // [6/6 phase 1] Merkle builds do not depend on the transcript: start them first, asynchronously on
     // the GPU, so they run underneath the sequential host absorption of steps 4 and 5.
-    zigz_commit_job *job = nullptr;
+    // RAII: the job is ended (and the context's active-job slot released) on every exit path, including a bad_alloc
+    // between begin and the transcript work
+    struct JobGuard {
+        zigz_commit_job *job = nullptr;
+        ~JobGuard() { if (job) zigz_commit_end(job); }
+    } guard;
     double t0 = now_s();
     size_t c0 = 0, c1 = ZIGZ_NUM_COLUMNS;  // sharded: this rank commits its block of columns only
     if (shard_.world > 1) {
@@ -225,20 +232,20 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     }
     if (witness)
         check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
-                                      (size_t)1 << num_vars, num_vars, &job));
+                                      (size_t)1 << num_vars, num_vars, &guard.job));
     else
-        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols + c0 * d_col_stride, c1 - c0, d_col_stride, num_vars, &job));
+        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols + c0 * d_col_stride, c1 - c0, d_col_stride, num_vars, &guard.job));
     timings[0] = now_s() - t0;
     // packagePublicIO (:514-559) only copies VM results; doing it here lets the serialiser start early
     proof.public_io = io;
     if (initial_regs) proof.public_io.initial_regs = *initial_regs;
     else proof.public_io.initial_regs.reset();
+    proof.lookup_placeholders = num_lookups;  // final before the writer thread exists
     std::thread writer;
     try {
         t0 = now_s();
         generateSumcheckProof(proof, num_steps, num_vars);  // [4/6]
         timings[1] = now_s() - t0;
-        proof.lookup_placeholders = num_lookups;
         if (bytes_out) {
             // everything up to the 43 openings is final now: write it while the transcript absorbs step 5
             size_t total = BinarySerializer::prefixSize(proof) + ZIGZ_NUM_COLUMNS * (68 + 41 * num_vars);
@@ -250,13 +257,13 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         t0 = now_s();
         generateLassoProofs(proof, num_lookups);            // [5/6]
         timings[2] = now_s() - t0;
-        generateCommitments(proof, job, num_vars);          // [6/6]
+        generateCommitments(proof, guard.job, num_vars);    // [6/6]
     } catch (...) {
         if (writer.joinable()) writer.join();
-        zigz_commit_end(job);
         throw;
     }
-    zigz_commit_end(job);
+    zigz_commit_end(guard.job);
+    guard.job = nullptr;
     if (bytes_out) {
         t0 = now_s();
         writer.join();
