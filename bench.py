@@ -1,6 +1,9 @@
 #!/usr/bin/env python3
 """bench.py -- trace steps/sec proved on the synthetic RV64I ADD/XOR loop at a 2^20 trace (BASELINE config 3).
 
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nv 20] [--mode traces|shard]
+                    [--no-cpu-baseline] [--kernels]
+
 A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces
 (default 4 per GPU; every trace gets its own complete proof) whose 43 witness columns each are already
 resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of Prover.prove
@@ -8,20 +11,26 @@ resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir 
 challenges, OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and
 the ZIGZ v1 serialisation of the proof.  Nothing is skipped or cached between steps.
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nv 20] [--no-cpu-baseline]
-
 Why a batch: one proof is bounded by its own sequential SHA3 transcript on ONE host core (19 bytes absorbed per
-lookup step, ~30 ms at 2^20) while its GPU work takes ~10 ms, so a proving service keeps the GPU busy by
-running several proofs per GPU concurrently (one host thread + one HIP stream each).  `--batch 1` measures
-single-proof latency.
+lookup step, ~28 ms at 2^20) while its GPU work takes ~8 ms, so a proving service keeps the GPU busy by
+running several proofs per GPU concurrently (one host thread + one HIP stream each).  The same JSON line also
+carries `single_proof_ms` (one proof at a time) and `pcie_inclusive_value` (trace upload + witness kernels inside
+the timed loop), measured right after the timed region.
 
-N > 1 is launched by torch.distributed.run (one rank per GPU, backend nccl = RCCL).  The path shards by
-independent traces (one proof per rank, no data-path collective): scaling = "weak"; value = all ranks'
-trace steps / max-over-ranks time.  Rank 0 prints ONE JSON line.
+N > 1: `python bench.py --gpus N` starts the N ranks itself (child `python -m torch.distributed.run`, before this
+process touches torch or HIP) and relays rank 0's JSON line; when a launcher has already set WORLD_SIZE the
+process is a rank.  One rank per GPU, backend nccl (= RCCL); the path shards by independent traces (one batch of
+proofs per rank, no data-path collective): "scaling": "weak", value = all ranks' trace steps / max-over-ranks
+time.  `--mode shard` (one proof per step, its 43 columns sharded over the ranks) is the strong-scaling variant.
+
+`--kernels` runs only the per-kernel leg (cold-HBM launches of the MLE and Keccak kernels with kernel
+timestamps) and prints its own JSON line; that is the command profiles/r02_kernels_* were taken from.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -30,35 +39,141 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md); ~6.3 TB/s achievable
-# 256 CUs x 4 SIMD x 32 lanes x 2.4 GHz (max clock) int32 VALU lane-ops/s
-VALU_PEAK_OPS = 256 * 4 * 32 * 2.4e9
-KECCAK_OPS = 4020.0  # VALU instructions per permutation in k_keccak_* (2756 v_bitop3 + 1204 v_alignbit + misc)
+# int-VALU issue peak the Keccak kernels are priced against: 256 CUs x 4 SIMDs x 32 lane-instructions per clock
+# (both VALU pipes) x 2.4 GHz.  Only v_bitop3 (and a few other simple ops) can use the second pipe; rotates cannot,
+# so the ceiling for the Keccak instruction mix is ~0.65 of this.
+VALU_PEAK_TOPS = 256 * 4 * 32 * 2.4e9 / 1e12
 
 
-def cpu_baseline(nv, program, num_lookups, sample_cols):
-    """Reference algorithm on the host CPU (oracle = literal C port, 1 thread) on a bounded sample of the same
-    workload: `sample_cols` of the 43 columns through commit + eval + open exactly as prover.zig:405-431 does
-    (scaled x43/sample_cols), plus the sequential transcript at the measured single-thread SHA3 rate."""
+def isa_counts():
+    """VALU instructions per hash of the Keccak kernels, counted from the gfx950 code (tools/isa_counts.py)."""
+    with open(os.path.join(ROOT, "profiles", "isa_counts.json")) as f:
+        k = json.load(f)["kernels"]
+    return {"leaves": k["k_keccak_leaves"]["valu"], "level": k["k_keccak_level<4>"]["valu"]}
+
+
+# ------------------------------------------------------------------ N > 1: self-launch (parent never touches the GPU)
+def free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(n, argv):
+    """Start n ranks as a child torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has
+    imported torch or loaded HIP at this point (tests/test_bench_launch.py asserts it)."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(free_port()), os.path.abspath(__file__)] + argv
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["ZIGZ_BENCH_LAUNCHED"] = "1"
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    line = None
+    for ln in proc.stdout:
+        t = ln.strip()
+        if t.startswith("{") and t.endswith("}"):
+            line = t
+        else:
+            sys.stderr.write(ln)
+    rc = proc.wait()
+    if line:
+        print(line, flush=True)
+    if rc == 0 and not line:
+        sys.stderr.write("bench.py: the ranks exited without printing a result line\n")
+        rc = 1
+    return rc
+
+
+# ------------------------------------------------------------------ CPU baseline (child process; the only oracle user)
+def cpu_baseline_child(nv, sample_cols):
+    """Runs in a process of its own, BEFORE the parent initialises the GPU: the reference algorithm on one host core
+    (oracle = literal C restatement, -O2, 1 thread) on a bounded sample of the same workload, every part timed for real:
+    `sample_cols` of the 43 columns through commit + eval + open exactly as prover.zig:405-431 does it (2N-1 hashes,
+    two naive O(v 2^v) evals, recompute-on-open), scaled x43/sample_cols, plus the complete sequential transcript of
+    steps [4/6]-[5/6] (prover.zig:229-363, one absorption pair per lookup step) run once in full."""
+    import ctypes as C
     import oracle_lib as O
+    import programs
     P = O.P_BB
-    cols, nv_o, ns = O.witness_from_program(P, program, 0x1000, None, 1 << (nv + 1))
+    N = 1 << nv
+    prog = programs.add_xor_loop((N - 3) // 4)
+    cols, nv_o, ns = O.witness_from_program(P, prog, 0x1000, None, 2 * N)
     assert nv_o == nv
+    num_lookups = O.vm_trace(prog, 0x1000, None, 2 * N)["num_lookups"]
     pts = O.splitmix64_field(99, sample_cols * nv).reshape(sample_cols, nv)
     t0 = time.perf_counter()
     for c in range(sample_cols):
         O.commit_column_literal(P, cols[(c * 43) // sample_cols], pts[c])
     t_cols = time.perf_counter() - t0
-    nbytes = 19 * num_lookups + 40 * nv + 43 * 32 * (1 + nv)  # LASSO_TABLE absorptions dominate the sponge input
-    buf = bytes(min(nbytes, 1 << 22))
+    f = O.lib.orc_prove_transcript_only
+    f.restype = C.c_uint64
+    f.argtypes = [C.c_uint64, C.c_char_p, C.c_uint64, C.c_size_t, C.c_size_t, C.c_size_t]
     t0 = time.perf_counter()
-    O.sha3_256(buf)
-    t_transcript = (time.perf_counter() - t0) * (nbytes / len(buf))
-    total = t_cols * (43.0 / sample_cols) + t_transcript
-    return {"value": ns / total, "unit": "trace steps/s", "cores": 1, "kind": "port",
-            "sample": "%d of 43 columns at 2^%d through commit + 2 naive evals + recompute-on-open (%.1f s), scaled "
-                      "x43/%d; + %d B of sequential transcript at the measured 1-thread SHA3 rate (%.0f ms); "
-                      "oracle/zigz_oracle.c, gcc -O3" % (sample_cols, nv, t_cols, sample_cols, nbytes, t_transcript * 1e3),
-            "seconds_per_proof_est": total}
+    f(P, bytes(32), 0x1000, ns, nv, num_lookups)
+    t_tr = time.perf_counter() - t0
+    total = t_cols * (43.0 / sample_cols) + t_tr
+    model = "unknown"
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    print(json.dumps({
+        "value": ns / total, "unit": "trace steps/s", "cores": 1, "kind": "port",
+        "sample": "%d of 43 columns at 2^%d through literal commit + 2 naive evals + recompute-on-open (%.1f s measured), "
+                  "scaled x43/%d; + the full sequential transcript of steps 4-5 (%d lookup absorptions) run for real (%.3f s "
+                  "measured); oracle/zigz_oracle.c, gcc -O2, 1 thread" % (sample_cols, nv, t_cols, sample_cols, num_lookups, t_tr),
+        "seconds_per_proof": total, "transcript_seconds": t_tr, "columns_seconds_scaled": t_cols * 43.0 / sample_cols,
+        "host_cpu": model, "host_nproc": os.cpu_count(), "threads_used": 1}))
+
+
+def run_cpu_baseline(nv, sample_cols):
+    out = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--nv", str(nv),
+                          "--cpu-sample-cols", str(sample_cols)], stdout=subprocess.PIPE, text=True, check=True)
+    return json.loads(out.stdout.strip().split("\n")[-1])
+
+
+# ------------------------------------------------------------------ per-kernel leg
+def kernel_leg(ctx, nv, ncols, iters, cold=True, big_nv=24):
+    """Cold-HBM launches of the hot kernels on synthetic resident tables, kernel timestamps (zigz_bench_kernel)."""
+    ic = isa_counts()
+    res = {}
+
+    def hbm(name, knv, kcols):
+        r = ctx.bench_kernel(name, knv, kcols, iters, cold)
+        gbs = r["algorithmic_bytes"] / 1e9 / (r["avg_us"] / 1e6)
+        res["%s[%dx2^%d]" % (name, kcols, knv)] = {
+            "bound": "hbm", "avg_us": r["avg_us"], "min_us": r["min_us"], "max_us": r["max_us"], "launches": r["launches"],
+            "algorithmic_bytes": r["algorithmic_bytes"], "achieved_GBs": gbs, "frac": gbs / HBM_PEAK_GBS,
+            "best_frac": r["algorithmic_bytes"] / 1e9 / (r["min_us"] / 1e6) / HBM_PEAK_GBS}
+        return res["%s[%dx2^%d]" % (name, kcols, knv)]
+
+    def valu(name, knv, kcols, instr):
+        r = ctx.bench_kernel(name, knv, kcols, iters, cold)
+        gperm = r["units"] / 1e9 / (r["avg_us"] / 1e6)
+        res["%s[%dx2^%d]" % (name, kcols, knv)] = {
+            "bound": "valu", "avg_us": r["avg_us"], "min_us": r["min_us"], "max_us": r["max_us"], "launches": r["launches"],
+            "permutations": r["units"], "gperm_per_s": gperm, "valu_instr_per_hash": instr,
+            "achieved_Tinstr_s": gperm * instr / 1e3, "frac": gperm * instr / 1e3 / VALU_PEAK_TOPS,
+            "hbm_frac": r["algorithmic_bytes"] / 1e9 / (r["avg_us"] / 1e6) / HBM_PEAK_GBS}
+        return res["%s[%dx2^%d]" % (name, kcols, knv)]
+
+    hbm("k_bind_vec", nv, ncols)        # partialEval of all columns at once: the batched bind of eval-by-folds
+    hbm("k_bind_vec_sums", nv, ncols)   # fused with the next round's half sums (sumcheck_core)
+    hbm("k_half_sums_vec", nv, ncols)   # roundPolynomial / sumOverHypercube
+    hbm("k_radix_fold", nv, ncols)      # eval: top v-10 variables in one pass
+    if big_nv:
+        hbm("k_bind_vec", big_nv, 1)        # one 2^24 table (config 5 row count)
+        hbm("k_bind_vec_sums", big_nv, 1)
+        hbm("k_half_sums_vec", big_nv, 1)
+        hbm("k_block_sums", big_nv, 1)      # radix sumcheck pass 1
+    valu("k_keccak_leaves", nv, ncols, ic["leaves"])
+    valu("k_keccak_level", nv, ncols, ic["level"])
+    return res
 
 
 def main():
@@ -67,24 +182,65 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=4, help="independent traces proven concurrently per GPU per step "
-                    "(one proof alone is bound by its sequential host transcript; 4 lanes saturate the GPU; 6 give +2 %% "
-                    "but the MLE kernel then waits for CU slots behind other proofs' Keccak workgroups, which distorts "
-                    "the per-launch roofline figure)")
+                    "(one proof alone is bound by its sequential host transcript; 4 lanes saturate the GPU)")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
-                    "scaling.  shard: ONE proof per step, its 43 columns sharded over the GPUs (two all-gathers of 43 x "
-                    "32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the sequential host transcript "
-                    "that every rank replays (DESIGN.md s7)")
+                    "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
+                    "GPUs (two all-gathers of 43 x 32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the "
+                    "sequential host transcript that every rank replays (DESIGN.md s7)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
                     "the headline is measured with the dense, data-independent build")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=12, help="columns of the CPU baseline sample (~1.1 s each)")
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--kernels", action="store_true", help="per-kernel leg only (cold-HBM launches, kernel timestamps)")
+    ap.add_argument("--kernel-iters", type=int, default=10)
+    ap.add_argument("--no-extras", action="store_true", help="skip the single-proof, PCIe-inclusive and per-kernel legs")
+    ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, "
+                    "all-reduce a token and rank 0 prints {dry_run, n_gpus}; nothing is measured")
     args = ap.parse_args()
+
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args.nv, args.cpu_sample_cols)
+        return 0
+
+    # ---- N > 1 without a launcher: become the launcher.  No torch / HIP import has happened in this process.
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        assert "torch" not in sys.modules and "zigz_amd" not in sys.modules
+        return launch_ranks(args.gpus, sys.argv[1:])
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        sys.stderr.write("bench.py: --gpus %d but the launcher started %d ranks (WORLD_SIZE); refusing to report a wrong "
+                         "n_gpus\n" % (args.gpus, world))
+        return 2
+
+    if args.dry_run:
+        tok = 1.0
+        if world > 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            import torch
+            import torch.distributed as dist
+            dist.init_process_group(backend="gloo")
+            t = torch.tensor([1.0], dtype=torch.float64)
+            dist.all_reduce(t)
+            tok = float(t.item())
+            dist.barrier()
+            dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"dry_run": True, "n_gpus": world, "ranks_seen": tok,
+                              "launched_by_bench": os.environ.get("ZIGZ_BENCH_LAUNCHED") == "1"}), flush=True)
+        return 0
+
+    # ---- CPU baseline first (rank 0, N = 1 only), in a child of its own: the GPU phase that follows is then one
+    # contiguous stretch, and this process never loads the oracle
+    cpu = None
+    if world == 1 and not args.no_cpu_baseline and not args.kernels:
+        cpu = run_cpu_baseline(args.nv, args.cpu_sample_cols)
+
     dist = None
     torch = None
     backend = os.environ.get("ZIGZ_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a 1-GPU box
@@ -92,13 +248,15 @@ def main():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist
+        ndev = torch.cuda.device_count()  # does not initialise HIP
+        if backend == "nccl" and ndev < world:
+            backend = "gloo"  # fewer GPUs than ranks (rehearsal on a 1-GPU box): RCCL cannot put two ranks on one device
+        local_rank = local_rank % max(ndev, 1)
         if backend == "nccl":
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)  # tolerates a launcher that masks devices per rank
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend=backend)
-            local_rank = local_rank % max(torch.cuda.device_count(), 1)
     tdev = "cuda" if backend == "nccl" else "cpu"
 
     import zigz_amd
@@ -109,6 +267,15 @@ def main():
 
     nv = args.nv
     N = 1 << nv
+
+    if args.kernels:
+        ctx = zigz_amd.Context(local_rank)
+        res = kernel_leg(ctx, nv, 43, args.kernel_iters)
+        ctx.close()
+        print(json.dumps({"kernels": res, "cold": True, "iters": args.kernel_iters,
+                          "hbm_peak_GBs": HBM_PEAK_GBS, "valu_peak_Tinstr_s": VALU_PEAK_TOPS}), flush=True)
+        return 0
+
     shard = args.mode == "shard"
     B = 1 if shard else max(1, args.batch)
 
@@ -133,6 +300,10 @@ def main():
                 self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
 
+        def upload_and_prove(self):  # PCIe-inclusive: the trace crosses PCIe and the witness kernels run inside the loop
+            self.trace.witness_to_device(self.ctx, self.d_cols, N)
+            return self.prove()
+
     allgather_hook = host.make_allgather(dist) if (shard and dist is not None) else None
     lanes = [Lane(k) for k in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
@@ -145,41 +316,59 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
-    def run_step():
-        return [f.result() for f in [pool.submit(l.prove) for l in lanes]]
+    def run_step(fn=Lane.prove, which=None):
+        ls = lanes if which is None else which
+        return [f.result() for f in [pool.submit(fn, l) for l in ls]]
+
+    def timed(steps, fn=Lane.prove, which=None):
+        """exactly `steps` steps between barrier + synchronize brackets; returns (seconds, accumulated stats)"""
+        acc = {}
+        phases = {}
+        sync_all()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            for st, ph in run_step(fn, which):
+                for k, v in st.items():
+                    acc[k] = acc.get(k, 0) + v
+                for k, v in ph.items():
+                    phases[k] = phases.get(k, 0.0) + v
+        sync_all()
+        return time.perf_counter() - t0, acc, phases
 
     run_step()  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
     for _ in range(args.warmup):
         run_step()
     for l in lanes:
         l.ctx.enable_timing(True)
-    bind_us = bind_bytes = bind_launches = 0
-    merkle_us = eval_us = 0.0
-    perms = 0
-    phases = {}
-    sync_all()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        for st, ph in run_step():
-            bind_us += st["bind_vec_us"]; bind_bytes += st["bind_vec_bytes"]; bind_launches += st["bind_vec_launches"]
-            merkle_us += st["merkle_build_us"]; eval_us += st["eval_us"]; perms += st["keccak_permutations"]
-            for k, v in ph.items():
-                phases[k] = phases.get(k, 0.0) + v
-    sync_all()
-    dt = time.perf_counter() - t0
-    # the same kernel with the GPU otherwise idle (one more proof on lane 0 alone), outside the timed region:
-    # under --batch > 1 the timed-region launches share the chip with other proofs' Keccak kernels
-    solo_runs = [lanes[0].prove()[0] for _ in range(3)]
-    solo_st = {k: sum(r[k] for r in solo_runs) / len(solo_runs) for k in solo_runs[0]}
+    dt, acc, phases = timed(args.steps)          # ---- THE timed region
+    nproofs = args.steps * B
+
+    # ---- legs outside the timed region (same run, same resident data)
+    extras = not args.no_extras and not shard
+    solo = pcie = kern = None
+    if extras:
+        ksolo = max(3, min(args.steps, 8))
+        run_step(which=lanes[:1])
+        dts, accs, _ = timed(ksolo, which=lanes[:1])           # one proof at a time on the GPU
+        solo = {"dt": dts, "n": ksolo, "acc": accs}
+        run_step(Lane.upload_and_prove)
+        dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
+        pcie = {"dt": dtp}
+        if rank == 0:
+            kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
+
     local_steps = float(sum(l.trace.num_steps for l in lanes))
     trace = lanes[0].trace
     prog = lanes[0].prog
     proof = lanes[0].proof
-    nproofs = args.steps * B
     if torch is not None:
-        t = torch.tensor([dt], dtype=torch.float64, device=tdev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        def allmax(x):
+            t = torch.tensor([x], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            return float(t.item())
+        dt = allmax(dt)
+        if pcie:
+            pcie["dt"] = allmax(pcie["dt"])
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
@@ -189,14 +378,64 @@ def main():
     if rank == 0:
         proof = proof.tobytes()
         assert host.verify(proof, prog) == "Accept"
-        ach = (bind_bytes / 1e9) / (bind_us / 1e6) if bind_us > 0 else 0.0
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "bind_traffic.json")
+        ic = isa_counts()
+        perms_leaves = acc["keccak_leaves_perms"]
+        # dominant kernel: k_keccak_leaves.  Per-launch kernel timestamps, all launches of the timed region
+        tr_ach = perms_leaves * ic["leaves"] / (acc["keccak_leaves_us"] / 1e6) / 1e12 if acc.get("keccak_leaves_us") else 0.0
+        keccak_us = acc["keccak_leaves_us"] + acc["keccak_level_wide_us"] + acc["keccak_level_small_us"]
+        roof = {
+            "kernel": "k_keccak_leaves (SHA3-256 leaf hashes of the 43 witness columns: 1 Keccak-f[1600] = %d VALU instructions "
+                      "per 4 B read + 32 B written; the dominant kernel, %.0f %% of the kernel time of a proof)"
+                      % (ic["leaves"], 100.0 * acc["keccak_leaves_us"] / max(keccak_us + acc["eval_us"], 1e-9)),
+            "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
+            "valu_instr_per_hash": ic["leaves"],
+            "timed_region_achieved": tr_ach, "timed_region_frac": tr_ach / VALU_PEAK_TOPS,
+            "timed_region_avg_launch_us": acc["keccak_leaves_us"] / nproofs,
+            "timed_region_note": "launches of %d concurrent proofs share the chip: per-launch durations stretch by the overlap"
+                                 % B if B > 1 else "one proof at a time",
+            "traffic": None,
+        }
+        tpath = os.path.join(ROOT, "profiles", "keccak_traffic.json")
         if os.path.exists(tpath):
             try:
-                traffic = json.load(open(tpath)).get("hbm_bytes_per_launch")
+                tj = json.load(open(tpath))
+                roof["traffic"] = tj.get("hbm_bytes_per_launch")
+                roof["traffic_source"] = tj.get("source", "profiles/keccak_traffic.json") + " (rocprofv3 PMC passes of this command; not re-measured in this run)"
             except Exception:
-                traffic = None
+                pass
+        if solo:
+            a = solo["acc"]
+            ach = a["keccak_leaves_perms"] * ic["leaves"] / (a["keccak_leaves_us"] / 1e6) / 1e12
+            roof.update({
+                "achieved": ach, "frac": ach / VALU_PEAK_TOPS,
+                "measured": "kernel timestamps of the %d k_keccak_leaves launches of the single-proof leg of this run (one "
+                            "proof on the GPU at a time, right after the timed region)" % solo["n"],
+                "avg_launch_us": a["keccak_leaves_us"] / solo["n"],
+                "gperm_per_s": a["keccak_leaves_perms"] / 1e9 / (a["keccak_leaves_us"] / 1e6),
+                "hbm_frac": a["keccak_leaves_perms"] * 36 / 1e9 / (a["keccak_leaves_us"] / 1e6) / HBM_PEAK_GBS,
+                "level_wide_gperm_per_s": a["keccak_level_wide_perms"] / 1e9 / (a["keccak_level_wide_us"] / 1e6),
+                "level_wide_frac": a["keccak_level_wide_perms"] * ic["level"] / (a["keccak_level_wide_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS,
+                "level_small_gperm_per_s": (a["keccak_level_small_perms"] / 1e9 / (a["keccak_level_small_us"] / 1e6))
+                if a["keccak_level_small_us"] else None,
+                "merkle_build_ms": a["merkle_build_us"] / solo["n"] / 1e3,
+                "merkle_build_gperm_per_s": a["keccak_permutations"] / 1e9 / (a["merkle_build_us"] / 1e6),
+                "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1),
+                "eval_fold_hbm_frac": (a["bind_vec_bytes"] / 1e9) / (a["bind_vec_us"] / 1e6) / HBM_PEAK_GBS if a["bind_vec_us"] else None,
+            })
+        else:
+            roof.update({"achieved": tr_ach, "frac": tr_ach / VALU_PEAK_TOPS, "measured": "timed region"})
+        if kern:  # the north-star MLE kernels, cold-HBM launches in this run (flat keys: the driver keeps scalars only)
+            for key, name in (("bind", "k_bind_vec[43x2^%d]" % nv), ("bind_sums", "k_bind_vec_sums[43x2^%d]" % nv),
+                              ("half_sums", "k_half_sums_vec[43x2^%d]" % nv), ("radix_fold", "k_radix_fold[43x2^%d]" % nv),
+                              ("bind_2p24", "k_bind_vec[1x2^24]"), ("bind_sums_2p24", "k_bind_vec_sums[1x2^24]"),
+                              ("half_sums_2p24", "k_half_sums_vec[1x2^24]"), ("block_sums_2p24", "k_block_sums[1x2^24]")):
+                if name in kern:
+                    roof[key + "_hbm_frac"] = kern[name]["frac"]
+                    roof[key + "_GBs"] = kern[name]["achieved_GBs"]
+                    roof[key + "_avg_us"] = kern[name]["avg_us"]
+            roof["mle_kernels_note"] = ("k_bind_vec = partialEval (6 B per table element), k_half_sums_vec / k_block_sums = "
+                                        "roundPolynomial (4 B), cold-HBM launches (1 GiB read sweep before each), kernel "
+                                        "timestamps, same process right after the timed region")
         out = {
             "metric": "trace steps/sec proved (BabyBear, 2^%d RV64I trace)" % nv,
             "value": total_steps * args.steps / dt,
@@ -211,34 +450,34 @@ def main():
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
                        "merkle_build": "run-aware (merkle_dedup)" if args.dedup else "dense",
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
-                       "parallelism": ("one proof per step, 43 columns sharded over %d GPU(s)" % world) if shard else
-                                      "independent traces: %d GPU x %d concurrent proofs" % (world, B)},
-            "roofline": {"kernel": "k_radix_fold (MLE bind of the top v-10 variables of all 43 columns in one pass: the bulk "
-                                   "of the 43 evals inside the timed region; 4 B read per element + partial sums)",
-                         "bound": "hbm", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": ach / HBM_PEAK_GBS, "traffic": traffic,
-                         "uncontended": {"achieved": (solo_st["bind_vec_bytes"] / 1e9) / (solo_st["bind_vec_us"] / 1e6),
-                                         "frac": (solo_st["bind_vec_bytes"] / 1e9) / (solo_st["bind_vec_us"] / 1e6) / HBM_PEAK_GBS,
-                                         "note": "same launches, one proof at a time on the GPU right after the timed region (mean of 3)"},
-                         "launches_per_proof": bind_launches / nproofs,
-                         "avg_launch_us": bind_us / max(bind_launches, 1),
-                         "algorithmic_bytes_per_launch": bind_bytes / max(bind_launches, 1)},
-            "kernels": {"merkle_build_ms_per_proof": merkle_us / nproofs / 1e3,
-                        "eval_ms_per_proof": eval_us / nproofs / 1e3,
-                        "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
-                        "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode(),
-                        # Keccak Merkle build of ONE proof alone on the GPU (the per-proof figures above are wall
-                        # times of concurrent lanes): permutations/s and the share of the int-VALU issue peak
-                        "uncontended": {
-                            "merkle_build_ms": solo_st["merkle_build_us"] / 1e3,
-                            "keccak_gperm_per_s": (solo_st["keccak_permutations"] / 1e9) / (solo_st["merkle_build_us"] / 1e6),
-                            "keccak_frac_of_int_valu_peak": (solo_st["keccak_permutations"] * KECCAK_OPS /
-                                                             (solo_st["merkle_build_us"] / 1e6)) / VALU_PEAK_OPS,
-                            "eval_ms": solo_st["eval_us"] / 1e3},
-                        "gpu_busy_keccak_gperm_per_s": (perms / 1e9) / dt},
+                       "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
+                                       "sequential host transcript every rank replays" % world) if shard else
+                                      ("independent-trace throughput: %d GPU(s) x %d concurrent proofs, one rank per GPU, no "
+                                       "data-path collective (one proof does not get faster with more GPUs: see --mode shard)"
+                                       % (world, B)),
+                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none"},
+            "roofline": roof,
         }
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(nv, prog, trace.num_lookups, args.cpu_sample_cols)
+        if solo:
+            out["config"]["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
+            out["config"]["single_proof_steps_per_s"] = trace.num_steps * solo["n"] / solo["dt"]
+        if pcie:
+            out["config"]["pcie_inclusive_value"] = total_steps * args.steps / pcie["dt"]
+            out["config"]["pcie_inclusive_ms_per_step"] = pcie["dt"] / args.steps * 1e3
+            out["config"]["pcie_inclusive_note"] = ("same batch, but every proof first uploads its trace over PCIe and runs the "
+                                                    "witness kernels inside the loop (never reported as value)")
+        out["kernels"] = {"timed_region": {
+            "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,
+            "keccak_leaves_ms_per_proof": acc["keccak_leaves_us"] / nproofs / 1e3,
+            "keccak_level_wide_ms_per_proof": acc["keccak_level_wide_us"] / nproofs / 1e3,
+            "keccak_level_small_ms_per_proof": acc["keccak_level_small_us"] / nproofs / 1e3,
+            "eval_ms_per_proof": acc["eval_us"] / nproofs / 1e3,
+            "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
+            "gpu_busy_keccak_gperm_per_s": (acc["keccak_permutations"] / 1e9) / dt},
+            "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode(),
+            "cold_hbm_launches": kern}
+        if cpu is not None:
+            out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
     pool.shutdown()
     for l in lanes:
@@ -247,7 +486,8 @@ def main():
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+    return 0
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main())

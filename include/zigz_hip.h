@@ -232,7 +232,31 @@ typedef struct zigz_kernel_stats {
      * them were uniform (0 / 0 when the option is off or the trees are smaller than 2^17 leaves) */
     uint64_t merkle_blocks;
     uint64_t merkle_uniform_blocks;
+    /* Keccak launches of the last batched commit by class, each launch timed with its own begin / end timestamps
+     * (kernel time as rocprofv3 --kernel-trace reports it; the gaps between launches are in merkle_build_us only):
+     * k_keccak_leaves; k_keccak_level<4> (the large levels); k_keccak_level<1> (the small levels); hashes = permutations */
+    double keccak_leaves_us;
+    uint64_t keccak_leaves_perms;
+    double keccak_level_wide_us;
+    uint64_t keccak_level_wide_perms;
+    double keccak_level_small_us;
+    uint64_t keccak_level_small_perms;
 } zigz_kernel_stats;
+/* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
+ * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per
+ * table element), "k_bind_vec_sums" (the same fused with the next roundPolynomial), "k_half_sums_vec" / "k_block_sums"
+ * (roundPolynomial / sumOverHypercube, multilinear.zig:188-232, 4 B per element; k_block_sums: ncols = 1),
+ * "k_radix_fold" (eval, multilinear.zig:110-144, 4 B per element + partial sums), "k_keccak_leaves" / "k_keccak_level"
+ * (hash.zig:135-147,187-195; units = permutations), "k_lasso_fingerprints" (lasso_prover.zig:208-239; units = rows of 3
+ * fields).  cold != 0: a 1 GiB read sweep before every launch empties L2 / Infinity Cache of the table. */
+typedef struct zigz_bench_result {
+    double avg_us, min_us, max_us;
+    uint64_t algorithmic_bytes; /* per launch */
+    uint64_t units;             /* table elements / permutations / rows per launch */
+    uint32_t launches;
+} zigz_bench_result;
+zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size_t nv, size_t ncols, int iters, int cold,
+                              zigz_bench_result *out);
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
 /* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
  * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;

@@ -1215,6 +1215,40 @@ static void w_u8(wbuf *w, uint8_t v) { w->b[w->pos++] = v; }
 static void w_u32(wbuf *w, uint32_t v) { for (int i = 0; i < 4; i++) w->b[w->pos++] = (uint8_t)(v >> (8 * i)); }
 static void w_u64(wbuf *w, uint64_t v) { le64(v, w->b + w->pos); w->pos += 8; }
 
+/* Steps [4/6] and [5/6] of Prover.prove as far as they are observable: generateSumcheckProof (prover.zig:229-289:
+ * zero round polynomials, nv challenges) and generateLassoProofs (prover.zig:292-363: one "LASSO_TABLE" + LE64(i)
+ * absorption per lookup step, placeholders with num_lookups = 1 => 0 variables).  cpoint may be NULL. */
+static void prove_transcript_steps_4_5(uint64_t p, orc_transcript *tr, size_t ns, size_t nv, size_t L, uint64_t *cpoint) {
+    tr_append_str(tr, "SUMCHECK_BEGIN");
+    orc_tr_append_field(tr, (uint64_t)ns % p);
+    orc_tr_append_field(tr, (uint64_t)nv % p);
+    for (size_t r = 0; r < nv; r++) {
+        for (int k = 0; k < 4; k++) orc_tr_append_field(tr, 0);
+        uint64_t ch = orc_tr_challenge(tr, p);
+        if (cpoint) cpoint[r] = ch;
+    }
+    tr_append_str(tr, "LASSO_BEGIN");
+    for (size_t i = 0; i < L; i++) {
+        tr_append_str(tr, "LASSO_TABLE");
+        orc_tr_append_field(tr, (uint64_t)(uint32_t)i % p);
+    }
+}
+
+/* The same two steps on a fresh transcript bound to (program_hash, entry_pc): the sequential sponge work of one proof,
+ * exported so bench.py's cpu_baseline leg can time it for real (returns the next challenge so the work cannot be
+ * optimised away).  Not a reference function by itself: it is the part of orc_prove above, run alone. */
+uint64_t orc_prove_transcript_only(uint64_t p, const uint8_t program_hash[32], uint64_t entry_pc, size_t ns, size_t nv,
+                                   size_t L) {
+    orc_transcript *tr = orc_tr_new();
+    if (!tr) return 0;
+    orc_tr_append_bytes(tr, program_hash, 32);
+    orc_tr_append_field(tr, entry_pc % p);
+    prove_transcript_steps_4_5(p, tr, ns, nv, L, NULL);
+    uint64_t ch = orc_tr_challenge(tr, p);
+    orc_tr_free(tr);
+    return ch;
+}
+
 int orc_prove(uint64_t p, const uint8_t *program, size_t program_len, uint64_t entry_pc,
               const uint64_t *initial_regs, size_t n_initial_regs, int has_initial_regs, size_t max_steps,
               const uint64_t *input, size_t n_input, uint8_t **proof_out, size_t *proof_len,
@@ -1258,21 +1292,8 @@ int orc_prove(uint64_t p, const uint8_t *program, size_t program_len, uint64_t e
     size_t L = 0;
     for (size_t i = 0; i < ns; i++) L += t->is_lookup[i];
 
-    /* [4/6] generateSumcheckProof, :229-289: zero round polys, challenges only */
-    tr_append_str(tr, "SUMCHECK_BEGIN");
-    orc_tr_append_field(tr, (uint64_t)ns % p);
-    orc_tr_append_field(tr, (uint64_t)nv % p);
-    for (size_t r = 0; r < nv; r++) {
-        for (int k = 0; k < 4; k++) orc_tr_append_field(tr, 0);
-        cpoint[r] = orc_tr_challenge(tr, p);
-    }
-
-    /* [5/6] generateLassoProofs, :292-363: placeholders, num_lookups = 1 => 0 variables */
-    tr_append_str(tr, "LASSO_BEGIN");
-    for (size_t i = 0; i < L; i++) {
-        tr_append_str(tr, "LASSO_TABLE");
-        orc_tr_append_field(tr, (uint64_t)(uint32_t)i % p);
-    }
+    /* [4/6] + [5/6]: transcript-only steps (zero round polys, Lasso placeholders) */
+    prove_transcript_steps_4_5(p, tr, ns, nv, L, cpoint);
 
     /* [6/6] generateCommitments */
     rc = orc_generate_commitments(p, tr, cols, nv, roots, points, values, indices, leaves, siblings, dirs);

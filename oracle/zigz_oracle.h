@@ -194,6 +194,10 @@ int orc_prove(uint64_t p, const uint8_t *program, size_t program_len, uint64_t e
               uint8_t **proof_out, size_t *proof_len, size_t *num_steps_out);
 /* generateCommitments on given columns (prover.zig:366-467) continuing transcript `t`:
  * roots[43*32], points[43*nv], values[43], indices[43], leaves[43], siblings[43*nv*32], dirs[43*nv] */
+/* steps [4/6] + [5/6] of orc_prove alone on a fresh transcript (the sequential sponge work of one proof); used by
+ * bench.py's cpu_baseline leg to time the transcript for real */
+uint64_t orc_prove_transcript_only(uint64_t p, const uint8_t program_hash[32], uint64_t entry_pc, size_t num_steps,
+                                   size_t nv, size_t num_lookups);
 int orc_generate_commitments(uint64_t p, orc_transcript *t, const uint64_t *cols, size_t nv,
                              uint8_t *roots, uint64_t *points, uint64_t *values, uint64_t *indices,
                              uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);

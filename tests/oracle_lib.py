@@ -333,6 +333,42 @@ def witness_from_program(p, program, entry_pc, initial_regs=None, max_steps=1 <<
         lib.orc_trace_free(tr)
 
 
+class OrcTrace(C.Structure):  # struct orc_trace of oracle/zigz_oracle.h
+    _fields_ = [("num_steps", C.c_size_t), ("capacity", C.c_size_t), ("pc", u64p), ("regs_after", u64p),
+                ("opcode", u8p), ("rd", u8p), ("rs1", u8p), ("rs2", u8p), ("funct3", u8p), ("funct7", u8p),
+                ("imm", C.POINTER(C.c_int64)), ("mem_kind", u8p), ("mem_addr", u64p), ("mem_value", u64p),
+                ("is_lookup", u8p), ("final_pc", C.c_uint64), ("final_regs", C.c_uint64 * 32), ("outputs", u64p),
+                ("n_outputs", C.c_size_t), ("cap_outputs", C.c_size_t), ("halted", C.c_int)]
+
+
+def vm_trace(program, entry_pc, initial_regs=None, max_steps=1 << 20, inputs=None):
+    """The oracle VM's execution trace (the loop of prover.zig:117-142) as numpy arrays, one entry per recorded step:
+    pc, regs_after[ns,32], opcode, rd, rs1, rs2, funct3, funct7, imm (int64), mem_kind (0 none / 1 load / 2 store),
+    mem_addr, mem_value, is_lookup; plus num_steps and num_lookups."""
+    tr = lib.orc_trace_new()
+    try:
+        ir, irp = (_u64(initial_regs) if initial_regs is not None and len(initial_regs) else _out_u64(1))
+        inp, inpp = (_u64(inputs) if inputs is not None and len(inputs) else _out_u64(1))
+        _chk(lib.orc_vm_run(bytes(program), len(program), entry_pc, irp, 0 if initial_regs is None else len(initial_regs),
+                            max_steps, inpp, 0 if inputs is None else len(inputs), tr))
+        t = C.cast(tr, C.POINTER(OrcTrace)).contents
+        ns = t.num_steps
+
+        def arr(ptr, n, dt):
+            return np.ctypeslib.as_array(ptr, shape=(max(n, 1),))[:n].astype(dt, copy=True) if n else np.zeros(0, dtype=dt)
+        out = {"num_steps": ns}
+        for k in ("pc", "mem_addr", "mem_value"):
+            out[k] = arr(getattr(t, k), ns, np.uint64)
+        out["regs_after"] = arr(t.regs_after, ns * 32, np.uint64).reshape(ns, 32)
+        for k in ("opcode", "rd", "rs1", "rs2", "funct3", "funct7", "mem_kind", "is_lookup"):
+            out[k] = arr(getattr(t, k), ns, np.uint8)
+        out["imm"] = arr(t.imm, ns, np.int64)
+        out["num_lookups"] = int(out["is_lookup"].sum())
+        return out
+    finally:
+        lib.orc_trace_free(tr)
+
+
 def prove(p, program, entry_pc=0x1000, initial_regs=None, max_steps=1 << 20, inputs=None):
     ir, irp = (_u64(initial_regs) if initial_regs is not None and len(initial_regs) else _out_u64(1))
     inp, inpp = (_u64(inputs) if inputs is not None and len(inputs) else _out_u64(1))

@@ -70,3 +70,29 @@ def test_product_never_imports_oracle():
                 if f.endswith((".py", ".cpp", ".hpp", ".hip", ".h")):
                     txt = open(os.path.join(d, f), errors="replace").read()
                     assert "oracle_lib" not in txt and "zigz_oracle" not in txt and "orc_" not in txt, os.path.join(d, f)
+
+
+def test_isa_counts_match_the_built_kernels():
+    """bench.py prices Keccak permutations/s with the VALU instruction count per hash read from
+    profiles/isa_counts.json: re-derive it from the gfx950 assembly of the current kernels.hip."""
+    import json
+    import shutil
+    import sys
+    if not (shutil.which("hipcc") or os.path.exists("/opt/rocm/bin/hipcc")):
+        pytest.skip("hipcc not available")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import isa_counts
+    now = isa_counts.count(isa_counts.assembly())
+    committed = json.load(open(os.path.join(ROOT, "profiles", "isa_counts.json")))["kernels"]
+    for k in ("k_keccak_leaves", "k_keccak_level<4>", "k_keccak_level<1>"):
+        for f in ("valu", "v_bitop3", "v_alignbit"):
+            assert now[k][f] == committed[k][f], (k, f, now[k][f], committed[k][f])
+    assert 3500 < now["k_keccak_leaves"]["valu"] < 4500  # one fully unrolled Keccak-f[1600] per function body
+
+
+def test_bench_timed_region_does_not_use_the_oracle():
+    """bench.py may touch the oracle only in its cpu_baseline child process."""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    body = src.split("def cpu_baseline_child", 1)[1].split("def run_cpu_baseline", 1)[0]
+    rest = src.replace(body, "")
+    assert "oracle_lib" in body and "oracle_lib" not in rest and "orc_" not in rest

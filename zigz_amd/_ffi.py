@@ -24,7 +24,15 @@ class KernelStats(C.Structure):
     _fields_ = [("merkle_build_us", C.c_double), ("eval_us", C.c_double), ("path_us", C.c_double),
                 ("bind_us", C.c_double), ("bind_launches", C.c_uint64), ("keccak_permutations", C.c_uint64),
                 ("bind_vec_us", C.c_double), ("bind_vec_launches", C.c_uint64), ("bind_vec_bytes", C.c_uint64),
-                ("merkle_blocks", C.c_uint64), ("merkle_uniform_blocks", C.c_uint64)]
+                ("merkle_blocks", C.c_uint64), ("merkle_uniform_blocks", C.c_uint64),
+                ("keccak_leaves_us", C.c_double), ("keccak_leaves_perms", C.c_uint64),
+                ("keccak_level_wide_us", C.c_double), ("keccak_level_wide_perms", C.c_uint64),
+                ("keccak_level_small_us", C.c_double), ("keccak_level_small_perms", C.c_uint64)]
+
+
+class BenchResult(C.Structure):
+    _fields_ = [("avg_us", C.c_double), ("min_us", C.c_double), ("max_us", C.c_double), ("algorithmic_bytes", C.c_uint64),
+                ("units", C.c_uint64), ("launches", C.c_uint32)]
 
 
 # name -> (restype, argtypes).  Every symbol include/zigz_hip.h declares must appear here
@@ -82,6 +90,7 @@ SIGNATURES = {
     "zigz_host_keccak_permute": (None, [u64p, C.c_int]),
     "zigz_ctx_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
     "zigz_ctx_enable_timing": (C.c_int32, [vp, C.c_int]),
+    "zigz_bench_kernel": (C.c_int32, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(BenchResult)]),
     "zigz_ctx_get_stats": (C.c_int32, [vp, C.POINTER(KernelStats)]),
 }
 

@@ -42,9 +42,16 @@ struct zigz_ctx {
     hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
     int pool_used;
     uint64_t pool_bytes;
+    // kernel-exact timestamps of the Keccak launches of the last batched commit (timing mode): pair i = kev[2i], kev[2i+1]
+    hipEvent_t kev[2 * 40];
+    uint8_t kev_class[40];  // 0 leaves, 1 level (HPT hashes per thread), 2 level (1 hash per thread), 3 top
+    uint64_t kev_perms[40];
+    int kev_n;
+    void *d_flush;          // 1 GiB read-only scratch of zigz_bench_kernel (cold-HBM runs), allocated on first use
     zigz_kernel_stats stats;
     zigz_commit_job *active_job;
 };
+static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 4096;
 constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck stage
 constexpr size_t RADIX_MIN_N = 1 << 11;  // smaller tables use the per-round form (one launch + read-back per round)
@@ -185,6 +192,8 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 128; i++)
         if (fail(hipEventCreate(&ctx->pool[i]))) st = ZIGZ_ERR_HIP;
+    for (int i = 0; st == ZIGZ_OK && i < 80; i++)
+        if (fail(hipEventCreate(&ctx->kev[i]))) st = ZIGZ_ERR_HIP;
     if (st != ZIGZ_OK) {
         zigz_ctx_destroy(ctx);
         return st;
@@ -210,6 +219,9 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 128; i++)
         if (ctx->pool[i]) (void)hipEventDestroy(ctx->pool[i]);
+    for (int i = 0; i < 80; i++)
+        if (ctx->kev[i]) (void)hipEventDestroy(ctx->kev[i]);
+    if (ctx->d_flush) (void)hipFree(ctx->d_flush);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -856,10 +868,21 @@ extern "C" zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint
 // ------------------------------------------------------------------ Merkle
 // builds all levels of `ncols` trees (leaf hashes + level merges), asynchronous on the stream
 static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
-                               uint8_t *d_tree, size_t ncols) {
+                               uint8_t *d_tree, size_t ncols, bool record = false) {
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
     unsigned l_start = 0;
+    if (record) ctx->kev_n = 0;
+    // timing mode: every dense Keccak launch carries its own begin / end timestamps, by class
+    KTime kt_store;
+    auto stamp = [&](int cls, uint64_t perms) -> const KTime * {
+        if (!record || ctx->kev_n >= 40) return nullptr;
+        kt_store = KTime{ctx->kev[2 * ctx->kev_n], ctx->kev[2 * ctx->kev_n + 1]};
+        ctx->kev_class[ctx->kev_n] = (uint8_t)cls;
+        ctx->kev_perms[ctx->kev_n] = perms;
+        ctx->kev_n++;
+        return &kt_store;
+    };
     if (ctx->merkle_dedup && height >= 17) {  // levels 0..8 run-aware; above the 256-leaf blocks the build is dense
         const size_t nblocks = npad >> DEDUP_BLOG;
         void *w;
@@ -875,7 +898,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         ctx->stats.merkle_blocks = (uint64_t)ncols * nblocks;
         l_start = DEDUP_BLOG;
     } else {
-        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream);
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
         ctx->stats.merkle_blocks = 0;
     }
     for (unsigned l = l_start; l < height; l++) {
@@ -885,9 +908,30 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             break;
         }
         launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols,
-                            ctx->stream);
+                            ctx->stream, stamp(keccak_level_is_wide(n_out, ncols) ? 1 : 2, (uint64_t)ncols * n_out));
     }
     HIPCHK(ctx, hipGetLastError());
+    return ZIGZ_OK;
+}
+
+// after the stream has passed the last recorded launch: per-class device time of the last recorded build
+static zigz_status keccak_times_collect(zigz_ctx *ctx) {
+    double us[4] = {0, 0, 0, 0};
+    uint64_t perms[4] = {0, 0, 0, 0};
+    for (int i = 0; i < ctx->kev_n; i++) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventSynchronize(ctx->kev[2 * i + 1]));
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[2 * i], ctx->kev[2 * i + 1]));
+        us[ctx->kev_class[i]] += (double)ms * 1000.0;
+        perms[ctx->kev_class[i]] += ctx->kev_perms[i];
+    }
+    ctx->stats.keccak_leaves_us = us[0];
+    ctx->stats.keccak_leaves_perms = perms[0];
+    ctx->stats.keccak_level_wide_us = us[1];
+    ctx->stats.keccak_level_wide_perms = perms[1];
+    ctx->stats.keccak_level_small_us = us[2];
+    ctx->stats.keccak_level_small_perms = perms[2];
+    ctx->kev_n = 0;
     return ZIGZ_OK;
 }
 
@@ -1036,7 +1080,7 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         job->d_tree = (uint8_t *)tree;
         HIPCHK(ctx, hipEventCreateWithFlags(&job->built, hipEventDisableTiming));
         CHK(timed_begin(ctx, 2));
-        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols));
+        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols, ctx->timing));
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         // roots -> contiguous device buffer -> pinned staging (async), then the "built" event
         void *d_roots;
@@ -1107,6 +1151,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
         ctx->stats.merkle_build_us = (double)ms * 1000.0;
+        CHK(keccak_times_collect(ctx));
     }
     job->state = 1;
     return ZIGZ_OK;
@@ -1234,6 +1279,117 @@ extern "C" zigz_status zigz_lasso_prove_with_mapping(zigz_ctx *ctx, const uint64
     return zigz_lasso_prove(ctx, table, table_rows, queries, n_queries, n_in, n_out, nv_out, rounds, point, final_eval,
                             query_commitment, table_commitment);
     ZIGZ_NOTHROW_END(ctx)
+}
+
+// ------------------------------------------------------------------ measurement hook: one hot kernel on synthetic tables
+// Launches the named kernel `iters` times on a device-resident synthetic table (ncols columns of 2^nv canonical
+// elements) and reports each launch's own duration (dispatch begin / end timestamps, what rocprofv3 --kernel-trace
+// shows).  cold != 0: a 1 GiB read-only sweep precedes every launch, so the inputs come from HBM and not from the
+// 256 MB Infinity Cache or L2 (a read sweep leaves no dirty lines behind, unlike a memset).
+extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size_t nv, size_t ncols, int iters, int cold,
+                                         zigz_bench_result *out) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !kernel || !out || nv < 13 || nv > 30 || ncols == 0 || ncols > 4096 || iters < 1) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;
+    if (iters > 64) iters = 64;
+    const size_t N = (size_t)1 << nv;
+    memset(out, 0, sizeof(*out));
+    enum { K_BIND, K_BIND_SUMS, K_HALF, K_BLOCK, K_FOLD, K_LEAVES, K_LEVEL, K_LASSO } which;
+    if (!strcmp(kernel, "k_bind_vec")) which = K_BIND;
+    else if (!strcmp(kernel, "k_bind_vec_sums")) which = K_BIND_SUMS;
+    else if (!strcmp(kernel, "k_half_sums_vec")) which = K_HALF;
+    else if (!strcmp(kernel, "k_block_sums")) which = K_BLOCK;
+    else if (!strcmp(kernel, "k_radix_fold")) which = K_FOLD;
+    else if (!strcmp(kernel, "k_keccak_leaves")) which = K_LEAVES;
+    else if (!strcmp(kernel, "k_keccak_level")) which = K_LEVEL;
+    else if (!strcmp(kernel, "k_lasso_fingerprints")) which = K_LASSO;
+    else return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (which == K_BLOCK && ncols != 1) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (which == K_FOLD && (nv < 14 || nv > 24)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (which != K_BLOCK && ncols * 2 > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    void *d_in_v, *d_out_v = nullptr, *d_tree_v = nullptr;
+    const size_t in_elems = which == K_LASSO ? ncols * N * 3 : ncols * N;
+    CHK(ws_get(ctx, WS_COLS, in_elems * 4, &d_in_v));
+    uint32_t *d_in = (uint32_t *)d_in_v;
+    launch_fill_pattern(d_in, in_elems, 0x5A49475A, ctx->stream);
+    const unsigned k2 = 10, k1 = nv >= k2 ? (unsigned)nv - k2 : 0;
+    const size_t m = (size_t)1 << k2, nb = (size_t)1 << k1, groups = radix_fold_groups(nb);
+    unsigned long long *d_part = nullptr;
+    uint32_t *d_w1 = nullptr;
+    switch (which) {
+    case K_BIND: case K_BIND_SUMS: case K_LASSO:
+        CHK(ws_get(ctx, WS_FOLD, ncols * N * 4, &d_out_v));
+        break;
+    case K_FOLD:
+        CHK(ws_get(ctx, WS_FOLD, ncols * (groups * m * 8 + nb * 4) + 256, &d_out_v));
+        d_part = (unsigned long long *)d_out_v;
+        d_w1 = (uint32_t *)(d_part + ncols * groups * m);
+        launch_fill_pattern(d_w1, ncols * nb, 7, ctx->stream);
+        break;
+    case K_LEAVES: case K_LEVEL:
+        CHK(ws_get(ctx, WS_TREE, ncols * tree_nodes(N) * 32, &d_tree_v));
+        launch_keccak_leaves(d_in, N, N, N, (uint8_t *)d_tree_v, tree_nodes(N), ncols, ctx->stream);
+        break;
+    default: break;
+    }
+    if (cold && !ctx->d_flush) {
+        HIPCHK(ctx, hipMalloc(&ctx->d_flush, FLUSH_BYTES));
+        launch_fill_pattern((uint32_t *)ctx->d_flush, FLUSH_BYTES / 4, 99, ctx->stream);
+    }
+    HIPCHK(ctx, hipGetLastError());
+    const uint32_t r_m = host_to_mont(123456789);
+    for (int it = 0; it < iters; it++) {
+        if (which != K_FOLD && which != K_LEAVES && which != K_LEVEL && which != K_LASSO)
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, SUMS_SLOTS * sizeof(unsigned long long), ctx->stream));
+        if (cold) launch_half_sums((const uint32_t *)ctx->d_flush, FLUSH_BYTES / 4, FLUSH_BYTES / 4, 1, ctx->d_sums + SUMS_SLOTS - 2, ctx->stream);
+        const KTime kt{ctx->pool[2 * it], ctx->pool[2 * it + 1]};
+        switch (which) {
+        case K_BIND:
+            launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, nullptr, ctx->stream, &kt);
+            break;
+        case K_BIND_SUMS:
+            launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, ctx->d_sums, ctx->stream, &kt);
+            break;
+        case K_HALF: launch_half_sums(d_in, N, N, ncols, ctx->d_sums, ctx->stream, &kt); break;
+        case K_BLOCK: launch_block_sums(d_in, N, (unsigned)nv - 10, ctx->d_sums, ctx->stream, &kt); break;
+        case K_FOLD:
+            launch_radix_fold(d_in, N, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream, kt.start, kt.stop);
+            break;
+        case K_LEAVES:
+            launch_keccak_leaves(d_in, N, N, N, (uint8_t *)d_tree_v, tree_nodes(N), ncols, ctx->stream, &kt);
+            break;
+        case K_LEVEL:
+            launch_keccak_level((uint8_t *)d_tree_v, tree_nodes(N), tree_level_offset(N, 0), tree_level_offset(N, 1), N / 2, ncols,
+                                ctx->stream, &kt);
+            break;
+        case K_LASSO: launch_lasso_fingerprints(d_in, ncols * N, 3, (uint32_t *)d_out_v, ctx->stream, &kt); break;
+        }
+        HIPCHK(ctx, hipGetLastError());
+    }
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    double sum = 0, mn = 1e30, mx = 0;
+    for (int it = 0; it < iters; it++) {
+        float ms = 0;
+        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pool[2 * it], ctx->pool[2 * it + 1]));
+        const double us = (double)ms * 1000.0;
+        sum += us;
+        if (us < mn) mn = us;
+        if (us > mx) mx = us;
+    }
+    out->avg_us = sum / iters;
+    out->min_us = mn;
+    out->max_us = mx;
+    out->launches = (uint32_t)iters;
+    const uint64_t n_all = (uint64_t)ncols * N;
+    switch (which) {  // algorithmic bytes per launch (SURVEY s8d, 4 B per element)
+    case K_BIND: case K_BIND_SUMS: out->algorithmic_bytes = 6 * n_all; out->units = n_all; break;  // read n, write n/2
+    case K_HALF: case K_BLOCK: out->algorithmic_bytes = 4 * n_all; out->units = n_all; break;
+    case K_FOLD: out->algorithmic_bytes = ncols * (N * 4 + groups * m * 8); out->units = n_all; break;
+    case K_LEAVES: out->algorithmic_bytes = n_all * (4 + 32); out->units = n_all; break;            // 1 permutation per leaf
+    case K_LEVEL: out->algorithmic_bytes = (n_all / 2) * (64 + 32); out->units = n_all / 2; break;  // 1 permutation per node
+    case K_LASSO: out->algorithmic_bytes = n_all * 16; out->units = n_all; break;                    // 3 x 4 B in, 4 B out per row
+    }
+    return ZIGZ_OK;
 }
 
 // ------------------------------------------------------------------ host transcript

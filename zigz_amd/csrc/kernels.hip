@@ -19,6 +19,13 @@ constexpr int TPB = 256;      // 4 waves per workgroup
 constexpr int UNROLL = 4;     // 16-byte chunks per thread per tile: 8 x 16 B loads in flight
 constexpr size_t VEC_MIN_HALF = 4096;  // vector path needs half % (4*TPB*UNROLL) == 0
 
+// launch with (kt != nullptr) or without kernel-exact timestamps
+#define ZK_LAUNCH(kt, kern, grid, block, lds, s, ...)                                                             \
+    do {                                                                                                          \
+        if (kt) hipExtLaunchKernelGGL(kern, grid, block, lds, s, (kt)->start, (kt)->stop, 0, __VA_ARGS__);         \
+        else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                          \
+    } while (0)
+
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
 #pragma unroll
@@ -120,25 +127,17 @@ bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_str
 }
 
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
-                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s) {
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s, const KTime *kt) {
     if (half == 0 || ncols == 0) return;
     const bool vec = bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride, d_in, d_out);
     if (vec) {
         dim3 grid((unsigned)(half / (4 * TPB * UNROLL)), (unsigned)ncols);
-        if (d_sums)
-            hipLaunchKernelGGL(k_bind_vec<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
-                               r_m, d_r_m, d_sums);
-        else
-            hipLaunchKernelGGL(k_bind_vec<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
-                               r_m, d_r_m, d_sums);
+        if (d_sums) ZK_LAUNCH(kt, k_bind_vec<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
+        else ZK_LAUNCH(kt, k_bind_vec<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
     } else {
         dim3 grid(1, (unsigned)ncols);
-        if (d_sums)
-            hipLaunchKernelGGL(k_bind_small<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half,
-                               r_m, d_r_m, d_sums);
-        else
-            hipLaunchKernelGGL(k_bind_small<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride,
-                               half, r_m, d_r_m, d_sums);
+        if (d_sums) ZK_LAUNCH(kt, k_bind_small<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
+        else ZK_LAUNCH(kt, k_bind_small<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
     }
 }
 
@@ -171,13 +170,13 @@ __global__ __launch_bounds__(TPB) void k_half_sums_small(const uint32_t *__restr
 }
 
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols, unsigned long long *d_sums,
-                      hipStream_t s) {
+                      hipStream_t s, const KTime *kt) {
     if (n == 0 || ncols == 0) return;
     if (n >= 2 * (size_t)(4 * TPB * UNROLL) && in_stride % 4 == 0 && aligned16(d_in)) {
         dim3 grid((unsigned)(n / (4 * TPB * UNROLL)), (unsigned)ncols);
-        hipLaunchKernelGGL(k_half_sums_vec, grid, dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
+        ZK_LAUNCH(kt, k_half_sums_vec, grid, dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
     } else {
-        hipLaunchKernelGGL(k_half_sums_small, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
+        ZK_LAUNCH(kt, k_half_sums_small, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
     }
 }
 
@@ -204,10 +203,10 @@ __global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__
     }
 }
 
-void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s) {
+void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s,
+                       const KTime *kt) {
     const size_t chunks = n / 4, per_block = (size_t)TPB * UNROLL;
-    hipLaunchKernelGGL(k_block_sums, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(TPB), 0, s, d_in, n, log2_m,
-                       d_sums);
+    ZK_LAUNCH(kt, k_block_sums, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(TPB), 0, s, d_in, n, log2_m, d_sums);
 }
 
 // Radix-2^k fold  T'[i] = sum_b W[b] * T[b*m + i].  Work split: a workgroup owns 1024 consecutive outputs (one
@@ -656,21 +655,23 @@ void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t
 }
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                          size_t tree_stride_nodes, size_t ncols, hipStream_t s) {
+                          size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt) {
     dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
-                       tree_stride_nodes);
+    ZK_LAUNCH(kt, k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
+              tree_stride_nodes);
 }
 
+bool keccak_level_is_wide(size_t n_out, size_t ncols) { return n_out * ncols >= (size_t)TPB * HPT * 4096; }
+
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
-                         size_t ncols, hipStream_t s) {
+                         size_t ncols, hipStream_t s, const KTime *kt) {
     // several hashes per thread only while that still leaves >= 16 workgroups per CU (small levels need the waves)
-    if (n_out * ncols >= (size_t)TPB * HPT * 4096) {
+    if (keccak_level_is_wide(n_out, ncols)) {
         dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-        hipLaunchKernelGGL(k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+        ZK_LAUNCH(kt, k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
     } else {
         dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
-        hipLaunchKernelGGL(k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+        ZK_LAUNCH(kt, k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
     }
 }
 
@@ -757,10 +758,27 @@ __global__ __launch_bounds__(TPB) void k_lasso_fingerprints(const uint32_t *__re
     out[i] = (uint32_t)(h % (uint64_t)P);
 }
 
-void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s) {
+void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s,
+                               const KTime *kt) {
     if (rows)
-        hipLaunchKernelGGL(k_lasso_fingerprints, dim3((unsigned)((rows + TPB - 1) / TPB)), dim3(TPB), 0, s, d_rows,
-                           rows, width, d_out);
+        ZK_LAUNCH(kt, k_lasso_fingerprints, dim3((unsigned)((rows + TPB - 1) / TPB)), dim3(TPB), 0, s, d_rows, rows, width,
+                  d_out);
+}
+
+// ------------------------------------------------------------------ synthetic data for the measurement hooks
+__global__ __launch_bounds__(TPB) void k_fill_pattern(uint32_t *__restrict__ out, size_t n, uint32_t seed) {
+    size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const size_t step = (size_t)gridDim.x * TPB;
+    for (; i < n; i += step) {
+        uint64_t z = (i + 1) * 0x9E3779B97F4A7C15ull + seed;  // splitmix64 finaliser
+        z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+        z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+        z ^= z >> 31;
+        out[i] = (uint32_t)(z % (uint64_t)P);
+    }
+}
+void launch_fill_pattern(uint32_t *d_out, size_t n, uint32_t seed, hipStream_t s) {
+    if (n) hipLaunchKernelGGL(k_fill_pattern, dim3(stream_grid(n)), dim3(TPB), 0, s, d_out, n, seed);
 }
 
 }  // namespace zk

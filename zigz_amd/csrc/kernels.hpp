@@ -7,6 +7,13 @@
 
 namespace zk {
 
+// Optional kernel-exact timing of one launch: both events are stamped with the dispatch's own begin / end timestamps
+// (hipExtLaunchKernelGGL), not with the position of an event command in the stream, so the elapsed time between them is
+// the kernel's duration as rocprofv3 --kernel-trace reports it.
+struct KTime {
+    hipEvent_t start, stop;
+};
+
 // Merkle tree of one column kept in HBM: levels bottom-up, level l (N>>l nodes of 32 B) starts at
 // node offset 2N - 2*(N>>l); root at node 2N-2.  Column stride = 2N nodes.
 inline size_t tree_level_offset(size_t npad, unsigned level) { return 2 * npad - 2 * (npad >> level); }
@@ -28,17 +35,19 @@ void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream
 // r_c (Montgomery form) = d_r_m ? d_r_m[c] : r_m.  If d_sums: sums[2c] += sum of out[0..half/2),
 // sums[2c+1] += sum of out[half/2..half)  (exact u64 sums; must be zeroed by the caller).
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
-                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s);
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s,
+                 const KTime *kt = nullptr);
 // true when launch_bind takes the vectorised k_bind_vec path for these arguments
 bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out);
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // K2/K3: sums[2c] += sum in[0..n/2), sums[2c+1] += sum in[n/2..n)   (n >= 2); n == 1: sums[2c] += in[0]
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols,
-                      unsigned long long *d_sums, hipStream_t s);
+                      unsigned long long *d_sums, hipStream_t s, const KTime *kt = nullptr);
 
 // Radix-2^k sumcheck stage (k rounds per pass over the table; see DESIGN.md "Sumcheck"):
 //  (1) block sums: sums[b] += sum of in[b*m .. (b+1)*m), b < n/m   (m = 2^log2_m >= 256, n >= 1024, exact u64)
-void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s);
+void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s,
+                       const KTime *kt = nullptr);
 //  (2) part[c][g][i] = sum over the g-th group of 64 consecutive b of W[c][b] * in[c][b*m + i]   (exact u64; i < m,
 //      m % 4 == 0, column c < ncols; W in Montgomery form; G = radix_fold_groups(nb) groups; strides in elements)
 size_t radix_fold_groups(size_t nb);
@@ -78,10 +87,12 @@ void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t
 
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
-                          uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s);
+                          uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr);
 // K6: one level.  out node i = SHA3(in node 2i || in node 2i+1), i < n_out  (node offsets per column)
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
-                         size_t ncols, hipStream_t s);
+                         size_t ncols, hipStream_t s, const KTime *kt = nullptr);
+// true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
+bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
                        size_t ncols, hipStream_t s);
@@ -96,6 +107,9 @@ void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t
 // gather element 0 of each column of a strided table
 void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s);
 // K9: Lasso fingerprints (src/lookups/lasso_prover.zig:208-239): rows x width canonical u32 -> u32
-void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s);
+void launch_lasso_fingerprints(const uint32_t *d_rows, size_t rows, size_t width, uint32_t *d_out, hipStream_t s,
+                               const KTime *kt = nullptr);
+// synthetic canonical table for the measurement hooks: out[i] = splitmix-style hash of (seed, i) mod p
+void launch_fill_pattern(uint32_t *d_out, size_t n, uint32_t seed, hipStream_t s);
 
 }  // namespace zk

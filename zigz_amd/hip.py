@@ -9,7 +9,7 @@ import ctypes as C
 import numpy as np
 
 from . import errors
-from ._ffi import KernelStats, lib, u8p, u64p, vp
+from ._ffi import BenchResult, KernelStats, lib, u8p, u64p, vp
 
 P = 2013265921
 NUM_COLUMNS = 43
@@ -113,6 +113,12 @@ class Context:
         s = KernelStats()
         self.check(lib.zigz_ctx_get_stats(self.h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in KernelStats._fields_}
+
+    def bench_kernel(self, kernel, nv, ncols, iters=10, cold=True):
+        """zigz_bench_kernel: per-launch kernel durations of one hot kernel on a synthetic resident table."""
+        r = BenchResult()
+        self.check(lib.zigz_bench_kernel(self.h, kernel.encode(), nv, ncols, iters, 1 if cold else 0, C.byref(r)))
+        return {f: getattr(r, f) for f, _ in BenchResult._fields_}
 
     # ---- Multilinear(F) seams, host buffers
     def mle_bind(self, evals, r):
