@@ -179,6 +179,35 @@ zigz_status zigz_dev_reduce_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, u
 zigz_status zigz_dev_witness_from_rows(zigz_ctx *ctx, const uint64_t *h_rows, size_t num_steps, size_t nv,
                                        uint32_t *d_cols, size_t col_stride);
 
+/* The same columns from the COMPACT trace: one 48-byte record per executed step instead of its 43 raw words (344 B).
+ * A `Step` of src/vm/trace.zig:73-97 carries two full register files, but regs_after differs from the previous step's
+ * in at most the one register the instruction wrote (src/vm/state.zig:188-597: every instruction writes <= 1 register;
+ * x0 never changes, src/vm/registers.zig:38-48), so a step is: pc, the instruction's decoded fields, the register
+ * write (wr_reg, rd_value) and the memory access.  The device rebuilds the 32 register columns by carrying each
+ * register's last written value forward (witness.zig:65-123), reduces every cell mod p (F.init, witness.zig:76,112,
+ * 164-170,237-239) and applies the padding rule (pc and registers repeat their last value, the rest is 0:
+ * witness.zig:80-87,116-123).  A Zig host fills one record per trace.steps.items[i]:
+ *   pc = step.pc; opcode..funct7, imm = step.instruction.*; (wr_reg, rd_value) = the r with regs_after[r] != regs_before[r]
+ *   (0 when none); mem_* = step.memory_access (zeros / mem_is_read = 0 when null; mem_is_read = 1 for .Load). */
+typedef struct zigz_trace_step {
+    uint64_t pc;        /* step.pc */
+    uint64_t rd_value;  /* regs_after[wr_reg]; ignored when wr_reg == 0 */
+    uint64_t mem_addr;  /* memory_access.address (0 when none) */
+    uint64_t mem_value; /* memory_access.value   (0 when none) */
+    int64_t imm;        /* instruction.imm */
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7; /* @intFromEnum(opcode) and the raw fields, witness.zig:164-169 */
+    uint8_t wr_reg;      /* 1..31: the register this step wrote; 0: none */
+    uint8_t mem_is_read; /* 1 = load, 0 = store or no access */
+} zigz_trace_step;
+/* initial_regs: the 32 register values before the first step (NULL = all zero); x0 is forced to 0.  h_steps may be
+ * pageable or pinned (zigz_host_register) memory; the call returns when the copy has completed. */
+zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                        const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride);
+/* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
+ * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer. */
+zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes);
+zigz_status zigz_host_unregister(zigz_ctx *ctx, void *h_ptr);
+
 /* ---------------------------------------------------------------- device-resident MLE / sumcheck */
 zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out);
 /* fused: d_out = bind(d_in, r) and sums[0..1] = (sum of low half, sum of high half) of d_out */
@@ -244,8 +273,9 @@ typedef struct zigz_kernel_stats {
 } zigz_kernel_stats;
 /* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
  * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per
- * table element), "k_bind_vec_sums" (the same fused with the next roundPolynomial), "k_half_sums_vec" / "k_block_sums"
- * (roundPolynomial / sumOverHypercube, multilinear.zig:188-232, 4 B per element; k_block_sums: ncols = 1),
+ * table element), "k_bind_vec_sums" (the same fused with the next roundPolynomial), "k_half_sums" / "k_block_sums"
+ * (roundPolynomial / sumOverHypercube, multilinear.zig:188-232: kernel k_block_sums with 2 resp. 1024 blocks, 4 B per
+ * element; "k_block_sums": ncols = 1),
  * "k_radix_fold" (eval, multilinear.zig:110-144, 4 B per element + partial sums), "k_keccak_leaves" / "k_keccak_level"
  * (hash.zig:135-147,187-195; units = permutations), "k_lasso_fingerprints" (lasso_prover.zig:208-239; units = rows of 3
  * fields).  cold != 0: a 1 GiB read sweep before every launch empties L2 / Infinity Cache of the table. */

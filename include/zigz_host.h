@@ -15,7 +15,7 @@
 extern "C" {
 #endif
 
-typedef struct zigzh_trace zigzh_trace; /* an executed program: packed trace rows + public IO */
+typedef struct zigzh_trace zigzh_trace; /* an executed program: compact trace records + public IO */
 
 const char *zigzh_last_error(void);
 void zigzh_free(void *p);
@@ -41,7 +41,12 @@ void zigzh_trace_free(zigzh_trace *t);
 size_t zigzh_trace_num_steps(const zigzh_trace *t);
 size_t zigzh_trace_num_vars(const zigzh_trace *t);
 size_t zigzh_trace_num_lookups(const zigzh_trace *t);
-const uint64_t *zigzh_trace_rows(const zigzh_trace *t); /* [num_steps][43] raw u64 */
+const uint64_t *zigzh_trace_rows(const zigzh_trace *t); /* [num_steps][43] raw u64 (expanded on first use) */
+/* the trace as recorded: num_steps compact records (zigz_trace_step, zigz_hip.h) + the register file before step 0 */
+const void *zigzh_trace_steps(const zigzh_trace *t);
+const uint64_t *zigzh_trace_initial_regs(const zigzh_trace *t);
+/* page-lock the records for repeated uploads (zigz_host_register); released by zigzh_trace_free */
+int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx);
 /* WitnessGenerator.generate -> 43 columns of 2^nv canonical u64, column-major   witness.zig:29-61 */
 int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out);
 /* builds the 43 witness columns directly in HBM (packed u32, column stride `stride` elements) */

@@ -395,6 +395,98 @@ def test_witness_from_rows(ctx, ns):
     assert np.array_equal(got, exp)
 
 
+def _expand_reference(steps, ns, N, init):
+    """numpy restatement of witness.zig:65-270 on compact records: regs_after by carrying writes forward, x mod p,
+    padding rule.  Returns [43, N] uint64."""
+    p = np.uint64(P)
+    exp = np.zeros((43, N), dtype=np.uint64)
+    exp[0, :ns] = steps["pc"] % p
+    for r in range(1, 32):
+        idx = np.where(steps["wr_reg"] == r, np.arange(ns), -1)
+        last = np.maximum.accumulate(idx)
+        vals = np.where(last >= 0, steps["rd_value"][np.maximum(last, 0)], np.uint64(init[r]))
+        exp[1 + r, :ns] = vals % p
+    for c, f in ((33, "opcode"), (34, "rd"), (35, "rs1"), (36, "rs2"), (37, "funct3"), (38, "funct7")):
+        exp[c, :ns] = steps[f]
+    exp[39, :ns] = steps["imm"].astype(np.int64).view(np.uint64) % p
+    exp[40, :ns] = steps["mem_addr"] % p
+    exp[41, :ns] = steps["mem_value"] % p
+    exp[42, :ns] = steps["mem_is_read"]
+    exp[:33, ns:] = exp[:33, ns - 1:ns]
+    return exp
+
+
+@pytest.mark.parametrize("ns", [1, 2, 3, 63, 64, 65, 127, 129, 1000, 4097, 70000])
+def test_witness_from_steps_synthetic(ctx, ns):
+    """Compact records with full-range 64-bit values and sparse / dense register writes (registers written once, never,
+    or on every step; writes at chunk boundaries) -> the 43 padded columns, vs the reference rule restated in numpy."""
+    import zigz_amd
+    rng = np.random.default_rng(1000 + ns)
+    st = np.zeros(ns, dtype=zigz_amd.hip.TRACE_STEP_DTYPE)
+    for f in ("pc", "rd_value", "mem_addr", "mem_value"):
+        st[f] = rng.integers(0, 2**64, size=ns, dtype=np.uint64)
+    st["imm"] = rng.integers(-2**63, 2**63, size=ns, dtype=np.int64)
+    for f, hi in (("opcode", 128), ("rd", 32), ("rs1", 32), ("rs2", 32), ("funct3", 8), ("funct7", 128), ("mem_is_read", 2)):
+        st[f] = rng.integers(0, hi, size=ns)
+    wr = rng.integers(0, 8, size=ns)          # x1..x7 dense, 0 = no write
+    sparse = rng.random(ns) < 0.01
+    wr[sparse] = rng.integers(8, 30, size=int(sparse.sum()))  # x8..x29 rarely; x30, x31 never
+    wr[0] = 9
+    if ns > 64:
+        wr[63], wr[64] = 10, 10             # last lane of a chunk / first lane of the next
+    st["wr_reg"] = wr
+    st["rd_value"][ns // 2] = P             # p, p-1 and 2^64-1 as written values
+    st["rd_value"][ns // 3] = 2**64 - 1
+    init = rng.integers(0, 2**64, size=32, dtype=np.uint64)
+    nv = 0 if ns == 1 else int(ns - 1).bit_length()
+    N = 1 << nv
+    stride = max(N, 4) + (4 if ns % 2 else 0)  # also a stride larger than the column
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        ctx.witness_from_steps(st, nv, d, stride, init)
+        got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+    finally:
+        ctx.dev_free(d)
+    init[0] = 0
+    exp = _expand_reference(st, ns, N, init)
+    bad = np.argwhere(got != exp)
+    assert bad.size == 0, (bad[:5], got[tuple(bad[0])], exp[tuple(bad[0])])
+
+
+@pytest.mark.parametrize("maker,arg,regs", [("fibonacci", 3, None), ("fibonacci", 60, None), ("mixed_loop", 40, None),
+                                            ("mixed_loop", 700, [0, 5, 1 << 40, 2**64 - 1] + [7] * 28),
+                                            ("add_xor_loop", 2000, None)])
+def test_witness_from_steps_vs_oracle(ctx, maker, arg, regs):
+    """Real traces: host VM (compact records) -> device expansion == the oracle's VM + WitnessGenerator (witness.zig),
+    and == the packed-rows path."""
+    import programs
+    from zigz_amd import host
+    made = getattr(programs, maker)(arg)
+    prog, inp = made if isinstance(made, tuple) else (made, None)
+    tr = host.Trace(prog, 0x1000, regs, 1 << 20, inp)
+    cols, nv, ns = O.witness_from_program(P, prog, 0x1000, regs, 1 << 20, inp)
+    assert (tr.num_steps, tr.num_vars) == (ns, nv)
+    N = 1 << nv
+    stride = max(N, 4)
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        tr.witness_to_device(ctx, d, stride)  # zigz_dev_witness_from_steps
+        got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+        assert np.array_equal(got, cols)
+        ctx.witness_from_rows(tr.rows(), nv, d, stride)  # the packed-rows entry on the host-expanded rows
+        got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+        assert np.array_equal(got, cols)
+    finally:
+        ctx.dev_free(d)
+    # the records themselves against the oracle's trace
+    st, init = tr.steps()
+    ot = O.vm_trace(prog, 0x1000, regs, 1 << 20, inp)
+    assert np.array_equal(st["pc"], ot["pc"]) and np.array_equal(st["imm"], ot["imm"])
+    for f in ("opcode", "rd", "rs1", "rs2", "funct3", "funct7"):
+        assert np.array_equal(st[f], ot[f]), f
+    assert np.array_equal(st["mem_is_read"], (ot["mem_kind"] == 1).astype(np.uint8))
+
+
 # ---------------------------------------------------------------- A5: both sumcheck forms agree
 @pytest.mark.parametrize("nv", [10, 11, 12, 13, 14, 15, 16, 18, 19, 21, 24])
 def test_sumcheck_radix_equals_per_round(ctx, nv):

@@ -31,6 +31,7 @@ struct zigz_ctx {
     unsigned long long *d_sums;  // SUMS_SLOTS u64
     uint32_t *d_flag;
     uint64_t *h_pin;  // pinned staging, PIN_WORDS u64
+    uint64_t h_sums[2048];  // host copy of padded / replicated half sums (dev_half_sums)
     uint8_t *h_roots;  // pinned, ROOTS_MAX_COLS * 32 B: the active commit job's roots travel through this buffer ONLY, so any
                        // other call on the context between zigz_commit_begin* and zigz_commit_roots leaves them intact
     bool timing;
@@ -52,7 +53,7 @@ struct zigz_ctx {
     zigz_commit_job *active_job;
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
-static const size_t SUMS_SLOTS = 4096;
+static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
 constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck stage
 constexpr size_t RADIX_MIN_N = 1 << 11;  // smaller tables use the per-round form (one launch + read-back per round)
 constexpr size_t HOST_TAIL_MAX = 1024;
@@ -343,6 +344,40 @@ extern "C" zigz_status zigz_dev_witness_from_rows(zigz_ctx *ctx, const uint64_t 
     return ZIGZ_OK;
 }
 
+static_assert(sizeof(zigz_trace_step) == sizeof(TraceStep), "zigz_trace_step and its device mirror differ");
+
+extern "C" zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                                   const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !h_steps || !d_cols || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (num_steps == 0) return ZIGZ_ERR_EMPTY_TRACE;
+    const size_t npad = (size_t)1 << nv;
+    if (num_steps > npad || (nv > 0 && num_steps <= npad / 2) || col_stride < npad) return ZIGZ_ERR_INVALID_ARGUMENT;
+    void *d_steps, *d_ws;
+    CHK(ws_get(ctx, WS_IN64, num_steps * sizeof(zigz_trace_step), &d_steps));
+    CHK(ws_get(ctx, WS_SCRATCH, witness_steps_ws_words(npad) * 4, &d_ws));
+    HIPCHK(ctx, hipMemcpyAsync(d_steps, h_steps, num_steps * sizeof(zigz_trace_step), hipMemcpyHostToDevice, ctx->stream));
+    Regs32 init;
+    for (int r = 0; r < 32; r++) init.v[r] = (r && initial_regs) ? (uint32_t)(initial_regs[r] % (uint64_t)P) : 0u;
+    launch_witness_steps((const TraceStep *)d_steps, num_steps, npad, init, (uint32_t *)d_ws, d_cols, col_stride, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_steps may be reused by the caller as soon as this returns
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !h_ptr || !bytes) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipHostRegister(h_ptr, bytes, hipHostRegisterDefault));
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_host_unregister(zigz_ctx *ctx, void *h_ptr) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !h_ptr) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipHostUnregister(h_ptr));
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || (n && (!h_out || !d_in))) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -367,10 +402,20 @@ static zigz_status read_u64(zigz_ctx *ctx, const void *d_src, size_t words, uint
 
 // ------------------------------------------------------------------ device-resident MLE ops
 static zigz_status dev_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t out[2]) {
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 16, ctx->stream));
-    launch_half_sums(d_in, n, n, 1, ctx->d_sums, ctx->stream);
+    // one big table: thousands of waves add into two counters; they get cache lines of their own and up to 64 copies,
+    // added here (<= 2^40 elements < 2^31 each: the u64 totals cannot overflow)
+    const SumsLayout lay = (aligned16(d_in)) ? half_sums_layout(n, 1, 2048) : SumsLayout{2, 1, 0, 1};
+    const size_t words = lay.nslots > 1 || lay.col_stride != 2 ? (size_t)lay.nslots * 32 : 2;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, words * 8, ctx->stream));
+    launch_half_sums(d_in, n, n, 1, ctx->d_sums, ctx->stream, nullptr, &lay);
     HIPCHK(ctx, hipGetLastError());
-    return read_u64(ctx, ctx->d_sums, 2, out);
+    CHK(read_u64(ctx, ctx->d_sums, words, ctx->h_sums));
+    out[0] = out[1] = 0;
+    for (unsigned k = 0; k < lay.nslots; k++) {
+        out[0] += ctx->h_sums[k * lay.slot_stride];
+        out[1] += ctx->h_sums[k * lay.slot_stride + lay.bin_stride];
+    }
+    return ZIGZ_OK;
 }
 
 extern "C" zigz_status zigz_dev_mle_half_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t half_sums[2]) {
@@ -585,7 +630,7 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
 static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,
                                  const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
     const size_t nv = log2_floor(n);
-    if (2 * (nv + 1) > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (2 * (nv + 1) > 4096) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n >= RADIX_MIN_N && aligned16(d_in) && !ctx->per_round_sumcheck && !ctx->timing)
         return sumcheck_radix(ctx, d_in, n, fixed, rounds, point, final_eval);
     if (!d_scratch) {
@@ -695,7 +740,7 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
     CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &wbuf));
     unsigned long long *d_B = ctx->d_sums;  // two alternating regions of 1024 block sums
     HIPCHK(ctx, hipMemsetAsync(d_B, 0, ((size_t)1 << k) * 8, ctx->stream));
-    launch_block_sums(d_in, len, log2_floor(m), d_B, ctx->stream);
+    launch_block_sums(d_in, len, len, log2_floor(m), 1, d_B, SumsLayout{0, 1, 0, 1}, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     std::vector<uint64_t> B((size_t)1 << k), W;
     CHK(read_u64(ctx, d_B, (size_t)1 << k, B.data()));
@@ -1297,7 +1342,7 @@ extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size
     enum { K_BIND, K_BIND_SUMS, K_HALF, K_BLOCK, K_FOLD, K_LEAVES, K_LEVEL, K_LASSO } which;
     if (!strcmp(kernel, "k_bind_vec")) which = K_BIND;
     else if (!strcmp(kernel, "k_bind_vec_sums")) which = K_BIND_SUMS;
-    else if (!strcmp(kernel, "k_half_sums_vec")) which = K_HALF;
+    else if (!strcmp(kernel, "k_half_sums")) which = K_HALF;
     else if (!strcmp(kernel, "k_block_sums")) which = K_BLOCK;
     else if (!strcmp(kernel, "k_radix_fold")) which = K_FOLD;
     else if (!strcmp(kernel, "k_keccak_leaves")) which = K_LEAVES;
@@ -1306,7 +1351,7 @@ extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size
     else return ZIGZ_ERR_INVALID_ARGUMENT;
     if (which == K_BLOCK && ncols != 1) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (which == K_FOLD && (nv < 14 || nv > 24)) return ZIGZ_ERR_INVALID_ARGUMENT;
-    if (which != K_BLOCK && ncols * 2 > SUMS_SLOTS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (which != K_BLOCK && ncols * 32 > 4096) return ZIGZ_ERR_INVALID_ARGUMENT;
     void *d_in_v, *d_out_v = nullptr, *d_tree_v = nullptr;
     const size_t in_elems = which == K_LASSO ? ncols * N * 3 : ncols * N;
     CHK(ws_get(ctx, WS_COLS, in_elems * 4, &d_in_v));
@@ -1340,8 +1385,11 @@ extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size
     const uint32_t r_m = host_to_mont(123456789);
     for (int it = 0; it < iters; it++) {
         if (which != K_FOLD && which != K_LEAVES && which != K_LEVEL && which != K_LASSO)
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, SUMS_SLOTS * sizeof(unsigned long long), ctx->stream));
-        if (cold) launch_half_sums((const uint32_t *)ctx->d_flush, FLUSH_BYTES / 4, FLUSH_BYTES / 4, 1, ctx->d_sums + SUMS_SLOTS - 2, ctx->stream);
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 4096 * sizeof(unsigned long long), ctx->stream));
+        if (cold) {
+            const SumsLayout fl = half_sums_layout(FLUSH_BYTES / 4, 1, 2048);
+            launch_half_sums((const uint32_t *)ctx->d_flush, FLUSH_BYTES / 4, FLUSH_BYTES / 4, 1, ctx->d_sums + 4096, ctx->stream, nullptr, &fl);
+        }
         const KTime kt{ctx->pool[2 * it], ctx->pool[2 * it + 1]};
         switch (which) {
         case K_BIND:
@@ -1350,8 +1398,12 @@ extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size
         case K_BIND_SUMS:
             launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, ctx->d_sums, ctx->stream, &kt);
             break;
-        case K_HALF: launch_half_sums(d_in, N, N, ncols, ctx->d_sums, ctx->stream, &kt); break;
-        case K_BLOCK: launch_block_sums(d_in, N, (unsigned)nv - 10, ctx->d_sums, ctx->stream, &kt); break;
+        case K_HALF: {  // as dev_half_sums launches it: padded, replicated counters
+            const SumsLayout lay = half_sums_layout(N, ncols, 4096);
+            launch_half_sums(d_in, N, N, ncols, ctx->d_sums, ctx->stream, &kt, &lay);
+            break;
+        }
+        case K_BLOCK: launch_block_sums(d_in, N, N, (unsigned)nv - 10, 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream, &kt); break;
         case K_FOLD:
             launch_radix_fold(d_in, N, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream, kt.start, kt.stop);
             break;

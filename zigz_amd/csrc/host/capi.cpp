@@ -11,9 +11,8 @@ using namespace zigz;
 
 static thread_local std::string g_err;
 static thread_local double g_timings[8] = {0};
-// trace-row storage recycled across executions on this thread: first-touch page faults of a fresh 360 MB buffer cost
-// more than running the VM for 2^20 steps
-static thread_local std::vector<uint64_t> g_row_pool;
+// trace storage recycled across executions on this thread (first-touch page faults of a fresh buffer are not free)
+static thread_local std::vector<zigz_trace_step> g_step_pool;
 static thread_local std::vector<uint8_t> g_proof;  // borrowed-proof buffer of zigzh_prove_trace(want_bytes = 2)
 
 template <class Fn>
@@ -49,6 +48,8 @@ struct zigzh_trace {
     ExecutionTrace trace;
     size_t num_lookups = 0, num_vars = 0;
     std::optional<std::vector<uint64_t>> initial_regs;
+    mutable std::vector<uint64_t> rows_cache;  // expandRows(), built on first use by zigzh_trace_rows
+    zigz_ctx *registered = nullptr;            // context that page-locked trace.steps (zigzh_trace_pin)
 };
 
 extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_t entry_pc, const uint64_t *initial_regs,
@@ -64,7 +65,7 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
         VMState vm(prog, entry_pc, input ? &in : nullptr);
         if (t->initial_regs)
             for (size_t i = 0; i < t->initial_regs->size() && i < 32; i++) vm.writeReg((unsigned)i, (*t->initial_regs)[i]);
-        vm.trace.rows.swap(g_row_pool);  // recycled capacity (contents are overwritten step by step)
+        vm.trace.steps.swap(g_step_pool);  // recycled capacity (contents are overwritten step by step)
         vm.trace.reserveSteps(max_steps < ((size_t)1 << 22) ? max_steps : ((size_t)1 << 22));
         size_t step_count = 0;
         while (!vm.halted && step_count < max_steps) {  // prover.zig:132-142
@@ -87,13 +88,27 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
     });
 }
 extern "C" void zigzh_trace_free(zigzh_trace *t) {
-    if (t && t->trace.rows.capacity() > g_row_pool.capacity()) g_row_pool.swap(t->trace.rows);
+    if (!t) return;
+    if (t->registered) (void)zigz_host_unregister(t->registered, t->trace.steps.data());
+    else if (t->trace.steps.capacity() > g_step_pool.capacity()) g_step_pool.swap(t->trace.steps);
     delete t;
 }
+extern "C" int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx) {
+    return guard([&] {
+        if (t->registered || t->trace.stepCount() == 0) return;
+        check(ctx, zigz_host_register(ctx, t->trace.steps.data(), t->trace.stepCount() * sizeof(zigz_trace_step)));
+        t->registered = ctx;
+    });
+}
+extern "C" const void *zigzh_trace_steps(const zigzh_trace *t) { return t->trace.steps.data(); }
+extern "C" const uint64_t *zigzh_trace_initial_regs(const zigzh_trace *t) { return t->trace.initial_regs; }
 extern "C" size_t zigzh_trace_num_steps(const zigzh_trace *t) { return t->trace.stepCount(); }
 extern "C" size_t zigzh_trace_num_vars(const zigzh_trace *t) { return t->num_vars; }
 extern "C" size_t zigzh_trace_num_lookups(const zigzh_trace *t) { return t->num_lookups; }
-extern "C" const uint64_t *zigzh_trace_rows(const zigzh_trace *t) { return t->trace.rows.data(); }
+extern "C" const uint64_t *zigzh_trace_rows(const zigzh_trace *t) {
+    if (t->rows_cache.empty()) t->rows_cache = t->trace.expandRows();
+    return t->rows_cache.data();
+}
 
 extern "C" int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out) {
     return guard([&] {
@@ -104,8 +119,9 @@ extern "C" int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out) {
 
 extern "C" int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride) {
     return guard([&] {
-        // the trace is already recorded as packed witness rows: one H2D + one transpose/mod-p kernel (K8)
-        check(ctx, zigz_dev_witness_from_rows(ctx, t->trace.rows.data(), t->trace.stepCount(), t->num_vars, d_cols, stride));
+        // the trace is recorded as compact 48-byte steps: one H2D + the expansion kernels (K8)
+        check(ctx, zigz_dev_witness_from_steps(ctx, t->trace.steps.data(), t->trace.stepCount(), t->num_vars,
+                                               t->trace.initial_regs, d_cols, stride));
     });
 }
 

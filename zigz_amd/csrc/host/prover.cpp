@@ -31,9 +31,10 @@ Witness WitnessGenerator::generate(const ExecutionTrace &trace) {
     const size_t N = (size_t)1 << w.num_vars;
     w.columns.assign(ROW_WORDS * N, 0);
     if (ns == 0) return w;
+    const std::vector<uint64_t> rows = trace.expandRows();
     for (size_t c = 0; c < ROW_WORDS; c++) {
         F *col = w.columns.data() + c * N;
-        for (size_t i = 0; i < ns; i++) col[i] = finit(trace.row(i)[c]);
+        for (size_t i = 0; i < ns; i++) col[i] = finit(rows[i * ROW_WORDS + c]);
         if (c <= 32) {  // pc and registers repeat the last value (:80-87,116-123); the rest pads with 0
             const F last = col[ns - 1];
             for (size_t i = ns; i < N; i++) col[i] = last;
@@ -284,12 +285,12 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     std::unique_ptr<VMState> vm(segments ? new VMState(*segments, entry_pc, input) : new VMState(program, entry_pc, input));
     if (initial_regs)
         for (size_t i = 0; i < initial_regs->size() && i < 32; i++) vm->writeReg((unsigned)i, (*initial_regs)[i]);
-    static thread_local std::vector<uint64_t> row_pool;  // recycled trace storage (avoids refaulting ~344 B per step)
-    vm->trace.rows.swap(row_pool);
+    static thread_local std::vector<zigz_trace_step> step_pool;  // recycled trace storage (avoids refaulting 48 B per step)
+    vm->trace.steps.swap(step_pool);
     struct Recycle {
-        std::vector<uint64_t> &pool, &rows;
-        ~Recycle() { if (rows.capacity() > pool.capacity()) pool.swap(rows); }
-    } recycle{row_pool, vm->trace.rows};
+        std::vector<zigz_trace_step> &pool, &steps;
+        ~Recycle() { if (steps.capacity() > pool.capacity()) pool.swap(steps); }
+    } recycle{step_pool, vm->trace.steps};
     vm->trace.reserveSteps(max_steps < ((size_t)1 << 22) ? max_steps : ((size_t)1 << 22));
     size_t step_count = 0;
     while (!vm->halted && step_count < max_steps) {
@@ -299,7 +300,7 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     }
     const size_t num_steps = vm->trace.stepCount();
     if (num_steps == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
-    // [2/6] witness (prover.zig:156-162): built directly in HBM from the packed trace rows (K8); the host
+    // [2/6] witness (prover.zig:156-162): built directly in HBM from the compact trace records (K8); the host
     // WitnessGenerator::generate stays available for callers that want the columns on the host
     const size_t nv = log2_int_ceil(num_steps), N = (size_t)1 << nv, stride = N < 4 ? 4 : N;
     struct DevCols {
@@ -308,7 +309,8 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
         ~DevCols() { if (p) zigz_dev_free(ctx, p); }
     } dcols{ctx_};
     check(ctx_, zigz_dev_alloc(ctx_, ROW_WORDS * stride * sizeof(uint32_t), &dcols.p));
-    check(ctx_, zigz_dev_witness_from_rows(ctx_, vm->trace.rows.data(), num_steps, nv, (uint32_t *)dcols.p, stride));
+    check(ctx_, zigz_dev_witness_from_steps(ctx_, vm->trace.steps.data(), num_steps, nv, vm->trace.initial_regs, (uint32_t *)dcols.p,
+                                            stride));
     // [3/6] constraint system: only the number of lookup constraints is observable (builder.zig:253-267)
     size_t L = 0;
     for (uint8_t f : vm->trace.is_lookup) L += f;

@@ -1,6 +1,6 @@
 // RV64IM interpreter + trace recording: the sequential front end of Prover.prove (src/vm/state.zig,
 // src/vm/memory.zig, src/isa/rv64i.zig, src/isa/instruction_table.zig).  Host only by nature.
-// Steps are recorded directly as the 43 raw witness words of that step (see zigz_host.hpp).
+// Steps are recorded as compact 48-byte records (zigz_trace_step): the device rebuilds the 43 witness words of a step.
 #include <cstring>
 #include <memory>
 #include <unordered_map>
@@ -244,20 +244,39 @@ uint64_t VMState::execute(const Instruction &in, uint64_t *mem_row) {  // state.
 }
 
 void ExecutionTrace::reserveSteps(size_t n) {
-    rows.reserve(n * ROW_WORDS);
+    steps.reserve(n);
     is_lookup.reserve(n);
 }
 
-uint64_t *ExecutionTrace::appendRow() {
+zigz_trace_step *ExecutionTrace::appendStep() {
     const size_t i = is_lookup.size();
-    if ((i + 1) * ROW_WORDS > rows.size()) {
-        // grow the logical size in blocks of 4096 steps so the per-step cost is one bounds check; rows beyond
-        // stepCount() are scratch until recorded (consumers use stepCount(), never rows.size())
-        size_t want = (i + 4096) * ROW_WORDS;
-        if (want > rows.capacity()) rows.reserve(rows.capacity() * 2 > want ? rows.capacity() * 2 : want);
-        rows.resize(want);
+    if (i + 1 > steps.size()) {
+        // grow the logical size in blocks of 4096 steps so the per-step cost is one bounds check; records beyond
+        // stepCount() are scratch until recorded (consumers use stepCount(), never steps.size())
+        size_t want = i + 4096;
+        if (want > steps.capacity()) steps.reserve(steps.capacity() * 2 > want ? steps.capacity() * 2 : want);
+        steps.resize(want);
     }
-    return rows.data() + i * ROW_WORDS;
+    return steps.data() + i;
+}
+
+std::vector<uint64_t> ExecutionTrace::expandRows() const {
+    const size_t ns = stepCount();
+    std::vector<uint64_t> rows(ns * ROW_WORDS);
+    uint64_t regs[32];
+    memcpy(regs, initial_regs, sizeof(regs));
+    regs[0] = 0;
+    for (size_t i = 0; i < ns; i++) {
+        const zigz_trace_step &st = steps[i];
+        if (st.wr_reg) regs[st.wr_reg & 31] = st.rd_value;
+        uint64_t *row = rows.data() + i * ROW_WORDS;
+        row[0] = st.pc;
+        memcpy(row + 1, regs, sizeof(regs));  // regs_after
+        row[33] = st.opcode; row[34] = st.rd; row[35] = st.rs1; row[36] = st.rs2; row[37] = st.funct3; row[38] = st.funct7;
+        row[39] = (uint64_t)st.imm;
+        row[40] = st.mem_addr; row[41] = st.mem_value; row[42] = st.mem_is_read;
+    }
+    return rows;
 }
 
 void VMState::step() {  // state.zig:128-167
@@ -268,15 +287,24 @@ void VMState::step() {  // state.zig:128-167
         invalid_instruction = true;  // error.InvalidInstruction: no step recorded
         return;
     }
+    if (trace.stepCount() == 0) {  // register file before the first recorded step (initial_regs were written by now)
+        memcpy(trace.initial_regs, regs_, sizeof(regs_));
+        trace.initial_regs[0] = 0;
+    }
     uint64_t mem_row[3] = {0, 0, 0};
     const uint64_t pc_before = pc;
+    wr_reg_ = 0;  // every instruction writes at most one register (execute() below); x0 never changes
+    wr_val_ = 0;
     const uint64_t next_pc = execute(in, mem_row);
-    uint64_t *row = trace.appendRow();
-    row[0] = pc_before;
-    memcpy(row + 1, regs_, sizeof(regs_));  // regs_[0] stays 0: writeReg ignores x0 (registers.zig:38-48)
-    row[33] = in.opcode; row[34] = in.rd; row[35] = in.rs1; row[36] = in.rs2; row[37] = in.funct3; row[38] = in.funct7;
-    row[39] = (uint64_t)in.imm;
-    row[40] = mem_row[0]; row[41] = mem_row[1]; row[42] = mem_row[2];
+    zigz_trace_step *st = trace.appendStep();
+    st->pc = pc_before;
+    st->rd_value = wr_val_;
+    st->mem_addr = mem_row[0];
+    st->mem_value = mem_row[1];
+    st->imm = in.imm;
+    st->opcode = in.opcode; st->rd = in.rd; st->rs1 = in.rs1; st->rs2 = in.rs2; st->funct3 = in.funct3; st->funct7 = in.funct7;
+    st->wr_reg = wr_reg_;
+    st->mem_is_read = (uint8_t)mem_row[2];
     trace.is_lookup.push_back(hasLookupTable(in) ? 1 : 0);
     pc = next_pc;
     step_count++;

@@ -154,16 +154,20 @@ struct Instruction {  // rv64i.zig:111-151
 bool hasLookupTable(const Instruction &inst);  // getTableMetadata(inst) != null, instruction_table.zig:243-274
 struct Segment { uint64_t vaddr; std::vector<uint8_t> data; };  // src/elf.zig:8-11
 
-// One recorded step, already in witness-row order (prover.zig:376-390): the 43 raw 64-bit words whose
-// `mod p` are the witness cells of that step (witness.zig:76,112,164-170,237-239).
+// One recorded step = one compact record (zigz_trace_step, include/zigz_hip.h): pc, the decoded instruction fields, the one
+// register the step wrote and its memory access -- what trace.zig:73-97 `Step` holds minus the two full register files.
+// The 43 raw witness words of a step (prover.zig:376-390 column order; witness.zig:76,112,164-170,237-239) are rebuilt
+// from the records by carrying register values forward: on the GPU (zigz_dev_witness_from_steps) for proving, on the
+// host (expandRows) for callers that want the rows or the host-side WitnessGenerator.
 constexpr size_t ROW_WORDS = 43;
-struct ExecutionTrace {  // trace.zig:16-70 (steps kept as packed rows instead of Step structs)
-    std::vector<uint64_t> rows;     // [num_steps][43] raw u64 (capacity grows in large chunks; see appendRow)
-    std::vector<uint8_t> is_lookup; // per step
+struct ExecutionTrace {  // trace.zig:16-70
+    std::vector<zigz_trace_step> steps;  // capacity grows in large chunks; see appendStep
+    std::vector<uint8_t> is_lookup;      // per step
+    uint64_t initial_regs[32] = {0};     // register file before the first recorded step
     size_t stepCount() const { return is_lookup.size(); }
-    const uint64_t *row(size_t i) const { return rows.data() + i * ROW_WORDS; }
-    void reserveSteps(size_t n);    // virtual reservation only: pages are touched as steps are recorded
-    uint64_t *appendRow();          // storage of the next step's 43 words (trace.addStep)
+    void reserveSteps(size_t n);      // virtual reservation only: pages are touched as steps are recorded
+    zigz_trace_step *appendStep();    // storage of the next step's record (trace.addStep)
+    std::vector<uint64_t> expandRows() const;  // [stepCount()][43] raw u64 words
 };
 class VMState {  // state.zig:35-598
   public:
@@ -173,7 +177,9 @@ class VMState {  // state.zig:35-598
     void step();                  // throws Error (InvalidInstruction is reported via `invalid_instruction`)
     void run(size_t max_steps);   // state.zig:172-184
     uint64_t readReg(unsigned r) const { return r ? regs_[r] : 0; }
-    void writeReg(unsigned r, uint64_t v) { if (r) regs_[r] = v; }
+    void writeReg(unsigned r, uint64_t v) {
+        if (r) { regs_[r] = v; wr_reg_ = (uint8_t)r; wr_val_ = v; }
+    }
     uint64_t pc = 0;
     bool halted = false;
     bool invalid_instruction = false;  // set when step() hit error.InvalidInstruction
@@ -185,6 +191,8 @@ class VMState {  // state.zig:35-598
     struct Mem;
     Mem *mem_;
     uint64_t regs_[32] = {0};
+    uint8_t wr_reg_ = 0;   // register written by the instruction being executed (0 = none) and its value
+    uint64_t wr_val_ = 0;
     std::vector<uint64_t> input_tape_;
     size_t input_pos_ = 0;
     uint64_t execute(const Instruction &in, uint64_t *mem_row /*[3]: addr,value,is_read*/);

@@ -2,7 +2,7 @@
 // interface and DESIGN.md for the per-kernel roofline accounting.
 //
 //  K1/K2  k_bind_vec / k_bind_small   MLE bind (+ fused next-round half sums)   HBM-bound, 6 B/output-pair
-//  K2/K3  k_half_sums_vec / _small    round-polynomial half sums                HBM-bound, 4 B/element
+//  K2/K3  k_block_sums / k_half_sums_small  round-polynomial half sums, block sums   HBM-bound, 4 B/element
 //  K5     k_keccak_leaves             SHA3-256 leaf hashes                      int-VALU bound
 //  K6     k_keccak_level / _top       SHA3-256 level merges                     int-VALU bound
 //  K7     k_paths                     authentication-path gather               latency
@@ -57,6 +57,20 @@ __device__ __forceinline__ void block_add2(unsigned long long s0, unsigned long 
     }
 }
 
+// one sum per workgroup: wave shuffle -> LDS -> one atomic
+__device__ __forceinline__ void block_add1(unsigned long long v, unsigned long long *dst) {
+    __shared__ unsigned long long lds1[TPB / 64];
+    v = wave_sum(v);
+    if ((threadIdx.x & 63) == 0) lds1[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+#pragma unroll
+        for (int w = 0; w < TPB / 64; w++) t += lds1[w];
+        if (t) atomicAdd(dst, t);
+    }
+}
+
 // ------------------------------------------------------------------ K1 (+K2): MLE bind
 // One tile = TPB*UNROLL uint4 chunks of outputs.  Loads are 16 B/lane, fully coalesced (1 KiB per
 // wave instruction); 2*UNROLL independent loads are issued before the first use.
@@ -93,7 +107,7 @@ __global__ __launch_bounds__(TPB) void k_bind_vec(const uint32_t *__restrict__ i
         // a tile never straddles the middle of the output (tiles are 4096 outputs, half/2 % 4096 == 0
         // on this path), so the whole block adds to one of the two sums.
         const bool upper = (size_t)blockIdx.x * (TPB * UNROLL * 4) >= half / 2;
-        block_add2(upper ? 0 : acc, upper ? acc : 0, sums + 2 * col);
+        block_add1(acc, sums + 2 * col + (upper ? 1 : 0));
     }
 }
 
@@ -141,20 +155,36 @@ void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t
     }
 }
 
-// ------------------------------------------------------------------ K2/K3: half sums
-__global__ __launch_bounds__(TPB) void k_half_sums_vec(const uint32_t *__restrict__ in, size_t in_stride, size_t n,
-                                                       unsigned long long *__restrict__ sums) {
+// ------------------------------------------------------------------ K2/K3: block sums (half sums = 2 blocks)
+// sums[c][b] += sum of in[c][b*m .. (b+1)*m), b < n/m, m = 2^log2_m >= 256.  The unit of work is the WAVE: each wave
+// streams W = 256*iters CONTIGUOUS elements that lie inside one block (W <= m), 8 x 16-byte loads per lane in flight,
+// accumulates exactly in u64, reduces with shuffles and issues ONE atomic.  (The previous form -- one 16 KiB tile per
+// workgroup, then shuffle -> LDS -> barrier -> atomic -- spent most of a workgroup's life in that tail with no loads in
+// flight: 3.4 TB/s for 43 x 2^20 and, with every workgroup adding to the same two words, 1.2 TB/s for one 2^24 table;
+// same-address atomics serialise at ~15 ns each.)  nslots > 1 spreads the adds of one (c, b) over nslots copies of the
+// sums array, slot_stride words apart; the consumer adds the copies.
+constexpr int BS_INFLIGHT = 8;
+__global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__ in, size_t in_stride, size_t n, unsigned log2_m,
+                                                    unsigned iters, unsigned long long *__restrict__ sums, SumsLayout lay) {
     const size_t col = blockIdx.y;
-    const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride);
-    const size_t base = (size_t)blockIdx.x * (TPB * UNROLL) + threadIdx.x;
-    uint4 a[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) a[u] = p[base + (size_t)u * TPB];
+    const unsigned lane = threadIdx.x & 63;
+    const size_t wave = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    const size_t c0 = wave * (size_t)iters * 64;  // first 16-byte chunk of this wave
+    if (c0 >= n / 4) return;                      // wave-uniform; no barrier below
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride) + c0 + lane;
     unsigned long long acc = 0;
+#pragma unroll 1
+    for (unsigned it = 0; it < iters; it += BS_INFLIGHT) {
+        uint4 a[BS_INFLIGHT];
 #pragma unroll
-    for (int u = 0; u < UNROLL; u++) acc += (unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w;
-    const bool upper = (size_t)blockIdx.x * (TPB * UNROLL * 4) >= n / 2;
-    block_add2(upper ? 0 : acc, upper ? acc : 0, sums + 2 * col);
+        for (int j = 0; j < BS_INFLIGHT; j++) a[j] = p[(size_t)(it + j < iters ? it + j : iters - 1) * 64];  // clamped, not branched
+#pragma unroll
+        for (int j = 0; j < BS_INFLIGHT; j++)
+            acc += it + j < iters ? (unsigned long long)a[j].x + a[j].y + a[j].z + a[j].w : 0ull;
+    }
+    acc = wave_sum(acc);
+    if (lane == 0 && acc)
+        atomicAdd(&sums[(size_t)(wave % lay.nslots) * lay.slot_stride + col * lay.col_stride + ((c0 * 4) >> log2_m) * lay.bin_stride], acc);
 }
 
 __global__ __launch_bounds__(TPB) void k_half_sums_small(const uint32_t *__restrict__ in, size_t in_stride, size_t n,
@@ -169,46 +199,52 @@ __global__ __launch_bounds__(TPB) void k_half_sums_small(const uint32_t *__restr
     block_add2(s0, s1, sums + 2 * col);
 }
 
+static unsigned floor_log2(size_t v) { unsigned l = 0; while (v > 1) { v >>= 1; l++; } return l; }
+
+// 16-byte chunks x 64 lanes per wave iteration; aim at ~8192 waves per launch (8 per SIMD: enough bytes in flight for
+// the HBM, and as few atomics as that allows), a wave's range inside one block
+static size_t block_sums_iters(size_t n, unsigned log2_m, size_t ncols) {
+    const size_t m = (size_t)1 << log2_m;
+    size_t iters = (ncols * n / 256) / 8192;
+    iters = iters < 1 ? 1 : (size_t)1 << floor_log2(iters);
+    if (iters > m / 256) iters = m / 256;
+    if (iters > 64) iters = 64;
+    return iters;
+}
+
+SumsLayout half_sums_layout(size_t n, size_t ncols, size_t max_words) {
+    // counters in 128-byte lines of their own (atomics serialise per cache line), copies while more than 64 waves
+    // would add into one counter and the words last
+    if (n < 2048 || (n & (n - 1))) return SumsLayout{2, 1, 0, 1};
+    const size_t per_addr = (n / 2) / (256 * block_sums_iters(n, floor_log2(n) - 1, ncols));
+    size_t slots = (per_addr + 63) / 64;
+    if (slots > 64) slots = 64;
+    while (slots > 1 && slots * ncols * 32 > max_words) slots--;
+    if (ncols * 32 > max_words) return SumsLayout{2, 1, 0, 1};
+    return SumsLayout{32, 16, ncols * 32, (unsigned)(slots < 1 ? 1 : slots)};
+}
+
+void launch_block_sums(const uint32_t *d_in, size_t in_stride, size_t n, unsigned log2_m, size_t ncols,
+                       unsigned long long *d_sums, SumsLayout lay, hipStream_t s, const KTime *kt) {
+    const size_t iters = block_sums_iters(n, log2_m, ncols);
+    const size_t waves = n / (256 * iters);
+    if (lay.nslots == 0) lay.nslots = 1;
+    dim3 grid((unsigned)((waves + TPB / 64 - 1) / (TPB / 64)), (unsigned)ncols);
+    ZK_LAUNCH(kt, k_block_sums, grid, dim3(TPB), 0, s, d_in, in_stride, n, log2_m, (unsigned)iters, d_sums, lay);
+}
+
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols, unsigned long long *d_sums,
-                      hipStream_t s, const KTime *kt) {
+                      hipStream_t s, const KTime *kt, const SumsLayout *lay) {
     if (n == 0 || ncols == 0) return;
-    if (n >= 2 * (size_t)(4 * TPB * UNROLL) && in_stride % 4 == 0 && aligned16(d_in)) {
-        dim3 grid((unsigned)(n / (4 * TPB * UNROLL)), (unsigned)ncols);
-        ZK_LAUNCH(kt, k_half_sums_vec, grid, dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
+    if (n >= 2048 && (n & (n - 1)) == 0 && in_stride % 4 == 0 && aligned16(d_in)) {
+        launch_block_sums(d_in, in_stride, n, floor_log2(n) - 1, ncols, d_sums, lay ? *lay : SumsLayout{2, 1, 0, 1}, s, kt);
     } else {
+        // (only reached with the plain layout: half_sums_layout returns it for these shapes; unaligned callers pass none)
         ZK_LAUNCH(kt, k_half_sums_small, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, n, d_sums);
     }
 }
 
 // ------------------------------------------------------------------ radix-2^k sumcheck stage
-// Block sums of 2^k contiguous blocks of m elements: every wave-level 256-element segment lies inside one block
-// (m >= 256), so it is reduced by shuffles and costs one u64 atomic.
-__global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__ in, size_t n, unsigned log2_m,
-                                                    unsigned long long *__restrict__ sums) {
-    const uint4 *p = reinterpret_cast<const uint4 *>(in);
-    const size_t base = (size_t)blockIdx.x * (TPB * UNROLL) + threadIdx.x;
-    const size_t chunks = n / 4;
-    uint4 a[UNROLL];
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-        const size_t c = base + (size_t)u * TPB;
-        a[u] = p[c < chunks ? c : chunks - 1];  // clamped, not branched: the UNROLL loads stay back to back
-    }
-#pragma unroll
-    for (int u = 0; u < UNROLL; u++) {
-        const size_t c = base + (size_t)u * TPB;
-        const unsigned long long mine = (unsigned long long)a[u].x + a[u].y + a[u].z + a[u].w;
-        unsigned long long v = wave_sum(c < chunks ? mine : 0ull);
-        if ((threadIdx.x & 63) == 0 && c < chunks && v) atomicAdd(&sums[(c * 4) >> log2_m], v);
-    }
-}
-
-void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s,
-                       const KTime *kt) {
-    const size_t chunks = n / 4, per_block = (size_t)TPB * UNROLL;
-    ZK_LAUNCH(kt, k_block_sums, dim3((unsigned)((chunks + per_block - 1) / per_block)), dim3(TPB), 0, s, d_in, n, log2_m, d_sums);
-}
-
 // Radix-2^k fold  T'[i] = sum_b W[b] * T[b*m + i].  Work split: a workgroup owns 1024 consecutive outputs (one
 // 16-byte load per lane per table row) and RB*RLOOPS = 64 CONSECUTIVE rows, i.e. it streams one contiguous range when
 // m = 1024 and long row segments otherwise -- the HBM access pattern of k_bind_vec.  Each (row-group g, output i)
@@ -415,6 +451,122 @@ void launch_witness_rows(const uint64_t *d_rows, size_t num_steps, size_t npad, 
     if (num_steps == 0) return;
     hipLaunchKernelGGL(k_witness_rows, dim3((unsigned)((npad + WTILE - 1) / WTILE)), dim3(TPB), 0, s, d_rows, num_steps, npad,
                        d_cols, stride);
+}
+
+// ------------------------------------------------------------------ K8 from the compact trace
+// One wave = one chunk of 64 consecutive steps.  Register r's column is the fill-forward of the values written to r:
+//   pass 1 (k_steps_summary)  per chunk and register: the last value written inside the chunk, if any
+//   pass 2 (k_steps_scan)     per register: carry[r][chunk] = value of r before the chunk (fill-forward over chunks)
+//   pass 3 (k_steps_expand)   per step: last write to r at or before the step inside the chunk (ballot + prefix mask +
+//                             find-last-set + cross-lane read), else the carry; 43 coalesced 256-byte column stores.
+// Reads 48 B and writes 172 B per step (the packed-rows kernel reads 344 B); the H2D of the trace shrinks by 7.2x.
+__device__ __forceinline__ uint32_t mod_p64(uint64_t x) { return (uint32_t)(x % (uint64_t)P); }
+
+__global__ __launch_bounds__(TPB) void k_steps_summary(const TraceStep *__restrict__ steps, size_t num_steps, size_t nchunks,
+                                                       uint32_t *__restrict__ sum_val, uint32_t *__restrict__ sum_has) {
+    const size_t chunk = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;  // wave-uniform
+    const unsigned lane = threadIdx.x & 63;
+    const size_t i = chunk * 64 + lane;
+    unsigned wr = 0;
+    uint32_t val = 0;
+    if (i < num_steps) {
+        wr = steps[i].wr_reg;
+        val = mod_p64(steps[i].rd_value);
+    }
+    uint32_t mine = 0;  // lane r keeps register r's summary
+    unsigned long long has = 0;
+#pragma unroll 1
+    for (unsigned r = 1; r < 32; r++) {
+        const unsigned long long mask = __ballot(wr == r);
+        if (mask) {  // wave-uniform
+            const int j = 63 - __builtin_clzll(mask);
+            const uint32_t v = __shfl(val, j, 64);
+            if (lane == r) mine = v;
+            has |= 1ull << r;
+        }
+    }
+    if (lane >= 1 && lane < 32) sum_val[(size_t)lane * nchunks + chunk] = mine;
+    if (lane == 0) sum_has[chunk] = (uint32_t)has;
+}
+
+// one workgroup per register: every thread fill-forwards a contiguous range of chunks, thread 0 chains the 256 ranges
+__global__ __launch_bounds__(TPB) void k_steps_scan(const uint32_t *__restrict__ sum_val, const uint32_t *__restrict__ sum_has,
+                                                    size_t nchunks, Regs32 init, uint32_t *__restrict__ carry) {
+    __shared__ uint32_t last_val[TPB];
+    __shared__ uint32_t last_has[TPB];
+    const unsigned r = blockIdx.x + 1;
+    const size_t per = (nchunks + TPB - 1) / TPB;
+    const size_t lo = (size_t)threadIdx.x * per, hi = lo + per < nchunks ? lo + per : nchunks;
+    const uint32_t *sv = sum_val + (size_t)r * nchunks;
+    uint32_t v = 0, h = 0;
+    for (size_t c = lo; c < hi; c++)
+        if ((sum_has[c] >> r) & 1u) { v = sv[c]; h = 1; }
+    last_val[threadIdx.x] = v;
+    last_has[threadIdx.x] = h;
+    __syncthreads();
+    if (threadIdx.x == 0) {  // exclusive fill-forward over the 256 ranges, starting from the initial register value
+        uint32_t cur = init.v[r];
+        for (int t = 0; t < TPB; t++) {
+            const uint32_t nv = last_has[t] ? last_val[t] : cur;
+            last_val[t] = cur;
+            cur = nv;
+        }
+    }
+    __syncthreads();
+    uint32_t cur = last_val[threadIdx.x];
+    uint32_t *cr = carry + (size_t)r * nchunks;
+    for (size_t c = lo; c < hi; c++) {
+        cr[c] = cur;
+        if ((sum_has[c] >> r) & 1u) cur = sv[c];
+    }
+}
+
+__global__ __launch_bounds__(TPB) void k_steps_expand(const TraceStep *__restrict__ steps, size_t num_steps, size_t npad,
+                                                      const uint32_t *__restrict__ carry, size_t nchunks,
+                                                      uint32_t *__restrict__ cols, size_t stride) {
+    const size_t chunk = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
+    if (chunk >= nchunks) return;  // wave-uniform
+    const unsigned lane = threadIdx.x & 63;
+    const size_t i = chunk * 64 + lane;
+    const bool live = i < num_steps, store = i < npad;
+    const TraceStep st = steps[live ? i : num_steps - 1];  // padding repeats the last step's pc (witness.zig:80-87)
+    const unsigned wr = live ? st.wr_reg : 0;
+    const uint32_t val = mod_p64(st.rd_value);
+    if (store) {
+        cols[i] = mod_p64(st.pc);                                   // column 0: pc
+        cols[1 * stride + i] = 0;                                   // x0
+        cols[33 * stride + i] = live ? st.opcode : 0;               // instruction fields pad with 0 (witness.zig:174-182)
+        cols[34 * stride + i] = live ? st.rd : 0;
+        cols[35 * stride + i] = live ? st.rs1 : 0;
+        cols[36 * stride + i] = live ? st.rs2 : 0;
+        cols[37 * stride + i] = live ? st.funct3 : 0;
+        cols[38 * stride + i] = live ? st.funct7 : 0;
+        cols[39 * stride + i] = live ? mod_p64((uint64_t)st.imm) : 0;  // u64(bitcast(i64 imm)) mod p (witness.zig:170)
+        cols[40 * stride + i] = live ? mod_p64(st.mem_addr) : 0;    // memory columns pad with 0 (witness.zig:249-253)
+        cols[41 * stride + i] = live ? mod_p64(st.mem_value) : 0;
+        cols[42 * stride + i] = live ? st.mem_is_read : 0;
+    }
+    const unsigned long long le = lane == 63 ? ~0ull : ((2ull << lane) - 1);  // lanes <= mine
+#pragma unroll 1
+    for (unsigned r = 1; r < 32; r++) {
+        const unsigned long long m = __ballot(wr == r) & le;
+        const int src = m ? 63 - __builtin_clzll(m) : 0;
+        const uint32_t w = __shfl(val, src, 64);
+        const uint32_t v = m ? w : carry[(size_t)r * nchunks + chunk];
+        if (store) cols[(size_t)(1 + r) * stride + i] = v;  // registers repeat their last value in the padding (:116-123)
+    }
+}
+
+void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
+                          uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand) {
+    if (num_steps == 0) return;
+    const size_t nchunks = (npad + 63) / 64;
+    uint32_t *sum_val = d_ws, *carry = d_ws + 32 * nchunks, *sum_has = d_ws + 64 * nchunks;
+    const dim3 grid((unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64)));
+    hipLaunchKernelGGL(k_steps_summary, grid, dim3(TPB), 0, s, d_steps, num_steps, nchunks, sum_val, sum_has);
+    hipLaunchKernelGGL(k_steps_scan, dim3(31), dim3(TPB), 0, s, sum_val, sum_has, nchunks, init, carry);
+    ZK_LAUNCH(kt_expand, k_steps_expand, grid, dim3(TPB), 0, s, d_steps, num_steps, npad, carry, nchunks, d_cols, stride);
 }
 
 static unsigned stream_grid(size_t n) {

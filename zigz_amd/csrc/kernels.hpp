@@ -29,6 +29,21 @@ void launch_reduce_u64(const uint64_t *d_in, uint32_t *d_out, size_t n, hipStrea
 void launch_witness_rows(const uint64_t *d_rows, size_t num_steps, size_t npad, uint32_t *d_cols, size_t stride,
                          hipStream_t s);
 void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream_t s);
+// K8 from the compact trace (include/zigz_hip.h: zigz_trace_step, 48 B per step; TraceStep is its device mirror).
+// Three launches: per-64-step summaries of the register writes, a fill-forward scan over the chunks per register, the
+// expansion into the 43 padded columns.  ws: (65 * nchunks + 64) u32 of scratch, nchunks = ceil(npad / 64).
+struct TraceStep {
+    uint64_t pc, rd_value, mem_addr, mem_value;
+    int64_t imm;
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7, wr_reg, mem_is_read;
+};
+static_assert(sizeof(TraceStep) == 48, "TraceStep must mirror zigz_trace_step (48 bytes)");
+struct Regs32 {
+    uint32_t v[32];  // initial register values mod p (x0 = 0)
+};
+inline size_t witness_steps_ws_words(size_t npad) { return 65 * ((npad + 63) / 64) + 64; }
+void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
+                          uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand = nullptr);
 
 // K1 (+K2 fused): batched MLE bind.  For column c in [0,ncols):
 //   out[c*out_stride + i] = in[c*in_stride + i] + r_c * (in[c*in_stride + i + half] - in[...+ i]),  i < half
@@ -40,14 +55,27 @@ void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t
 // true when launch_bind takes the vectorised k_bind_vec path for these arguments
 bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out);
 inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
-// K2/K3: sums[2c] += sum in[0..n/2), sums[2c+1] += sum in[n/2..n)   (n >= 2); n == 1: sums[2c] += in[0]
+// Where k_block_sums adds its partial sums: counter of (column c, block b, copy k) = sums[k*slot_stride + c*col_stride +
+// b*bin_stride], copy k = wave index mod nslots.  u64 atomics serialise per 128-byte cache line (~15 ns each), so when
+// few counters receive many partial sums they sit in lines of their own and are replicated; the consumer adds the copies.
+struct SumsLayout {
+    size_t col_stride, bin_stride, slot_stride;
+    unsigned nslots;
+};
+// layout for half sums of ncols tables of n elements within max_words u64 of sums space: padded + replicated when the
+// vector path runs and the words suffice, the plain {2, 1, 0, 1} (sums[2c], sums[2c+1]) otherwise
+SumsLayout half_sums_layout(size_t n, size_t ncols, size_t max_words);
+// K2/K3: (plain layout) sums[2c] += sum in[0..n/2), sums[2c+1] += sum in[n/2..n)   (n >= 2); n == 1: sums[2c] += in[0].
+// lay: optional non-plain layout from half_sums_layout (aligned power-of-two tables of >= 2048 elements only).
 void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t ncols,
-                      unsigned long long *d_sums, hipStream_t s, const KTime *kt = nullptr);
+                      unsigned long long *d_sums, hipStream_t s, const KTime *kt = nullptr, const SumsLayout *lay = nullptr);
 
-// Radix-2^k sumcheck stage (k rounds per pass over the table; see DESIGN.md "Sumcheck"):
-//  (1) block sums: sums[b] += sum of in[b*m .. (b+1)*m), b < n/m   (m = 2^log2_m >= 256, n >= 1024, exact u64)
-void launch_block_sums(const uint32_t *d_in, size_t n, unsigned log2_m, unsigned long long *d_sums, hipStream_t s,
-                       const KTime *kt = nullptr);
+// Block sums (k_block_sums): counter(c, b) += sum of in[c][b*m .. (b+1)*m), b < n/m, m = 2^log2_m >= 256,
+// n a power of two >= 2*m, exact u64; sums must be zeroed by the caller.  Serves roundPolynomial /
+// sumOverHypercube (2 blocks) and the radix-2^k sumcheck stage (<= 1024 blocks; see DESIGN.md "Sumcheck").
+void launch_block_sums(const uint32_t *d_in, size_t in_stride, size_t n, unsigned log2_m, size_t ncols,
+                       unsigned long long *d_sums, SumsLayout lay, hipStream_t s, const KTime *kt = nullptr);
+// Radix-2^k sumcheck stage (k rounds per pass over the table; pass 1 = launch_block_sums):
 //  (2) part[c][g][i] = sum over the g-th group of 64 consecutive b of W[c][b] * in[c][b*m + i]   (exact u64; i < m,
 //      m % 4 == 0, column c < ncols; W in Montgomery form; G = radix_fold_groups(nb) groups; strides in elements)
 size_t radix_fold_groups(size_t nb);

@@ -13,6 +13,11 @@ from ._ffi import BenchResult, KernelStats, lib, u8p, u64p, vp
 
 P = 2013265921
 NUM_COLUMNS = 43
+# zigz_trace_step (include/zigz_hip.h): one compact record per executed step, 48 bytes
+TRACE_STEP_DTYPE = np.dtype([("pc", "<u8"), ("rd_value", "<u8"), ("mem_addr", "<u8"), ("mem_value", "<u8"), ("imm", "<i8"),
+                             ("opcode", "u1"), ("rd", "u1"), ("rs1", "u1"), ("rs2", "u1"), ("funct3", "u1"), ("funct7", "u1"),
+                             ("wr_reg", "u1"), ("mem_is_read", "u1")])
+assert TRACE_STEP_DTYPE.itemsize == 48
 
 
 def _name(code):
@@ -97,6 +102,16 @@ class Context:
         """WitnessGenerator.generate on the device from packed trace rows [num_steps, 43] (raw u64)."""
         rows = np.ascontiguousarray(rows, dtype=np.uint64)
         self.check(lib.zigz_dev_witness_from_rows(self.h, rows.ctypes.data_as(u64p), rows.shape[0], nv, vp(d_cols), stride))
+
+    def witness_from_steps(self, steps, nv, d_cols, stride, initial_regs=None):
+        """WitnessGenerator.generate on the device from compact records (structured array of TRACE_STEP_DTYPE)."""
+        steps = np.ascontiguousarray(steps, dtype=TRACE_STEP_DTYPE)
+        ir = None
+        if initial_regs is not None:
+            ira = np.ascontiguousarray(initial_regs, dtype=np.uint64)
+            assert ira.size == 32
+            ir = ira.ctypes.data_as(u64p)
+        self.check(lib.zigz_dev_witness_from_steps(self.h, vp(steps.ctypes.data), steps.shape[0], nv, ir, vp(d_cols), stride))
 
     def download(self, d_ptr, n):
         o, op = _out_u64(n)

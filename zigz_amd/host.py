@@ -32,6 +32,9 @@ SIGNATURES = {
     "zigzh_trace_num_vars": (C.c_size_t, [vp]),
     "zigzh_trace_num_lookups": (C.c_size_t, [vp]),
     "zigzh_trace_rows": (u64p, [vp]),
+    "zigzh_trace_steps": (vp, [vp]),
+    "zigzh_trace_initial_regs": (u64p, [vp]),
+    "zigzh_trace_pin": (C.c_int, [vp, vp]),
     "zigzh_trace_witness": (C.c_int, [vp, u64p]),
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
@@ -135,6 +138,18 @@ class Trace:
     def rows(self):
         p = lib.zigzh_trace_rows(self.h)
         return np.ctypeslib.as_array(p, shape=(self.num_steps, 43)).copy()
+
+    def steps(self):
+        """The compact records (numpy structured array, dtype hip.TRACE_STEP_DTYPE) and the initial register file."""
+        from .hip import TRACE_STEP_DTYPE
+        n = self.num_steps
+        buf = (C.c_uint8 * (n * 48)).from_address(lib.zigzh_trace_steps(self.h))
+        regs = np.ctypeslib.as_array(lib.zigzh_trace_initial_regs(self.h), shape=(32,)).copy()
+        return np.frombuffer(buf, dtype=TRACE_STEP_DTYPE, count=n).copy(), regs
+
+    def pin(self, ctx):
+        """Page-lock the records: repeated witness_to_device uploads then run at PCIe rate."""
+        _check(lib.zigzh_trace_pin(self.h, ctx.h))
 
     def witness(self):
         """WitnessGenerator.generate: [43, 2^nv] canonical uint64 (host)."""
