@@ -303,7 +303,7 @@ def main():
 
         def upload_and_prove(self):  # PCIe-inclusive: the compact trace (48 B per step) crosses PCIe and the witness
             # kernels rebuild the 43 columns inside the loop
-            self.trace.witness_to_device(self.ctx, self.d_cols, N)
+            self.trace.witness_to_device(self.ctx, self.d_cols, N, wait=False)  # enqueued; the proof's builds follow on the stream
             return self.prove()
 
     allgather_hook = host.make_allgather(dist) if (shard and dist is not None) else None

@@ -203,6 +203,11 @@ typedef struct zigz_trace_step {
  * pageable or pinned (zigz_host_register) memory; the call returns when the copy has completed. */
 zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
                                         const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride);
+/* The same, without waiting: copy, expansion and whatever the caller enqueues next (zigz_commit_begin_dev on d_cols)
+ * run on the context's stream underneath the host's transcript work.  h_steps MUST be page-locked (zigz_host_register)
+ * and stay unmodified until the stream has passed the copy (zigz_commit_roots / zigz_ctx_synchronize). */
+zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                              const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride);
 /* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
  * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer. */
 zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes);

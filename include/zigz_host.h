@@ -51,6 +51,9 @@ int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx);
 int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out);
 /* builds the 43 witness columns directly in HBM (packed u32, column stride `stride` elements) */
 int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride);
+/* the same without waiting for the copy (the trace must be pinned on this context: zigzh_trace_pin); the upload and
+ * the witness kernels then run underneath the transcript work of the zigzh_prove_trace call that follows */
+int zigzh_trace_witness_dev_async(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride);
 /* steps [4/6]..[6/6] + packagePublicIO for an executed trace; d_cols == NULL: host witness is generated and
  * uploaded; otherwise the resident columns are used.  want_bytes: 0 = proof struct only; 1 = also serialize ("ZIGZ"
  * v1) into a malloc'd buffer the caller frees with zigzh_free; 2 = serialize with the early sections written on a

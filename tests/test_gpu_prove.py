@@ -78,6 +78,28 @@ def test_prove_programs_vs_oracle(ctx, maker, arg):
     assert host.verify(proof, prog) == "Accept"
 
 
+@pytest.mark.parametrize("maker,arg", [("mixed_loop", 300), ("fibonacci", 2500)])
+def test_prove_from_pinned_compact_trace_async(ctx, maker, arg):
+    """The service path of bench.py's PCIe-inclusive leg: pinned compact trace -> asynchronous upload + witness kernels
+    -> proof on the resident columns, three times over the same buffers; bytes identical to the oracle's proof."""
+    from zigz_amd import host
+    r = getattr(programs, maker)(arg)
+    prog, inp = r if isinstance(r, tuple) else (r, None)
+    oproof, ons = O.prove(P, prog, 0x1000, None, 1 << 20, inp)
+    tr = host.Trace(prog, 0x1000, None, 1 << 20, inp)
+    N = 1 << tr.num_vars
+    d = ctx.dev_alloc(43 * max(N, 4) * 4)
+    try:
+        tr.pin(ctx)
+        for _ in range(3):
+            tr.witness_to_device(ctx, d, max(N, 4), wait=False)
+            proof = tr.prove(ctx, d, max(N, 4), want_bytes=True)
+            assert tr.num_steps == ons and proof == oproof
+    finally:
+        ctx.dev_free(d)
+        del tr
+
+
 def test_prove_config2_fibonacci_2_16_bit_exact(ctx):
     """BASELINE config 2: fibonacci proved end-to-end at a 2^16 trace, byte-identical to the CPU oracle
     (literal reference algorithm: naive eval twice per column, recompute-on-open Merkle)."""

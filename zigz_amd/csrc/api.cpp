@@ -19,7 +19,7 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_SLOTS };
 
 struct zigz_ctx {
     int device;
@@ -346,23 +346,34 @@ extern "C" zigz_status zigz_dev_witness_from_rows(zigz_ctx *ctx, const uint64_t 
 
 static_assert(sizeof(zigz_trace_step) == sizeof(TraceStep), "zigz_trace_step and its device mirror differ");
 
-extern "C" zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
-                                                   const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride) {
-    ZIGZ_ENTER(ctx);
+static zigz_status witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                      const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride, bool wait) {
     if (!ctx || !h_steps || !d_cols || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (num_steps == 0) return ZIGZ_ERR_EMPTY_TRACE;
     const size_t npad = (size_t)1 << nv;
     if (num_steps > npad || (nv > 0 && num_steps <= npad / 2) || col_stride < npad) return ZIGZ_ERR_INVALID_ARGUMENT;
     void *d_steps, *d_ws;
     CHK(ws_get(ctx, WS_IN64, num_steps * sizeof(zigz_trace_step), &d_steps));
-    CHK(ws_get(ctx, WS_SCRATCH, witness_steps_ws_words(npad) * 4, &d_ws));
+    CHK(ws_get(ctx, WS_WITNESS, witness_steps_ws_words(npad) * 4, &d_ws));
     HIPCHK(ctx, hipMemcpyAsync(d_steps, h_steps, num_steps * sizeof(zigz_trace_step), hipMemcpyHostToDevice, ctx->stream));
     Regs32 init;
     for (int r = 0; r < 32; r++) init.v[r] = (r && initial_regs) ? (uint32_t)(initial_regs[r] % (uint64_t)P) : 0u;
     launch_witness_steps((const TraceStep *)d_steps, num_steps, npad, init, (uint32_t *)d_ws, d_cols, col_stride, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_steps may be reused by the caller as soon as this returns
+    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));  // h_steps may be reused by the caller as soon as this returns
     return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                                   const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride) {
+    ZIGZ_ENTER(ctx);
+    return witness_from_steps(ctx, h_steps, num_steps, nv, initial_regs, d_cols, col_stride, true);
+}
+extern "C" zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps,
+                                                         size_t nv, const uint64_t *initial_regs, uint32_t *d_cols,
+                                                         size_t col_stride) {
+    ZIGZ_ENTER(ctx);
+    return witness_from_steps(ctx, h_steps, num_steps, nv, initial_regs, d_cols, col_stride, false);
 }
 
 extern "C" zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes) {

@@ -37,6 +37,7 @@ SIGNATURES = {
     "zigzh_trace_pin": (C.c_int, [vp, vp]),
     "zigzh_trace_witness": (C.c_int, [vp, u64p]),
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
+    "zigzh_trace_witness_dev_async": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
     "zigzh_prove_trace_sharded": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.POINTER(u8p), szp]),
     "zigzh_vm_run": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, szp]),
@@ -157,8 +158,12 @@ class Trace:
         _check(lib.zigzh_trace_witness(self.h, cols.ctypes.data_as(u64p)))
         return cols
 
-    def witness_to_device(self, ctx, d_cols, stride):
-        _check(lib.zigzh_trace_witness_dev(self.h, ctx.h, vp(d_cols), stride))
+    def witness_to_device(self, ctx, d_cols, stride, wait=True):
+        """Upload the compact records and build the 43 columns in HBM.  wait=False: enqueue only (pinned traces)."""
+        if wait:
+            _check(lib.zigzh_trace_witness_dev(self.h, ctx.h, vp(d_cols), stride))
+        else:
+            _check(lib.zigzh_trace_witness_dev_async(self.h, ctx.h, vp(d_cols), stride))
 
     def prove(self, ctx, d_cols=None, stride=0, want_bytes=True):
         """want_bytes: True -> proof bytes; False -> None (proof struct only);
