@@ -323,13 +323,23 @@ def main():
         return [f.result() for f in [pool.submit(fn, l) for l in ls]]
 
     def timed(steps, fn=Lane.prove, which=None):
-        """exactly `steps` steps between barrier + synchronize brackets; returns (seconds, accumulated stats)"""
+        """Exactly `steps` steps (= steps x len(lanes) proofs) between barrier + synchronize brackets.  Every lane proves its
+        `steps` traces back to back on its own host thread + HIP stream -- a proving service does not run its lanes in
+        lockstep -- and the region ends when the last lane has finished.  Returns (seconds, accumulated stats, phases)."""
+        ls = lanes if which is None else which
         acc = {}
         phases = {}
+
+        def lane_loop(l):
+            out = []
+            for _ in range(steps):
+                out.append(fn(l))
+            return out
         sync_all()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            for st, ph in run_step(fn, which):
+        futs = [pool.submit(lane_loop, l) for l in ls]
+        for f in futs:
+            for st, ph in f.result():
                 for k, v in st.items():
                     acc[k] = acc.get(k, 0) + v
                 for k, v in ph.items():
