@@ -226,6 +226,31 @@ zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t 
                                     const uint64_t *fixed_challenges, uint64_t *rounds, uint64_t *point,
                                     uint64_t *final_eval);
 
+/* ---------------------------------------------------------------- one sumcheck over several GPUs (row sharding)
+ * SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) of ONE table of n = n_local * world elements, element i on
+ * rank i mod world at local index i / world (so every MSB-first bind pair of partialEval, multilinear.zig:166-173, is
+ * rank-local).  Radix form: per stage of k <= 10 rounds the ranks exchange 2^k exact u64 partial block sums, then one
+ * exchange re-assembles the last <= 1024 * world entries: 2-3 exchanges per proof, all through `allgather` (every rank
+ * contributes `bytes` from `send`; `recv` gets world * bytes in rank order; return 0 on success -- bind it to RCCL,
+ * MPI or torch.distributed).  Every rank returns the same rounds / point / final_eval as the unsharded prover. */
+typedef int (*zigz_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
+zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, int rank, int world,
+                                            zigz_allgather_fn allgather, void *user, uint64_t *rounds, uint64_t *point,
+                                            uint64_t *final_eval);
+/* The same orchestration over caller-supplied data passes on the local table (what the GPU passes of the call above do):
+ * block_sums: exact u64 sums of the 2^k contiguous blocks of the current table; fold: current := sum_b w[b] *
+ * current[b*m + i] (2^k canonical weights, m = length / 2^k) and, when k_next != 0, the 2^k_next block sums of the result;
+ * read_tail: the current table (m canonical values).  Each returns a zigz_status.  No GPU is touched. */
+typedef struct zigz_radix_ops {
+    void *user;
+    zigz_status (*block_sums)(void *user, unsigned k, uint64_t *sums);
+    zigz_status (*fold)(void *user, unsigned k, const uint64_t *weights, unsigned k_next, uint64_t *next_sums);
+    zigz_status (*read_tail)(void *user, size_t m, uint64_t *out);
+} zigz_radix_ops;
+zigz_status zigz_sumcheck_radix_run(const zigz_radix_ops *ops, size_t n_local, int rank, int world,
+                                    zigz_allgather_fn allgather, void *comm_user, const uint64_t *fixed_challenges,
+                                    uint64_t *rounds, uint64_t *point, uint64_t *final_eval);
+
 /* ---------------------------------------------------------------- host SHA3 sponge / transcript
  * FiatShamirTranscript   src/core/hash.zig:255-324 (sequential by construction: stays on the host) */
 zigz_transcript *zigz_transcript_new(void);

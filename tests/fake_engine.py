@@ -69,6 +69,30 @@ class FakeOps:
         return rounds, point, int(cur[0])
 
 
+class FakeRadixOps:
+    """The three data passes of the radix sumcheck (zigz_radix_ops) on a numpy table, exact Python-int arithmetic:
+    what k_block_sums / k_radix_fold + k_radix_finalize do on the GPU."""
+
+    def __init__(self, table):
+        self.t = [int(x) for x in table]
+
+    def block_sums(self, k):
+        m = len(self.t) >> k
+        return [sum(self.t[b * m:(b + 1) * m]) for b in range(1 << k)]  # exact, unreduced (like the u64 sums)
+
+    def fold(self, k, weights, k_next):
+        m = len(self.t) >> k
+        self.t = [sum(weights[b] * self.t[b * m + i] for b in range(1 << k)) % P for i in range(m)]
+        if not k_next:
+            return None
+        m2 = m >> k_next
+        return [sum(self.t[b * m2:(b + 1) * m2]) for b in range(1 << k_next)]
+
+    def read_tail(self, m):
+        assert m == len(self.t)
+        return self.t
+
+
 class FakeTreeOps:
     """Local subtree work of shard.RowShardedMerkle on the oracle."""
 

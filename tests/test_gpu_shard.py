@@ -34,6 +34,25 @@ def _worker(rank, world, port, q):
         ops = shard.GpuOps(ctx)
         local = ops.upload(shard.interleave_rows(table, rank, world))
         r, p, fe = shard.sumcheck_prove_row_sharded(ops, local, 1 << 16, dist, zigz_amd.Transcript)
+        # the product path: radix form orchestrated in C++ (2-3 all-gathers per proof), same table + a 2^22 table timed
+        d_loc = ctx.dev_alloc((1 << 16) // world * 4)
+        ctx.upload(shard.interleave_rows(table, rank, world), d_loc)
+        cb = shard.make_allgather(dist)
+        r2, p2, fe2 = shard.sumcheck_prove_row_sharded_radix(ctx, d_loc, (1 << 16) // world, dist, cb)
+        ctx.dev_free(d_loc)
+        big = O.splitmix64_field(1888, 1 << 22)
+        d_big = ctx.dev_alloc((1 << 22) // world * 4)
+        ctx.upload(shard.interleave_rows(big, rank, world), d_big)
+        import time
+        shard.sumcheck_prove_row_sharded_radix(ctx, d_big, (1 << 22) // world, dist, cb)  # warm-up (workspaces)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(5):
+            rb, pb, feb = shard.sumcheck_prove_row_sharded_radix(ctx, d_big, (1 << 22) // world, dist, cb)
+        ms_sharded = (time.perf_counter() - t0) / 5 * 1e3
+        ctx.dev_free(d_big)
+        radix = dict(rounds=r2.tolist(), point=p2.tolist(), fe=fe2, big_rounds=rb.tolist(), big_point=pb.tolist(), big_fe=feb,
+                     ms_2p22=ms_sharded)
         ops.close()
         nm = 1 << 14
         vals = O.splitmix64_field(199, nm)
@@ -56,7 +75,7 @@ def _worker(rank, world, port, q):
         ctx.dev_free(d)
         q.put((rank, {k: (v.tolist() if hasattr(v, "tolist") else v) for k, v in res.items()},
                dict(rounds=r.tolist(), point=p.tolist(), fe=fe), dict(root=t.root.hex(), height=t.height, opens=opens),
-               dict(sha3=hashlib.sha3_256(sharded).hexdigest(), n=len(sharded), nv=tr.num_vars)))
+               dict(sha3=hashlib.sha3_256(sharded).hexdigest(), n=len(sharded), nv=tr.num_vars), radix))
     finally:
         ctx.close()
         dist.destroy_process_group()
@@ -85,7 +104,24 @@ def test_sharded_paths_world2_on_gpu():
     import programs
     prog, inp = programs.fibonacci(700)
     oproof, _ = O.prove(P, prog, 0x1000, None, 1 << 14, inp)
-    for rank, got, sc, mk, pr in outs:
+    big = O.splitmix64_field(1888, 1 << 22)
+    import zigz_amd
+    with zigz_amd.Context(0) as c1:  # the unsharded GPU prover on the same 2^22 table (itself oracle-checked elsewhere)
+        rb, pb, feb = c1.sumcheck_prove(big)
+        import time
+        d = c1.dev_alloc((1 << 22) * 4)
+        c1.upload(big, d)
+        c1.dev_sumcheck_prove(d, 1 << 22)
+        t0 = time.perf_counter()
+        for _ in range(5):
+            c1.dev_sumcheck_prove(d, 1 << 22)
+        ms_single = (time.perf_counter() - t0) / 5 * 1e3
+        c1.dev_free(d)
+    for rank, got, sc, mk, pr, rx in outs:
+        assert rx["rounds"] == [int(x) for x in r] and rx["point"] == [int(x) for x in p] and rx["fe"] == fe, rank
+        assert rx["big_rounds"] == [int(x) for x in rb] and rx["big_point"] == [int(x) for x in pb] and rx["big_fe"] == feb
+        print("rank %d: row-sharded radix sumcheck 2^22 over 2 ranks (gloo exchanges, one GPU): %.3f ms; unsharded %.3f ms"
+              % (rank, rx["ms_2p22"], ms_single))
         assert pr["nv"] >= 11 and pr["n"] == len(oproof) and pr["sha3"] == hashlib.sha3_256(oproof).hexdigest(), rank
         assert mk["root"] == mroot.hex() and mk["height"] == mheight
         for idx, sib, dirs, leaf in mk["opens"]:

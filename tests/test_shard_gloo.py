@@ -54,6 +54,12 @@ def _worker(rank, world, port, kind, q):
                 opens.append((idx, sib.tobytes().hex(), dirs.tobytes().hex(), leaf))
             t.close()
             q.put((rank, dict(root=t.root.hex(), height=t.height, opens=opens)))
+        elif kind.startswith("radix"):
+            nv = int(kind.split(":")[1])
+            table = O.splitmix64_field(880 + nv, 1 << nv)
+            local = shard.interleave_rows(table, rank, world)
+            r, p, fe = shard.sumcheck_radix_run(fake_engine.FakeRadixOps(local), len(local), dist)
+            q.put((rank, dict(rounds=r.tolist(), point=p.tolist(), fe=fe)))
         else:
             nv = 9
             table = O.splitmix64_field(88, 1 << nv)
@@ -107,6 +113,33 @@ def test_row_sharded_sumcheck_gloo(world):
     r, p, fe = O.sumcheck_prove(P, table)
     for rank in range(world):
         assert out[rank]["rounds"] == [int(x) for x in r] and out[rank]["point"] == [int(x) for x in p] and out[rank]["fe"] == fe
+
+
+@pytest.mark.parametrize("world,nv", [(2, 13), (4, 13), (2, 12), (4, 14), (2, 3), (4, 2), (2, 1)])
+def test_row_sharded_radix_sumcheck_gloo(world, nv):
+    """The C++ radix orchestration of zigz_dev_sumcheck_prove_sharded (zigz_sumcheck_radix_run: same code, stand-in
+    data passes) with world ranks over gloo: 2-3 all-gathers per proof; rounds, challenges and final_eval equal the
+    unsharded reference prover's on every rank -- with device stages (local tables >= 2^11) and without."""
+    out = _run(world, "radix:%d" % nv)
+    table = O.splitmix64_field(880 + nv, 1 << nv)
+    r, p, fe = O.sumcheck_prove(P, table)
+    for rank in range(world):
+        assert out[rank]["rounds"] == [int(x) for x in r] and out[rank]["point"] == [int(x) for x in p] and out[rank]["fe"] == fe
+
+
+def test_radix_run_single_rank_matches_oracle():
+    """world = 1 through the same entry (no hook): the unsharded radix sumcheck, 1 and 2 device stages."""
+    from zigz_amd import shard
+    import fake_engine
+    for nv in (11, 12, 15):
+        table = O.splitmix64_field(990 + nv, 1 << nv)
+        r, p, fe = shard.sumcheck_radix_run(fake_engine.FakeRadixOps(table), 1 << nv, None)
+        r0, p0, fe0 = O.sumcheck_prove(P, table)
+        assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
+        chs = O.splitmix64_field(5, nv)
+        r, p, fe = shard.sumcheck_radix_run(fake_engine.FakeRadixOps(table), 1 << nv, None, challenges=chs)
+        r0, p0, fe0 = O.sumcheck_prove(P, table, chs)
+        assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
 
 
 @pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (4, 4), (2, 2)])

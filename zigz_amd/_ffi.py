@@ -35,6 +35,16 @@ class BenchResult(C.Structure):
                 ("units", C.c_uint64), ("launches", C.c_uint32)]
 
 
+ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, vp)  # zigz_allgather_fn
+RADIX_BLOCK_SUMS_FN = C.CFUNCTYPE(C.c_int32, vp, C.c_uint, u64p)
+RADIX_FOLD_FN = C.CFUNCTYPE(C.c_int32, vp, C.c_uint, u64p, C.c_uint, u64p)
+RADIX_READ_TAIL_FN = C.CFUNCTYPE(C.c_int32, vp, C.c_size_t, u64p)
+
+
+class RadixOps(C.Structure):  # zigz_radix_ops
+    _fields_ = [("user", vp), ("block_sums", RADIX_BLOCK_SUMS_FN), ("fold", RADIX_FOLD_FN), ("read_tail", RADIX_READ_TAIL_FN)]
+
+
 # name -> (restype, argtypes).  Every symbol include/zigz_hip.h declares must appear here
 # (tests/test_abi.py cross-checks this table against the header and the shared object).
 SIGNATURES = {
@@ -82,6 +92,9 @@ SIGNATURES = {
     "zigz_dev_mle_half_sums": (C.c_int32, [vp, vp, C.c_size_t, u64p]),
     "zigz_dev_mle_eval": (C.c_int32, [vp, vp, C.c_size_t, u64p, C.c_size_t, u64p]),
     "zigz_dev_sumcheck_prove": (C.c_int32, [vp, vp, C.c_size_t, vp, u64p, u64p, u64p, u64p]),
+    "zigz_dev_sumcheck_prove_sharded": (C.c_int32, [vp, vp, C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p, u64p]),
+    "zigz_sumcheck_radix_run": (C.c_int32, [C.POINTER(RadixOps), C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p,
+                                            u64p, u64p]),
     "zigz_transcript_new": (vp, []),
     "zigz_transcript_free": (None, [vp]),
     "zigz_transcript_append_bytes": (None, [vp, C.c_char_p, C.c_size_t]),

@@ -719,10 +719,36 @@ inline uint64_t h_sub(uint64_t a, uint64_t b) { return a >= b ? a - b : a + P - 
 inline uint64_t h_mul(uint64_t a, uint64_t b) { return (uint64_t)(((unsigned __int128)a * b) % P); }
 }  // namespace
 
-static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *fixed, uint64_t *rounds,
-                                  uint64_t *point, uint64_t *final_eval) {
+// The radix sumcheck as orchestration over three data passes (RadixOps) and, when the table is sharded by rows over
+// several GPUs, one exchange hook.  Row sharding: global index i lives on rank i mod G at local index
+// i / G, so the MSB-first bind pairs (i, i + n/2) of the first v - log2 G rounds are rank-local, the top k index bits
+// of i are the top k bits of the local index -- a rank's block sums are its share of the global block sums -- and the
+// fold T'[i'] = sum_b eq_b T[b*m + i'] is rank-local too.  Per stage of k <= 10 rounds the ranks exchange 2^k <= 1024
+// exact u64 partial sums (ONE all-gather, added locally = an all-reduce), and once the local tables are <= 1024
+// entries one all-gather re-assembles the remaining table (local index j of rank g -> global index j*G + g) that
+// every rank finishes identically.  2-3 exchanges per proof instead of one per round; transcripts run in lockstep.
+namespace {
+struct RadixOps {
+    void *user;
+    // exact u64 sums of the 2^k contiguous blocks of the current local table
+    zigz_status (*block_sums)(void *user, unsigned k, uint64_t *sums);
+    // current := fold of the current table with the 2^k canonical weights (length / 2^k entries); when k_next != 0 also
+    // the exact u64 sums of the 2^k_next blocks of the result
+    zigz_status (*fold)(void *user, unsigned k, const uint64_t *weights, unsigned k_next, uint64_t *next_sums);
+    // the current local table (m canonical values)
+    zigz_status (*read_tail)(void *user, size_t m, uint64_t *out);
+};
+struct ShardComm {
+    int rank, world;
+    zigz_allgather_fn allgather;
+    void *user;
+};
+
+zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const ShardComm *comm, const uint64_t *fixed,
+                      uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
     ZIGZ_NOTHROW_BEGIN
-    const unsigned nv = log2_floor(n);
+    const size_t world = comm && comm->world > 1 ? (size_t)comm->world : 1;
+    const unsigned nv = log2_floor(n_local) + log2_floor(world);
     Transcript tr;  // fresh transcript per sumcheck, sumcheck_protocol.zig:161
     size_t round = 0;
     auto next_challenge = [&](uint64_t c0, uint64_t c1, uint64_t *ch) -> zigz_status {
@@ -739,73 +765,75 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
         point[round++] = *ch;
         return ZIGZ_OK;
     };
-    unsigned k = nv - 8 < RADIX_MAX_K ? nv - 8 : RADIX_MAX_K;
-    size_t len = n, m = len >> k;
-    // workspace: partial sums u64[G][m0] + two out u32[m0] regions, sized by the first (largest) stage
-    const size_t m0 = m, g0 = radix_fold_groups((size_t)1 << k);
-    void *ws;
-    CHK(ws_get(ctx, WS_SCRATCH, g0 * m0 * 8 + 2 * m0 * 4 + 256, &ws));
-    unsigned long long *d_part = (unsigned long long *)ws;
-    uint32_t *d_outs = (uint32_t *)(d_part + g0 * m0);
-    void *wbuf;
-    CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &wbuf));
-    unsigned long long *d_B = ctx->d_sums;  // two alternating regions of 1024 block sums
-    HIPCHK(ctx, hipMemsetAsync(d_B, 0, ((size_t)1 << k) * 8, ctx->stream));
-    launch_block_sums(d_in, len, len, log2_floor(m), 1, d_B, SumsLayout{0, 1, 0, 1}, ctx->stream);
-    HIPCHK(ctx, hipGetLastError());
-    std::vector<uint64_t> B((size_t)1 << k), W;
-    CHK(read_u64(ctx, d_B, (size_t)1 << k, B.data()));
-    const uint32_t *cur = d_in;
-    std::vector<uint64_t> tail;
-    for (unsigned stage = 0;; stage++) {
-        for (auto &b : B) b %= P;
-        W.assign(1, 1);
-        for (unsigned j = 0; j < k; j++) {  // k rounds on the block-sums table (MSB-first, like partialEval)
-            const size_t half = B.size() / 2;
-            uint64_t s0 = 0, s1 = 0;
-            for (size_t x = 0; x < half; x++) { s0 = h_add(s0, B[x]); s1 = h_add(s1, B[x + half]); }
-            uint64_t ch;
-            CHK(next_challenge(s0, h_sub(s1, s0), &ch));
-            for (size_t x = 0; x < half; x++) B[x] = h_add(B[x], h_mul(ch, h_sub(B[x + half], B[x])));
-            B.resize(half);
-            std::vector<uint64_t> W2(W.size() * 2);
-            const uint64_t one_minus = h_sub(1, ch);
-            for (size_t x = 0; x < W.size(); x++) { W2[2 * x] = h_mul(W[x], one_minus); W2[2 * x + 1] = h_mul(W[x], ch); }
-            W.swap(W2);
+    std::vector<uint64_t> gather;
+    // partial sums of every rank -> totals (exact: < 2^31 * 2^40 per rank, a few ranks)
+    auto sum_over_ranks = [&](std::vector<uint64_t> &v) -> zigz_status {
+        if (world == 1) return ZIGZ_OK;
+        gather.resize(world * v.size());
+        if (!comm->allgather || comm->allgather(comm->user, v.data(), v.size() * 8, gather.data()) != 0) {
+            set_err(ctx, "sharded sumcheck: the all-gather hook failed");
+            return ZIGZ_ERR_INVALID_ARGUMENT;
         }
-        // pass 2: radix fold with the eq weights (Montgomery form), accumulate in u64, finalize mod p
-        const size_t nb = (size_t)1 << k;
-        uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
-        for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(W[b]);
-        HIPCHK(ctx, hipMemcpyAsync(wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
-        uint32_t *d_out = d_outs + (stage & 1) * m0;
-        const size_t groups = radix_fold_groups(nb);
-        launch_radix_fold(cur, 0, m, nb, (const uint32_t *)wbuf, 0, d_part, 0, 1, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        if (m <= HOST_TAIL_MAX) {
-            launch_radix_finalize(d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
-            HIPCHK(ctx, hipGetLastError());
-            uint32_t *h32 = (uint32_t *)ctx->h_pin;
-            HIPCHK(ctx, hipMemcpyAsync(h32, d_out, m * 4, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            tail.assign(h32, h32 + m);
-            break;
+        for (size_t i = 0; i < v.size(); i++) {
+            uint64_t t = 0;
+            for (size_t r = 0; r < world; r++) t += gather[r * v.size() + i];
+            v[i] = t;
         }
-        const unsigned lm = log2_floor(m);
-        const unsigned k2 = lm - 8 < RADIX_MAX_K ? lm - 8 : RADIX_MAX_K;
-        unsigned long long *d_B2 = ctx->d_sums + (((stage + 1) & 1) ? 1024 : 0);
-        HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k2) * 8, ctx->stream));
-        launch_radix_finalize(d_part, 0, groups, d_out, 0, m, lm - k2, d_B2, 1, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        B.assign((size_t)1 << k2, 0);
-        CHK(read_u64(ctx, d_B2, (size_t)1 << k2, B.data()));
-        cur = d_out;
-        len = m;
-        k = k2;
-        m = len >> k;
+        return ZIGZ_OK;
+    };
+    std::vector<uint64_t> B, W, tail;
+    size_t len = n_local;
+    if (len > HOST_TAIL_MAX) {
+        unsigned k = log2_floor(len) - 8 < RADIX_MAX_K ? log2_floor(len) - 8 : RADIX_MAX_K;
+        B.assign((size_t)1 << k, 0);
+        CHK(ops.block_sums(ops.user, k, B.data()));
+        CHK(sum_over_ranks(B));
+        for (;;) {
+            for (auto &b : B) b %= P;
+            W.assign(1, 1);
+            for (unsigned j = 0; j < k; j++) {  // k rounds on the block-sums table (MSB-first, like partialEval)
+                const size_t half = B.size() / 2;
+                uint64_t s0 = 0, s1 = 0;
+                for (size_t x = 0; x < half; x++) { s0 = h_add(s0, B[x]); s1 = h_add(s1, B[x + half]); }
+                uint64_t ch;
+                CHK(next_challenge(s0, h_sub(s1, s0), &ch));
+                for (size_t x = 0; x < half; x++) B[x] = h_add(B[x], h_mul(ch, h_sub(B[x + half], B[x])));
+                B.resize(half);
+                std::vector<uint64_t> W2(W.size() * 2);
+                const uint64_t one_minus = h_sub(1, ch);
+                for (size_t x = 0; x < W.size(); x++) { W2[2 * x] = h_mul(W[x], one_minus); W2[2 * x + 1] = h_mul(W[x], ch); }
+                W.swap(W2);
+            }
+            const size_t m = len >> k;
+            const unsigned lm = log2_floor(m);
+            const unsigned k_next = m <= HOST_TAIL_MAX ? 0 : (lm - 8 < RADIX_MAX_K ? lm - 8 : RADIX_MAX_K);
+            B.assign(k_next ? (size_t)1 << k_next : 0, 0);
+            CHK(ops.fold(ops.user, k, W.data(), k_next, k_next ? B.data() : nullptr));
+            len = m;
+            if (!k_next) break;
+            CHK(sum_over_ranks(B));
+            k = k_next;
+        }
     }
-    // last <= 10 rounds on the <= 1024-entry table
-    while (tail.size() > 1) {
+    // the remaining table: len local entries per rank, global index j*G + g
+    std::vector<uint64_t> mine(len);
+    CHK(ops.read_tail(ops.user, len, mine.data()));
+    if (world == 1) {
+        tail.swap(mine);
+    } else {
+        gather.resize(world * len);
+        if (!comm->allgather || comm->allgather(comm->user, mine.data(), len * 8, gather.data()) != 0) {
+            set_err(ctx, "sharded sumcheck: the all-gather hook failed");
+            return ZIGZ_ERR_INVALID_ARGUMENT;
+        }
+        tail.resize(world * len);
+        for (size_t r = 0; r < world; r++)
+            for (size_t j = 0; j < len; j++) {
+                if (gather[r * len + j] >= P) return ZIGZ_ERR_NOT_CANONICAL;
+                tail[j * world + r] = gather[r * len + j];
+            }
+    }
+    while (tail.size() > 1) {  // last rounds on the <= 1024 * G entry table, identical on every rank
         const size_t half = tail.size() / 2;
         uint64_t s0 = 0, s1 = 0;
         for (size_t x = 0; x < half; x++) { s0 = h_add(s0, tail[x]); s1 = h_add(s1, tail[x + half]); }
@@ -818,6 +846,114 @@ static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n,
     *final_eval = tail[0];
     return ZIGZ_OK;
     ZIGZ_NOTHROW_END(ctx)
+}
+
+// the three passes on the GPU, buffers from the context's workspaces (sized by the first, largest stage; two output
+// regions used alternately; no allocation inside the loop)
+struct GpuRadix {
+    zigz_ctx *ctx;
+    const uint32_t *cur;
+    size_t len, m0;
+    unsigned long long *d_part;
+    uint32_t *d_outs;
+    void *wbuf;
+    unsigned stage;
+};
+zigz_status gpu_block_sums(void *user, unsigned k, uint64_t *sums) {
+    GpuRadix *g = (GpuRadix *)user;
+    zigz_ctx *ctx = g->ctx;
+    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, ((size_t)1 << k) * 8, ctx->stream));
+    launch_block_sums(g->cur, g->len, g->len, log2_floor(g->len >> k), 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    return read_u64(ctx, ctx->d_sums, (size_t)1 << k, sums);
+}
+zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k_next, uint64_t *next_sums) {
+    GpuRadix *g = (GpuRadix *)user;
+    zigz_ctx *ctx = g->ctx;
+    const size_t nb = (size_t)1 << k, m = g->len >> k;
+    uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
+    for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(weights[b]);
+    HIPCHK(ctx, hipMemcpyAsync(g->wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+    uint32_t *d_out = g->d_outs + (g->stage & 1) * g->m0;
+    const size_t groups = radix_fold_groups(nb);
+    launch_radix_fold(g->cur, 0, m, nb, (const uint32_t *)g->wbuf, 0, g->d_part, 0, 1, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    if (k_next) {
+        unsigned long long *d_B2 = ctx->d_sums + ((g->stage + 1) & 1 ? 1024 : 0);
+        HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k_next) * 8, ctx->stream));
+        launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        CHK(read_u64(ctx, d_B2, (size_t)1 << k_next, next_sums));
+    } else {
+        launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+    }
+    g->cur = d_out;
+    g->len = m;
+    g->stage++;
+    return ZIGZ_OK;
+}
+zigz_status gpu_read_tail(void *user, size_t m, uint64_t *out) {
+    GpuRadix *g = (GpuRadix *)user;
+    zigz_ctx *ctx = g->ctx;
+    if (m > PIN_WORDS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    uint32_t *h32 = (uint32_t *)ctx->h_pin;
+    HIPCHK(ctx, hipMemcpyAsync(h32, g->cur, m * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < m; i++) out[i] = h32[i];
+    return ZIGZ_OK;
+}
+}  // namespace
+
+static zigz_status sumcheck_radix_sharded(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const ShardComm *comm,
+                                          const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    GpuRadix g{ctx, d_in, n, 0, nullptr, nullptr, nullptr, 0};
+    if (n > HOST_TAIL_MAX) {
+        const unsigned lv = log2_floor(n);
+        const unsigned k = lv - 8 < RADIX_MAX_K ? lv - 8 : RADIX_MAX_K;
+        g.m0 = n >> k;
+        const size_t g0 = radix_fold_groups((size_t)1 << k);
+        void *ws;
+        CHK(ws_get(ctx, WS_SCRATCH, g0 * g.m0 * 8 + 2 * g.m0 * 4 + 256, &ws));
+        g.d_part = (unsigned long long *)ws;
+        g.d_outs = (uint32_t *)(g.d_part + g0 * g.m0);
+        CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &g.wbuf));
+    }
+    const RadixOps ops{&g, gpu_block_sums, gpu_fold, gpu_read_tail};
+    return radix_run(ctx, ops, n, comm, fixed, rounds, point, final_eval);
+}
+
+static zigz_status sumcheck_radix(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const uint64_t *fixed, uint64_t *rounds,
+                                  uint64_t *point, uint64_t *final_eval) {
+    return sumcheck_radix_sharded(ctx, d_in, n, nullptr, fixed, rounds, point, final_eval);
+}
+
+// SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) of ONE table sharded by rows over `world` GPUs
+extern "C" zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, int rank,
+                                                       int world, zigz_allgather_fn allgather, void *user,
+                                                       uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !d_local || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n_local));
+    if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
+    if (!aligned16(d_local)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const ShardComm comm{rank, world, allgather, user};
+    return sumcheck_radix_sharded(ctx, d_local, n_local, &comm, nullptr, rounds, point, final_eval);
+}
+
+// The orchestration alone, over caller-supplied data passes (multi-process tests on CPU drive exactly the code path of
+// zigz_dev_sumcheck_prove_sharded with stand-in passes; a host with its own kernels could do the same)
+extern "C" zigz_status zigz_sumcheck_radix_run(const zigz_radix_ops *ops, size_t n_local, int rank, int world,
+                                               zigz_allgather_fn allgather, void *comm_user, const uint64_t *fixed_challenges,
+                                               uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    if (!ops || !ops->block_sums || !ops->fold || !ops->read_tail || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n_local));
+    if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
+    const ShardComm comm{rank, world, allgather, comm_user};
+    const RadixOps r{ops->user, ops->block_sums, ops->fold, ops->read_tail};
+    return radix_run(nullptr, r, n_local, &comm, fixed_challenges, rounds, point, final_eval);
 }
 
 extern "C" zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_scratch,

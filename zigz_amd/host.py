@@ -186,29 +186,8 @@ class Trace:
         return BorrowedProof(out, n.value)
 
 
-ALLGATHER_FN = C.CFUNCTYPE(C.c_int, vp, vp, C.c_size_t, vp)  # zigzh_allgather_fn
-
-
-def make_allgather(dist):
-    """zigzh_allgather_fn on torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the tests): every rank
-    contributes `nbytes` from `send`, `recv` receives world * nbytes in rank order."""
-    import torch
-    world = dist.get_world_size()
-    dev = torch.device("cuda", torch.cuda.current_device()) if dist.get_backend() == "nccl" else torch.device("cpu")
-
-    def hook(_user, send, nbytes, recv):
-        try:
-            src = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).to(dev)
-            outs = [torch.empty_like(src) for _ in range(world)]
-            dist.all_gather(outs, src)
-            dst = (C.c_uint8 * (world * nbytes)).from_address(recv)
-            for r, o in enumerate(outs):
-                C.memmove(C.addressof(dst) + r * nbytes, o.cpu().numpy().ctypes.data, nbytes)
-            return 0
-        except Exception:  # never unwind into C
-            return 1
-
-    return ALLGATHER_FN(hook)
+from ._ffi import ALLGATHER_FN  # noqa: E402  zigzh_allgather_fn == zigz_allgather_fn
+from .shard import make_allgather  # noqa: E402,F401  (the hook on torch.distributed)
 
 
 class BorrowedProof:

@@ -6,10 +6,12 @@ over xGMI on a node, "gloo" in the CPU tests).  SURVEY.md s8(e):
   block of columns.  Exchange steps: one all-gather of the roots (43 x 32 B) before the transcript absorbs
   them, one all-gather of the openings (value, index, leaf, v x 33 B) after.  Every rank runs the same
   deterministic transcript, so challenges need no broadcast.
-* rows     -- `sumcheck_prove_row_sharded`: a single large table is owned interleaved (global index i lives
-  on rank i mod G), which keeps every MSB-bind pair (i, i + n/2) on one rank for the first v - log2(G)
-  rounds; each round costs ONE all-reduce(sum) of the two partial half sums (16 bytes), the last log2(G)
-  rounds run on the all-gathered G-element table.
+* rows     -- a single large table is owned interleaved (global index i lives on rank i mod G), which keeps every
+  MSB-bind pair (i, i + n/2) on one rank for the first v - log2(G) rounds.  `sumcheck_prove_row_sharded_radix` (the
+  product path) hands the whole proof to the C++ radix orchestration of libzigz_hip.so: 2-3 exchanges of <= 1024 u64
+  block sums per proof.  `sumcheck_prove_row_sharded` is the per-round form kept as a second, independent statement
+  of the same proof for the tests: ONE all-reduce(sum) of the two partial half sums (16 bytes) per round, the last
+  log2(G) rounds on the all-gathered G-element table.
 
 * rows (Merkle) -- `RowShardedMerkle`: one large column owned by CONTIGUOUS slices (top log2 G index bits), the
   layout a Merkle tree prefers: each rank builds the subtree over its slice, the G subtree roots (G x 32 B) are
@@ -113,6 +115,94 @@ def generate_commitments_sharded(engine, transcript, local_cols, nv, dist, ncols
 def interleave_rows(table, rank, world):
     """The slice of a global table owned by `rank` under interleaved ownership (index mod world)."""
     return np.ascontiguousarray(np.asarray(table)[rank::world])
+
+
+def make_allgather(dist):
+    """zigz_allgather_fn on torch.distributed (backend "nccl" = RCCL on ROCm, "gloo" in the tests): every rank
+    contributes `nbytes` from `send`, `recv` receives world * nbytes in rank order.  Keep the returned object alive
+    while C code may call it."""
+    import ctypes as C
+    import torch
+    from ._ffi import ALLGATHER_FN
+    world = dist.get_world_size()
+    dev = _dist_device(dist)
+
+    def hook(_user, send, nbytes, recv):
+        try:
+            src = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).to(dev)
+            outs = [torch.empty_like(src) for _ in range(world)]
+            dist.all_gather(outs, src)
+            dst = (C.c_uint8 * (world * nbytes)).from_address(recv)
+            for r, o in enumerate(outs):
+                C.memmove(C.addressof(dst) + r * nbytes, o.cpu().numpy().ctypes.data, nbytes)
+            return 0
+        except Exception:  # never unwind into C
+            return 1
+
+    return ALLGATHER_FN(hook)
+
+
+def sumcheck_prove_row_sharded_radix(ctx, d_local, n_local, dist, allgather=None):
+    """SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) over a table sharded by rows (interleaved), radix
+    form, orchestrated in C++ (zigz_dev_sumcheck_prove_sharded): 2-3 exchanges of <= 1024 u64 per proof through the
+    all-gather hook, no per-round collective, no Python in the loop.  d_local: this rank's n_local elements in HBM
+    (16-byte aligned).  Returns (rounds[2v], point[v], final_eval), identical on every rank and to the unsharded proof."""
+    cb = allgather or make_allgather(dist)
+    return ctx.dev_sumcheck_prove_sharded(d_local, n_local, dist.get_rank(), dist.get_world_size(), cb)
+
+
+def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
+    """The C++ orchestration of the radix sumcheck (zigz_sumcheck_radix_run) over Python data passes:
+    py_ops.block_sums(k) -> 2^k ints, py_ops.fold(k, weights, k_next) -> 2^k_next ints or None, py_ops.read_tail(m) -> m
+    ints.  Used by the multi-process CPU tests to drive the exchange logic of the sharded prover without a GPU."""
+    import ctypes as C
+    from . import _ffi
+    world = dist.get_world_size() if dist is not None else 1
+    rank = dist.get_rank() if dist is not None else 0
+    cb = allgather or (make_allgather(dist) if world > 1 else _ffi.ALLGATHER_FN(lambda *a: 1))
+    err = []
+
+    def guard(fn):
+        def w(*a):
+            try:
+                fn(*a)
+                return 0
+            except Exception as e:  # never unwind into C
+                err.append(e)
+                return 103
+        return w
+
+    def c_block_sums(_u, k, out):
+        v = py_ops.block_sums(k)
+        for i in range(1 << k):
+            out[i] = int(v[i])
+
+    def c_fold(_u, k, w, k_next, nxt):
+        v = py_ops.fold(k, [int(w[i]) for i in range(1 << k)], k_next)
+        for i in range((1 << k_next) if k_next else 0):
+            nxt[i] = int(v[i])
+
+    def c_read_tail(_u, m, out):
+        v = py_ops.read_tail(m)
+        for i in range(m):
+            out[i] = int(v[i])
+
+    ops = _ffi.RadixOps(None, _ffi.RADIX_BLOCK_SUMS_FN(guard(c_block_sums)), _ffi.RADIX_FOLD_FN(guard(c_fold)),
+                        _ffi.RADIX_READ_TAIL_FN(guard(c_read_tail)))
+    nv = (n_local * world).bit_length() - 1
+    r = (C.c_uint64 * max(2 * nv, 1))()
+    pt = (C.c_uint64 * max(nv, 1))()
+    fe = C.c_uint64()
+    ch = None
+    if challenges is not None:
+        ch = (C.c_uint64 * max(nv, 1))(*[int(c) for c in challenges])
+    rc = _ffi.lib.zigz_sumcheck_radix_run(C.byref(ops), n_local, rank, world, cb, None, ch, r, pt, C.byref(fe))
+    if err:
+        raise err[0]
+    if rc != 0:
+        from . import errors
+        raise errors.ZigzError(rc, _ffi.lib.zigz_status_name(rc).decode())
+    return np.array(r[: 2 * nv], dtype=np.uint64), np.array(pt[:nv], dtype=np.uint64), fe.value
 
 
 def sumcheck_prove_row_sharded(ops, local_table, n_global, dist, transcript_factory):
