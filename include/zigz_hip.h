@@ -237,6 +237,17 @@ typedef int (*zigz_allgather_fn)(void *user, const void *send, size_t bytes, voi
 zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, int rank, int world,
                                             zigz_allgather_fn allgather, void *user, uint64_t *rounds, uint64_t *point,
                                             uint64_t *final_eval);
+/* Built-in zigz_allgather_fn for the ranks of ONE node: a mailbox in POSIX shared memory.  What the sharded provers
+ * exchange is host-resident (it was read back for the SHA3 transcript) and <= 64 KiB, so between processes of a node
+ * this is the shortest path (a few microseconds per exchange); across nodes bind the hook to RCCL / MPI.  Every rank
+ * calls create with the same job-unique `name` (<= 80 chars, no '/'), world and max_bytes (largest `bytes` of any
+ * exchange); rank 0 creates the segment, the others attach (waiting up to timeout_s; <= 0: 60 s).  Pass the comm as the
+ * hook's `user`.  A rank that waits longer than timeout_s inside an exchange returns nonzero instead of hanging. */
+typedef struct zigz_shm_comm zigz_shm_comm;
+zigz_status zigz_shm_comm_create(const char *name, int rank, int world, size_t max_bytes, double timeout_s,
+                                 zigz_shm_comm **out);
+int zigz_shm_allgather(void *comm, const void *send, size_t bytes, void *recv);
+void zigz_shm_comm_destroy(zigz_shm_comm *comm);
 /* The same orchestration over caller-supplied data passes on the local table (what the GPU passes of the call above do):
  * block_sums: exact u64 sums of the 2^k contiguous blocks of the current table; fold: current := sum_b w[b] *
  * current[b*m + i] (2^k canonical weights, m = length / 2^k) and, when k_next != 0, the 2^k_next block sums of the result;

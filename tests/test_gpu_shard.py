@@ -50,8 +50,18 @@ def _worker(rank, world, port, q):
         for _ in range(5):
             rb, pb, feb = shard.sumcheck_prove_row_sharded_radix(ctx, d_big, (1 << 22) // world, dist, cb)
         ms_sharded = (time.perf_counter() - t0) / 5 * 1e3
+        # ... and through the built-in same-node transport (shared-memory mailbox) instead of torch.distributed
+        comm = shard.ShmComm("zigz_gpu_shard_%d" % port, rank, world)
+        shard.sumcheck_prove_row_sharded_radix(ctx, d_big, (1 << 22) // world, dist, comm)
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            rs, ps, fes = shard.sumcheck_prove_row_sharded_radix(ctx, d_big, (1 << 22) // world, dist, comm)
+        ms_shm = (time.perf_counter() - t0) / 20 * 1e3
+        comm.close()
+        assert np.array_equal(rs, rb) and np.array_equal(ps, pb) and fes == feb
         ctx.dev_free(d_big)
-        radix = dict(rounds=r2.tolist(), point=p2.tolist(), fe=fe2, big_rounds=rb.tolist(), big_point=pb.tolist(), big_fe=feb,
+        radix = dict(ms_shm=ms_shm, rounds=r2.tolist(), point=p2.tolist(), fe=fe2, big_rounds=rb.tolist(), big_point=pb.tolist(), big_fe=feb,
                      ms_2p22=ms_sharded)
         ops.close()
         nm = 1 << 14
@@ -120,8 +130,8 @@ def test_sharded_paths_world2_on_gpu():
     for rank, got, sc, mk, pr, rx in outs:
         assert rx["rounds"] == [int(x) for x in r] and rx["point"] == [int(x) for x in p] and rx["fe"] == fe, rank
         assert rx["big_rounds"] == [int(x) for x in rb] and rx["big_point"] == [int(x) for x in pb] and rx["big_fe"] == feb
-        print("rank %d: row-sharded radix sumcheck 2^22 over 2 ranks (gloo exchanges, one GPU): %.3f ms; unsharded %.3f ms"
-              % (rank, rx["ms_2p22"], ms_single))
+        print("rank %d: row-sharded radix sumcheck 2^22 over 2 ranks on one GPU: %.3f ms (torch/gloo hook), %.3f ms "
+              "(shared-memory hook); unsharded %.3f ms" % (rank, rx["ms_2p22"], rx["ms_shm"], ms_single))
         assert pr["nv"] >= 11 and pr["n"] == len(oproof) and pr["sha3"] == hashlib.sha3_256(oproof).hexdigest(), rank
         assert mk["root"] == mroot.hex() and mk["height"] == mheight
         for idx, sib, dirs, leaf in mk["opens"]:

@@ -142,6 +142,59 @@ def test_radix_run_single_rank_matches_oracle():
         assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
 
 
+def _shm_worker(rank, world, name, nv, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from zigz_amd import shard
+    import fake_engine
+    comm = shard.ShmComm(name, rank, world, max_bytes=1 << 14, timeout_s=60)
+    try:
+        echo = []
+        for it in range(50):  # many back-to-back exchanges of varying size: the two slot sets are reused correctly
+            n = 1 + (it * 37) % 300
+            got = comm.all_gather(bytes([(rank * 17 + it + j) & 255 for j in range(n)]))
+            echo.append(all(got[r] == bytes([(r * 17 + it + j) & 255 for j in range(n)]) for r in range(world)))
+        table = O.splitmix64_field(660 + nv, 1 << nv)
+        local = shard.interleave_rows(table, rank, world)
+        r, p, fe = shard.sumcheck_radix_run(fake_engine.FakeRadixOps(local), len(local), None, allgather=comm)
+        q.put((rank, dict(echo=all(echo), rounds=r.tolist(), point=p.tolist(), fe=fe)))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("world,nv", [(2, 13), (4, 14), (8, 14)])
+def test_row_sharded_radix_sumcheck_shm(world, nv):
+    """The same orchestration with the built-in same-node transport (zigz_shm_comm, no torch, no sockets):
+    world processes, 2-3 shared-memory all-gathers per proof, results equal the unsharded reference prover's."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "zigz_test_%d_%d_%d" % (os.getpid(), world, nv)
+    procs = [ctx.Process(target=_shm_worker, args=(r, world, name, nv, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = dict(q.get(timeout=180) for _ in range(world))
+    [p.join(timeout=60) for p in procs]
+    assert all(p.exitcode == 0 for p in procs)
+    table = O.splitmix64_field(660 + nv, 1 << nv)
+    r, p, fe = O.sumcheck_prove(P, table)
+    for rank in range(world):
+        assert out[rank]["echo"]
+        assert out[rank]["rounds"] == [int(x) for x in r] and out[rank]["point"] == [int(x) for x in p] and out[rank]["fe"] == fe
+
+
+def test_shm_comm_times_out_instead_of_hanging():
+    """A rank whose peers never arrive gets an error after timeout_s, not a hang ('the others hang')."""
+    from zigz_amd import shard
+    import zigz_amd
+    with pytest.raises(zigz_amd.ZigzError):      # rank 1 of 2, rank 0 never creates the segment
+        shard.ShmComm("zigz_test_absent_%d" % os.getpid(), 1, 2, timeout_s=0.3)
+    comm = shard.ShmComm("zigz_test_alone_%d" % os.getpid(), 0, 2, timeout_s=0.3)
+    try:
+        with pytest.raises(RuntimeError):
+            comm.all_gather(b"abc")               # rank 1 never shows up
+    finally:
+        comm.close()
+
+
 @pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (4, 4), (2, 2)])
 def test_row_sharded_merkle_gloo(world, n):
     """Contiguous row ownership: subtree per rank, G roots all-gathered, top levels on every rank; root and openings

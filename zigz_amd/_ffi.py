@@ -95,6 +95,9 @@ SIGNATURES = {
     "zigz_dev_sumcheck_prove_sharded": (C.c_int32, [vp, vp, C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p, u64p]),
     "zigz_sumcheck_radix_run": (C.c_int32, [C.POINTER(RadixOps), C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p,
                                             u64p, u64p]),
+    "zigz_shm_comm_create": (C.c_int32, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.POINTER(vp)]),
+    "zigz_shm_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "zigz_shm_comm_destroy": (None, [vp]),
     "zigz_transcript_new": (vp, []),
     "zigz_transcript_free": (None, [vp]),
     "zigz_transcript_append_bytes": (None, [vp, C.c_char_p, C.c_size_t]),

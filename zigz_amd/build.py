@@ -64,6 +64,7 @@ def build_hip(force=False):
         ("host_hash.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
         ("host_keccak_avx512.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
         ("host_keccak_bmi.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
+        ("shm_comm.cpp", [_host_cxx(), "-O2", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
     ]
     for src, cmd in units:
         s = os.path.join(CSRC, src)
@@ -73,7 +74,7 @@ def build_hip(force=False):
         objs.append(o)
     so = os.path.join(LIB, "libzigz_hip.so")
     if force or _newer(so, objs):
-        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", so] + objs)
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", so] + objs + ["-lrt", "-pthread"])
     return so
 
 

@@ -214,14 +214,14 @@ class Context:
                                                C.byref(fe)))
         return r[: 2 * nv].copy(), pt[:nv].copy(), fe.value
 
-    def dev_sumcheck_prove_sharded(self, d_local, n_local, rank, world, allgather):
+    def dev_sumcheck_prove_sharded(self, d_local, n_local, rank, world, allgather, user=None):
         """zigz_dev_sumcheck_prove_sharded: SumcheckProver.prove of ONE table sharded by rows (element i on rank i mod world
         at local index i // world).  `allgather`: an _ffi.ALLGATHER_FN (shard.make_allgather(dist))."""
         nv = (n_local * world).bit_length() - 1
         r, rp = _out_u64(2 * nv)
         pt, ptp = _out_u64(nv)
         fe = C.c_uint64()
-        self.check(lib.zigz_dev_sumcheck_prove_sharded(self.h, vp(d_local), n_local, rank, world, allgather, None, rp, ptp,
+        self.check(lib.zigz_dev_sumcheck_prove_sharded(self.h, vp(d_local), n_local, rank, world, allgather, user, rp, ptp,
                                                        C.byref(fe)))
         return r[: 2 * nv].copy(), pt[:nv].copy(), fe.value
 

@@ -142,11 +142,45 @@ def make_allgather(dist):
     return ALLGATHER_FN(hook)
 
 
+class ShmComm:
+    """zigz_shm_comm: the built-in same-node all-gather (shared-memory mailbox).  `hook` / `user` are what the C entry
+    points take as (allgather, user); `all_gather(bytes)` is the same exchange from Python."""
+
+    def __init__(self, name, rank, world, max_bytes=1 << 16, timeout_s=60.0):
+        import ctypes as C
+        from . import _ffi, errors
+        h = _ffi.vp()
+        rc = _ffi.lib.zigz_shm_comm_create(name.encode(), rank, world, max_bytes, timeout_s, C.byref(h))
+        if rc != 0:
+            raise errors.ZigzError(rc, _ffi.lib.zigz_status_name(rc).decode(), "zigz_shm_comm_create(%s)" % name)
+        self.h, self.rank, self.world = h, rank, world
+        self.hook = C.cast(_ffi.lib.zigz_shm_allgather, _ffi.ALLGATHER_FN)
+        self.user = h
+
+    def all_gather(self, payload):
+        import ctypes as C
+        from . import _ffi
+        n = len(payload)
+        send = (C.c_uint8 * max(n, 1)).from_buffer_copy(bytes(payload) or b"\0")
+        recv = (C.c_uint8 * max(n * self.world, 1))()
+        if _ffi.lib.zigz_shm_allgather(self.h, send, n, recv) != 0:
+            raise RuntimeError("zigz_shm_allgather failed (a rank timed out)")
+        return [bytes(recv[r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def close(self):
+        if self.h:
+            from . import _ffi
+            _ffi.lib.zigz_shm_comm_destroy(self.h)
+            self.h = None
+
+
 def sumcheck_prove_row_sharded_radix(ctx, d_local, n_local, dist, allgather=None):
     """SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) over a table sharded by rows (interleaved), radix
     form, orchestrated in C++ (zigz_dev_sumcheck_prove_sharded): 2-3 exchanges of <= 1024 u64 per proof through the
     all-gather hook, no per-round collective, no Python in the loop.  d_local: this rank's n_local elements in HBM
     (16-byte aligned).  Returns (rounds[2v], point[v], final_eval), identical on every rank and to the unsharded proof."""
+    if isinstance(allgather, ShmComm):
+        return ctx.dev_sumcheck_prove_sharded(d_local, n_local, allgather.rank, allgather.world, allgather.hook, allgather.user)
     cb = allgather or make_allgather(dist)
     return ctx.dev_sumcheck_prove_sharded(d_local, n_local, dist.get_rank(), dist.get_world_size(), cb)
 
@@ -159,7 +193,11 @@ def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
     from . import _ffi
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
-    cb = allgather or (make_allgather(dist) if world > 1 else _ffi.ALLGATHER_FN(lambda *a: 1))
+    comm_user = None
+    if isinstance(allgather, ShmComm):
+        cb, comm_user, world, rank = allgather.hook, allgather.user, allgather.world, allgather.rank
+    else:
+        cb = allgather or (make_allgather(dist) if world > 1 else _ffi.ALLGATHER_FN(lambda *a: 1))
     err = []
 
     def guard(fn):
@@ -196,7 +234,7 @@ def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
     ch = None
     if challenges is not None:
         ch = (C.c_uint64 * max(nv, 1))(*[int(c) for c in challenges])
-    rc = _ffi.lib.zigz_sumcheck_radix_run(C.byref(ops), n_local, rank, world, cb, None, ch, r, pt, C.byref(fe))
+    rc = _ffi.lib.zigz_sumcheck_radix_run(C.byref(ops), n_local, rank, world, cb, comm_user, ch, r, pt, C.byref(fe))
     if err:
         raise err[0]
     if rc != 0:
