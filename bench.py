@@ -176,6 +176,41 @@ def kernel_leg(ctx, nv, ncols, iters, cold=True, big_nv=24):
     return res
 
 
+def lasso_leg(ctx, reps=5):
+    """LassoProver.prove (src/lookups/lasso_prover.zig:103-173) end to end through zigz_lasso_prove: the reference's 8-bit
+    XOR table (2^16 rows x 3 fields) and Q random valid queries, host buffers in, proof out (uploads included), plus the
+    fingerprint kernel alone and the sumcheck of the same size on a resident table."""
+    import numpy as np
+    a = np.arange(256, dtype=np.uint64)
+    tab = np.stack([np.repeat(a, 256), np.tile(a, 256), np.repeat(a, 256) ^ np.tile(a, 256)], axis=1)
+    rng = np.random.default_rng(7)
+    out = {"table_rows": len(tab), "sizes": {}}
+    for lq in (16, 18, 20):
+        q = tab[rng.integers(0, len(tab), size=1 << lq)]
+        ctx.lasso_prove(tab, q)  # warm-up: workspaces
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.lasso_prove(tab, q)
+        ms = (time.perf_counter() - t0) / reps * 1e3
+        d = ctx.dev_alloc((1 << lq) * 4)
+        ctx.upload(np.arange(1 << lq, dtype=np.uint64) % 2013265921, d)
+        ctx.dev_sumcheck_prove(d, 1 << lq)
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            ctx.dev_sumcheck_prove(d, 1 << lq)
+        ms_sc = (time.perf_counter() - t0) / reps * 1e3
+        ctx.dev_free(d)
+        sponge_bytes = ((1 << lq) + len(tab)) * 8
+        out["sizes"]["2^%d" % lq] = {"lasso_prove_ms": ms, "queries_per_s": (1 << lq) / (ms / 1e3),
+                                     "sumcheck_resident_ms": ms_sc, "flat_commit_bytes": sponge_bytes}
+    k = ctx.bench_kernel("k_lasso_fingerprints", 20, 1, 10, True)
+    out["k_lasso_fingerprints[2^20 rows x 3]"] = {"avg_us": k["avg_us"], "min_us": k["min_us"],
+                                                  "rows_per_s": k["units"] / (k["avg_us"] / 1e6),
+                                                  "hbm_frac": k["algorithmic_bytes"] / 1e9 / (k["avg_us"] / 1e6) / HBM_PEAK_GBS}
+    ctx.close()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -195,6 +230,8 @@ def main():
     ap.add_argument("--cpu-sample-cols", type=int, default=12, help="columns of the CPU baseline sample (~1.1 s each)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--kernels", action="store_true", help="per-kernel leg only (cold-HBM launches, kernel timestamps)")
+    ap.add_argument("--lasso", action="store_true", help="Lasso leg only: zigz_lasso_prove end to end (8-bit XOR table, 2^16 rows) "
+                    "with 2^16 .. 2^20 queries + the fingerprint kernel, prints its own JSON line")
     ap.add_argument("--kernel-iters", type=int, default=10)
     ap.add_argument("--no-extras", action="store_true", help="skip the single-proof, PCIe-inclusive and per-kernel legs")
     ap.add_argument("--dry-run", action="store_true", help="launcher rehearsal without a GPU: the ranks rendezvous over gloo, "
@@ -274,6 +311,10 @@ def main():
         ctx.close()
         print(json.dumps({"kernels": res, "cold": True, "iters": args.kernel_iters,
                           "hbm_peak_GBs": HBM_PEAK_GBS, "valu_peak_Tinstr_s": VALU_PEAK_TOPS}), flush=True)
+        return 0
+
+    if args.lasso:
+        print(json.dumps(lasso_leg(zigz_amd.Context(local_rank))), flush=True)
         return 0
 
     shard = args.mode == "shard"

@@ -10,6 +10,7 @@
 #include <string.h>
 
 #include <new>
+#include <thread>
 #include <vector>
 
 #include "field.hpp"
@@ -1414,7 +1415,6 @@ extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, si
                                         size_t n_queries, size_t n_in, size_t n_out, size_t *nv_out, uint64_t *rounds,
                                         uint64_t *point, uint64_t *final_eval, uint8_t query_commitment[32],
                                         uint8_t table_commitment[32]) {
-    ZIGZ_NOTHROW_BEGIN
     ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_queries == 0) return ZIGZ_ERR_NO_QUERIES;  // :108-110
@@ -1424,29 +1424,47 @@ extern "C" zigz_status zigz_lasso_prove(zigz_ctx *ctx, const uint64_t *table, si
     CHK(mle_check(table_rows));  // Multilinear.init(table_evals), :124
     if (n_queries > ((size_t)1 << 40)) return ZIGZ_ERR_TOO_MANY_QUERIES;
     const size_t padded = ceil_pow2(n_queries);  // :131
+    // The two flat SHA3 commitments (K10, :242-252) are sequential sponges over 8 B per element -- the longest part of a
+    // Lasso proof by far (2^20 queries: 8 MiB = 62 k dependent permutations) -- and depend only on the fingerprints, not
+    // on the sumcheck: each runs on a helper thread as soon as its fingerprints are on the host, underneath the uploads,
+    // the other fingerprint kernel and the whole GPU sumcheck.
+    std::vector<uint32_t> hq, ht;  // declared before the threads that read them: destroyed after the joiner below
+    std::thread th_table, th_query;
+    struct Joiner {
+        std::thread &a, &b;
+        ~Joiner() {
+            if (a.joinable()) a.join();
+            if (b.joinable()) b.join();
+        }
+    } joiner{th_table, th_query};
+    ZIGZ_NOTHROW_BEGIN
+    hq.resize(padded);
+    ht.resize(table_rows);
     // fingerprints of table rows and queries (K9)
     void *d_fp;
     CHK(ws_get(ctx, WS_LASSO, (table_rows + padded) * 4, &d_fp));
     uint32_t *d_tev = (uint32_t *)d_fp, *d_qev = d_tev + table_rows;
     uint32_t *d_rows;
     CHK(stage_in(ctx, table, table_rows * w, &d_rows));
+    CHK(timed_begin(ctx, 0));
     launch_lasso_fingerprints(d_rows, table_rows, w, d_tev, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ht.data(), d_tev, table_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    th_table = std::thread([&ht, table_rows, table_commitment] { flat_commit(ht.data(), table_rows, table_commitment); });
     CHK(stage_in(ctx, queries, n_queries * w, &d_rows));
     HIPCHK(ctx, hipMemsetAsync(d_qev, 0, padded * 4, ctx->stream));  // zero-pad, :139-142
     launch_lasso_fingerprints(d_rows, n_queries, w, d_qev, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(hq.data(), d_qev, padded * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    th_query = std::thread([&hq, padded, query_commitment] { flat_commit(hq.data(), padded, query_commitment); });
     *nv_out = log2_floor(padded);
     if (padded == 1) return ZIGZ_ERR_NO_VARIABLES;  // SumcheckProver.prove on a 0-variable poly, :160
     if (!rounds || !point) return ZIGZ_ERR_INVALID_ARGUMENT;
     CHK(sumcheck_core(ctx, d_qev, padded, nullptr, nullptr, rounds, point, final_eval));
-    std::vector<uint32_t> hq(padded), ht(table_rows);
-    HIPCHK(ctx, hipMemcpyAsync(hq.data(), d_qev, padded * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipMemcpyAsync(ht.data(), d_tev, table_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-    flat_commit(hq.data(), padded, query_commitment);
-    flat_commit(ht.data(), table_rows, table_commitment);
+    th_table.join();
+    th_query.join();
     return ZIGZ_OK;
     ZIGZ_NOTHROW_END(ctx)
 }
