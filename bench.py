@@ -226,6 +226,8 @@ def main():
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
                     "the headline is measured with the dense, data-independent build")
+    ap.add_argument("--dense-merkle", action="store_true", help="hash every leaf and level-1 node of all 43 columns (turns off the "
+                    "table lookups for the 8 structurally small-domain columns: x0, opcode, rd, rs1, rs2, funct3, funct7, is_read)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=12, help="columns of the CPU baseline sample (~1.1 s each)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -296,6 +298,8 @@ def main():
             dist.init_process_group(backend=backend)
     tdev = "cuda" if backend == "nccl" else "cpu"
 
+    if args.dense_merkle:
+        os.environ["ZIGZ_DENSE_MERKLE"] = "1"
     import zigz_amd
     from zigz_amd import host
     import programs
@@ -501,7 +505,11 @@ def main():
                                    "Prover.prove hot path incl. Fiat-Shamir transcript and ZIGZ v1 serialisation; "
                                    "%d independent traces (proofs) per GPU per step" % (nv, B),
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
-                       "merkle_build": "run-aware (merkle_dedup)" if args.dedup else "dense",
+                       "merkle_build": "run-aware (merkle_dedup)" if args.dedup else
+                                       ("dense" if args.dense_merkle else "dense; leaf + level-1 digests of the 8 structurally "
+                                        "small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, is_read: values < 128 by "
+                                        "construction) from constant tables, identical trees"),
+                       "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
                        "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
                                        "sequential host transcript every rank replays" % world) if shard else

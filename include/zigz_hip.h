@@ -311,6 +311,11 @@ typedef struct zigz_kernel_stats {
     uint64_t keccak_level_wide_perms;
     double keccak_level_small_us;
     uint64_t keccak_level_small_perms;
+    /* option "small_domain_mask": columns whose levels 0-1 came from the constant tables in the last batched commit, the
+     * kernel time of that launch, and the number of waves that found a value >= 128 and hashed instead */
+    uint64_t small_domain_columns;
+    double small_domain_us;
+    uint64_t small_domain_fallback_waves;
 } zigz_kernel_stats;
 /* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
  * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per
@@ -331,7 +336,13 @@ zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size_t nv, size
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
 /* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
  * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;
- * "merkle_dedup" = 1 enables the run-aware Merkle build (identical trees; fewer hashes on piecewise-constant columns) */
+ * "merkle_dedup" = 1 enables the run-aware Merkle build (identical trees; fewer hashes on piecewise-constant columns);
+ * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
+ *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the
+ *   instruction fields opcode / rd / rs1 / rs2 / funct3 / funct7 (7-, 5-, 5-, 5-, 3-, 7-bit fields, rv64i.zig:124-151) and
+ *   mem.is_read (0 / 1) -- so its leaf digests SHA3(LE64(v)) and level-1 nodes are looked up in two constant tables
+ *   (128 + 128^2 digests) instead of hashed: 1.5 N of the 2 N permutations of such a column.  The bound is checked per
+ *   wave on the device; where it does not hold the digests are hashed, so the trees are identical for ANY input. */
 zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
 

@@ -261,6 +261,46 @@ def test_commit_job_survives_interleaved_calls(ctx, nv):
         assert np.array_equal(got[k], exp[k]), k
 
 
+@pytest.mark.parametrize("nv", [10, 12, 15])
+def test_small_domain_tables_identical_trees(ctx, nv):
+    """Option "small_domain_mask": hinted columns take leaf + level-1 digests from the constant tables.  Roots and every
+    opening equal the oracle's (literal hashing) for columns that satisfy the bound (values < 128), columns that violate
+    it everywhere (hint wrong: the device notices and hashes) and columns that violate it in a few places only."""
+    import zigz_amd
+    N = 1 << nv
+    rng = np.random.default_rng(nv)
+    cols = rnd(0x5D00 + nv, 43 * N).reshape(43, N)
+    small = [1, 33, 34, 35, 36, 37, 38, 42]
+    for c in small:
+        cols[c] = rng.integers(0, 128, size=N, dtype=np.uint64)
+    cols[1] = 0
+    cols[42] = rng.integers(0, 2, size=N, dtype=np.uint64)
+    cols[36, 777] = 128               # one value just outside the domain
+    cols[37, N - 1] = P - 1           # ... and one far outside, in the last pair
+    hinted = small + [5, 20]          # two hinted columns hold arbitrary field elements: the hint is simply wrong there
+    mask = sum(1 << c for c in hinted)
+    exp = O.generate_commitments(P, O.Transcript(), cols, fast=(nv > 10))
+    ctx.set_option("small_domain_mask", mask)
+    try:
+        job = zigz_amd.CommitJob(ctx, cols=cols)
+        roots = job.roots()
+        st = ctx.stats()
+        got = job.open_all(exp["points"])
+        job.end()
+    finally:
+        ctx.set_option("small_domain_mask", 0)
+    assert st["small_domain_columns"] == len(hinted)
+    # columns 5 and 20 fall back on every wave, 36 and 37 on one wave each
+    assert st["small_domain_fallback_waves"] == 2 * (N // 2 // 64) + 2
+    assert np.array_equal(roots, exp["roots"])
+    for k in ("values", "indices", "leaves", "siblings", "dirs"):
+        assert np.array_equal(got[k], exp[k]), k
+    # openings that pass through looked-up nodes: leaf index pairs inside hinted columns
+    for c in (1, 36, 42, 5):
+        lv, _ = O.merkle_levels(cols[c])
+        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == roots[c].tobytes()
+
+
 def test_commit_job_large_properties(ctx):
     """43 x 2^18 columns (BASELINE-scale shape): every opening verifies against its root through the
     oracle's Merkle verifier; values match the oracle's fold-eval on sampled columns."""

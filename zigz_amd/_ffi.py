@@ -27,7 +27,9 @@ class KernelStats(C.Structure):
                 ("merkle_blocks", C.c_uint64), ("merkle_uniform_blocks", C.c_uint64),
                 ("keccak_leaves_us", C.c_double), ("keccak_leaves_perms", C.c_uint64),
                 ("keccak_level_wide_us", C.c_double), ("keccak_level_wide_perms", C.c_uint64),
-                ("keccak_level_small_us", C.c_double), ("keccak_level_small_perms", C.c_uint64)]
+                ("keccak_level_small_us", C.c_double), ("keccak_level_small_perms", C.c_uint64),
+                ("small_domain_columns", C.c_uint64), ("small_domain_us", C.c_double),
+                ("small_domain_fallback_waves", C.c_uint64)]
 
 
 class BenchResult(C.Structure):

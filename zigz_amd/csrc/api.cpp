@@ -50,6 +50,9 @@ struct zigz_ctx {
     uint64_t kev_perms[40];
     int kev_n;
     void *d_flush;          // 1 GiB read-only scratch of zigz_bench_kernel (cold-HBM runs), allocated on first use
+    uint64_t small_domain_mask;  // option: columns (bit c) whose values are < 128 by construction -> levels 0-1 by table
+    uint8_t *d_sd_tables;        // T0 | T1 (kernels.hpp SD_TABLE_BYTES), built on first use
+    unsigned long long *d_sd_fallbacks;
     zigz_kernel_stats stats;
     zigz_commit_job *active_job;
 };
@@ -224,6 +227,8 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
     for (int i = 0; i < 80; i++)
         if (ctx->kev[i]) (void)hipEventDestroy(ctx->kev[i]);
     if (ctx->d_flush) (void)hipFree(ctx->d_flush);
+    if (ctx->d_sd_tables) (void)hipFree(ctx->d_sd_tables);
+    if (ctx->d_sd_fallbacks) (void)hipFree(ctx->d_sd_fallbacks);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -272,6 +277,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "merkle_dedup") == 0) { ctx->merkle_dedup = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
@@ -1091,8 +1097,37 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         ctx->stats.merkle_blocks = (uint64_t)ncols * nblocks;
         l_start = DEDUP_BLOG;
     } else {
-        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
+        // columns hinted as small-domain (values < 128 by construction): levels 0 and 1 come from two constant tables,
+        // checked per wave and hashed where the bound does not hold; the other columns are hashed densely
+        ColMap H{}, D{};
+        bool use_sd = ctx->small_domain_mask && npad >= 1024 && ncols <= 64;
+        if (use_sd) {
+            for (size_t c = 0; c < ncols; c++) {
+                ColMap &m = (ctx->small_domain_mask >> c) & 1 ? H : D;
+                m.c[m.n++] = (uint8_t)c;
+            }
+            use_sd = H.n != 0;
+        }
         ctx->stats.merkle_blocks = 0;
+        ctx->stats.small_domain_columns = 0;
+        if (use_sd) {
+            if (!ctx->d_sd_tables) {
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
+                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_fallbacks, 64));
+                launch_sd_tables(ctx->d_sd_tables, ctx->stream);
+            }
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
+            launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
+                                    ctx->stream, stamp(3, 0));
+            launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
+                                 stamp(0, (uint64_t)D.n * npad), &D);
+            launch_keccak_level(d_tree, stride, tree_level_offset(npad, 0), tree_level_offset(npad, 1), npad / 2, ncols, ctx->stream,
+                                stamp(keccak_level_is_wide(npad / 2, D.n) ? 1 : 2, (uint64_t)D.n * (npad / 2)), &D);
+            ctx->stats.small_domain_columns = H.n;
+            l_start = 1;
+        } else {
+            launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
+        }
     }
     for (unsigned l = l_start; l < height; l++) {
         const size_t n_out = npad >> (l + 1);
@@ -1109,7 +1144,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
 
 // after the stream has passed the last recorded launch: per-class device time of the last recorded build
 static zigz_status keccak_times_collect(zigz_ctx *ctx) {
-    double us[4] = {0, 0, 0, 0};
+    double us[4] = {0, 0, 0, 0};  // 0 leaves, 1 wide levels, 2 small levels, 3 small-domain table lookups
     uint64_t perms[4] = {0, 0, 0, 0};
     for (int i = 0; i < ctx->kev_n; i++) {
         float ms = 0;
@@ -1124,6 +1159,7 @@ static zigz_status keccak_times_collect(zigz_ctx *ctx) {
     ctx->stats.keccak_level_wide_perms = perms[1];
     ctx->stats.keccak_level_small_us = us[2];
     ctx->stats.keccak_level_small_perms = perms[2];
+    ctx->stats.small_domain_us = us[3];
     ctx->kev_n = 0;
     return ZIGZ_OK;
 }
@@ -1291,7 +1327,9 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         delete job;
         return st;
     }
-    ctx->stats.keccak_permutations = (uint64_t)ncols * (2 * job->N - 1);
+    // hinted columns take levels 0 and 1 (N + N/2 digests) from the tables (waves that had to hash are counted in
+    // small_domain_fallback_waves, read in zigz_commit_roots; they are not added back here)
+    ctx->stats.keccak_permutations = (uint64_t)ncols * (2 * job->N - 1) - (uint64_t)ctx->stats.small_domain_columns * (job->N + job->N / 2);
     ctx->active_job = job;
     *out = job;
     return ZIGZ_OK;
@@ -1339,6 +1377,13 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
         ctx->stats.merkle_uniform_blocks = cnt;
     } else {
         ctx->stats.merkle_uniform_blocks = 0;
+    }
+    if (ctx->stats.small_domain_columns) {
+        unsigned long long fb = 0;
+        HIPCHK(ctx, hipMemcpy(&fb, ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost));
+        ctx->stats.small_domain_fallback_waves = fb;
+    } else {
+        ctx->stats.small_domain_fallback_waves = 0;
     }
     if (ctx->timing) {
         float ms = 0;

@@ -4,6 +4,7 @@
 // sequential O(L) transcript absorption of the Lasso placeholders.
 #include <chrono>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <thread>
@@ -80,6 +81,11 @@ size_t Proof::estimateSize() const {  // :279-312
 }
 
 // ---------------------------------------------------------------- Prover
+bool Prover::defaultSmallDomain() {
+    const char *e = getenv("ZIGZ_DENSE_MERKLE");
+    return !(e && e[0] == '1');
+}
+
 void Prover::bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs) {
     transcript_.reset();                                   // prover.zig:91
     transcript_.appendBytes(program_hash.data(), 32);      // :98-100
@@ -231,6 +237,18 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
             throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "sharded prove: bad rank / world");
         columnBlock(ZIGZ_NUM_COLUMNS, shard_.world, shard_.rank, c0, c1);
     }
+    // Columns that hold values < 128 by construction (x0; opcode, rd, rs1, rs2, funct3, funct7; mem.is_read --
+    // witness.zig:164-169,239, registers.zig:38-48): their leaf and level-1 digests come from constant tables
+    // (zigz_hip.h, option "small_domain_mask"; checked on the device, identical trees for any input).
+    if (small_domain_tables) {
+        const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
+        check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
+    }
+    struct MaskReset {
+        zigz_ctx *ctx;
+        bool on;
+        ~MaskReset() { if (on) (void)zigz_ctx_set_option(ctx, "small_domain_mask", 0); }
+    } mask_reset{ctx_, small_domain_tables};
     if (witness)
         check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
                                       (size_t)1 << num_vars, num_vars, &guard.job));

@@ -295,6 +295,10 @@ class Prover {  // src/prover/prover.zig
     // 2 lasso transcript, 3 wait for roots, 4 absorb roots + challenges, 5 open_all, 6 packaging
     double timings[8] = {0};
     bool verbose = false;  // the reference prints progress banners unconditionally (prover.zig:82-85); off by default here
+    // leaf / level-1 digests of the structurally small-domain witness columns by table lookup (identical trees); the
+    // environment variable ZIGZ_DENSE_MERKLE=1 turns it off process-wide (A/B measurements)
+    bool small_domain_tables = defaultSmallDomain();
+    static bool defaultSmallDomain();
 
   private:
     void bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs);  // :91-110

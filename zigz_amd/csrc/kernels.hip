@@ -619,8 +619,8 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
 constexpr int HPT = ZK_HPT;
 __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
-                                                       size_t tree_stride_nodes) {
-    const size_t col = blockIdx.y;
+                                                       size_t tree_stride_nodes, ColMap cmap) {
+    const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
     const uint32_t *v = vals + col * val_stride;
 #pragma unroll 1
@@ -638,9 +638,9 @@ __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restric
 // Requires n_out % 64 == 0 (levels handled here have >= 512 nodes).
 template <int H>
 __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
-                                                      size_t in_off, size_t out_off, size_t n_out) {
+                                                      size_t in_off, size_t out_off, size_t n_out, ColMap cmap) {
     __shared__ uint4 stage[TPB / 64][64 * 5];
-    const size_t col = blockIdx.y;
+    const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 #pragma unroll 1
@@ -807,24 +807,82 @@ void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t
 }
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                          size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt) {
-    dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
+                          size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
+    ColMap cm{};
+    if (cols) cm = *cols;
+    if (cols && cm.n == 0) return;  // an explicit, empty column list
+    dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)(cols ? cm.n : ncols));
     ZK_LAUNCH(kt, k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
-              tree_stride_nodes);
+              tree_stride_nodes, cm);
 }
 
 bool keccak_level_is_wide(size_t n_out, size_t ncols) { return n_out * ncols >= (size_t)TPB * HPT * 4096; }
 
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
-                         size_t ncols, hipStream_t s, const KTime *kt) {
+                         size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
+    ColMap cm{};
+    if (cols) cm = *cols;
+    if (cols && cm.n == 0) return;
+    const size_t nc = cols ? cm.n : ncols;
     // several hashes per thread only while that still leaves >= 16 workgroups per CU (small levels need the waves)
-    if (keccak_level_is_wide(n_out, ncols)) {
-        dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-        ZK_LAUNCH(kt, k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+    if (keccak_level_is_wide(n_out, nc)) {
+        dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)nc);
+        ZK_LAUNCH(kt, k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
     } else {
-        dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)ncols);
-        ZK_LAUNCH(kt, k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out);
+        dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)nc);
+        ZK_LAUNCH(kt, k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
     }
+}
+
+// ------------------------------------------------------------------ small-domain columns: levels 0 and 1 by table
+__global__ __launch_bounds__(TPB) void k_sd_tables(uint8_t *__restrict__ tables) {
+    const unsigned t = blockIdx.x * TPB + threadIdx.x;  // (a, b) = (t / 128, t % 128)
+    if (t >= SD_DOMAIN * SD_DOMAIN) return;
+    const unsigned a = t / SD_DOMAIN, b = t % SD_DOMAIN;
+    const Digest la = sha3_leaf(a), lb = sha3_leaf(b);
+    store_digest(tables + (size_t)SD_DOMAIN * 32, t, sha3_node(la, lb));
+    if (b == 0) store_digest(tables, a, la);
+}
+void launch_sd_tables(uint8_t *d_tables, hipStream_t s) {
+    hipLaunchKernelGGL(k_sd_tables, dim3(SD_DOMAIN * SD_DOMAIN / TPB), dim3(TPB), 0, s, d_tables);
+}
+
+__global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                          size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes,
+                                                          ColMap cmap, const uint8_t *__restrict__ tables,
+                                                          unsigned long long *__restrict__ fallbacks) {
+    const size_t col = cmap.c[blockIdx.y];
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;  // level-1 node
+    const size_t n1 = npad / 2;
+    const bool live = i < n1;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    const uint32_t *v = vals + col * val_stride;
+    // padding leaves hash the value 0 (merkle_tree.zig:302-306)
+    const uint32_t v0 = live && 2 * i < n_values ? v[2 * i] : 0, v1 = live && 2 * i + 1 < n_values ? v[2 * i + 1] : 0;
+    Digest l0, l1, nd;
+    if (__all(v0 < SD_DOMAIN && v1 < SD_DOMAIN)) {  // wave-uniform: every value under this wave's nodes is in the domain
+        l0 = load_digest(tables, v0);
+        l1 = load_digest(tables, v1);
+        nd = load_digest(tables + (size_t)SD_DOMAIN * 32, (size_t)v0 * SD_DOMAIN + v1);
+    } else {  // the bound does not hold here (a caller's hint was wrong): hash, same digests
+        l0 = sha3_leaf(v0);
+        l1 = sha3_leaf(v1);
+        nd = sha3_node(l0, l1);
+        if ((threadIdx.x & 63) == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
+    }
+    if (live) {
+        store_digest(t, 2 * i, l0);
+        store_digest(t, 2 * i + 1, l1);
+        store_digest(t, npad + i, nd);  // level 1 starts at node offset 2*npad - 2*(npad/2) = npad
+    }
+}
+void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                             size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
+                             unsigned long long *d_fallbacks, hipStream_t s, const KTime *kt) {
+    if (cols.n == 0 || npad < 2) return;
+    dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
+    ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
+              d_tables, d_fallbacks);
 }
 
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,

@@ -113,12 +113,29 @@ void launch_keccak_leaves_dedup(const uint32_t *d_vals, size_t val_stride, size_
 void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned out_level,
                                const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols, hipStream_t s);
 
+// The columns a Keccak launch works on: blockIdx.y = k -> column c[k] (n == 0: identity, column = blockIdx.y).
+struct ColMap {
+    uint8_t n;
+    uint8_t c[64];
+};
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
-                          uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr);
+                          uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,
+                          const ColMap *cols = nullptr);
 // K6: one level.  out node i = SHA3(in node 2i || in node 2i+1), i < n_out  (node offsets per column)
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
-                         size_t ncols, hipStream_t s, const KTime *kt = nullptr);
+                         size_t ncols, hipStream_t s, const KTime *kt = nullptr, const ColMap *cols = nullptr);
+// Small-domain columns (values < 128 by construction: the instruction-field columns of the witness, x0, is_read): leaf
+// digests and level-1 nodes are looked up in two constant tables instead of hashed -- T0[v] = SHA3(LE64(v)), v < 128, and
+// T1[a*128+b] = SHA3(T0[a] || T0[b]) (128 + 16384 digests in tree form, 516 KiB) -- whenever all 128 values under a
+// wave's 64 level-1 nodes are < 128; otherwise the wave hashes its 3 x 64 digests.  Identical trees either way.
+constexpr unsigned SD_DOMAIN = 128;
+constexpr size_t SD_TABLE_BYTES = (size_t)(SD_DOMAIN + SD_DOMAIN * SD_DOMAIN) * 32;
+void launch_sd_tables(uint8_t *d_tables, hipStream_t s);
+// levels 0 and 1 of the columns in `cols` (npad >= 2); d_fallbacks: count of waves that had to hash (diagnostics)
+void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                             size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
+                             unsigned long long *d_fallbacks, hipStream_t s, const KTime *kt = nullptr);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
