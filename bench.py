@@ -475,6 +475,7 @@ def main():
                 "level_small_gperm_per_s": (a["keccak_level_small_perms"] / 1e9 / (a["keccak_level_small_us"] / 1e6))
                 if a["keccak_level_small_us"] else None,
                 "merkle_build_ms": a["merkle_build_us"] / solo["n"] / 1e3,
+                "small_domain_lookup_us": a["small_domain_us"] / solo["n"],
                 "merkle_build_gperm_per_s": a["keccak_permutations"] / 1e9 / (a["merkle_build_us"] / 1e6),
                 "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1),
                 "eval_fold_hbm_frac": (a["bind_vec_bytes"] / 1e9) / (a["bind_vec_us"] / 1e6) / HBM_PEAK_GBS if a["bind_vec_us"] else None,
@@ -533,6 +534,8 @@ def main():
             "keccak_level_wide_ms_per_proof": acc["keccak_level_wide_us"] / nproofs / 1e3,
             "keccak_level_small_ms_per_proof": acc["keccak_level_small_us"] / nproofs / 1e3,
             "eval_ms_per_proof": acc["eval_us"] / nproofs / 1e3,
+            "small_domain_lookup_ms_per_proof": acc["small_domain_us"] / nproofs / 1e3,
+            "small_domain_fallback_waves": acc["small_domain_fallback_waves"],
             "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
             "gpu_busy_keccak_gperm_per_s": (acc["keccak_permutations"] / 1e9) / dt},
             "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode(),

@@ -1100,7 +1100,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         // columns hinted as small-domain (values < 128 by construction): levels 0 and 1 come from two constant tables,
         // checked per wave and hashed where the bound does not hold; the other columns are hashed densely
         ColMap H{}, D{};
-        bool use_sd = ctx->small_domain_mask && npad >= 1024 && ncols <= 64;
+        bool use_sd = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
         if (use_sd) {
             for (size_t c = 0; c < ncols; c++) {
                 ColMap &m = (ctx->small_domain_mask >> c) & 1 ? H : D;
@@ -1117,8 +1117,10 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
                 launch_sd_tables(ctx->d_sd_tables, ctx->stream);
             }
             HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
+            void *todo;
+            CHK(ws_get(ctx, WS_DEDUP, sd_todo_words(npad, H.n) * 4, &todo));
             launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
-                                    ctx->stream, stamp(3, 0));
+                                    (uint32_t *)todo, ctx->stream, stamp(3, 0));
             launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
                                  stamp(0, (uint64_t)D.n * npad), &D);
             launch_keccak_level(d_tree, stride, tree_level_offset(npad, 0), tree_level_offset(npad, 1), npad / 2, ncols, ctx->stream,

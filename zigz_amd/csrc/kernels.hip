@@ -847,42 +847,70 @@ void launch_sd_tables(uint8_t *d_tables, hipStream_t s) {
     hipLaunchKernelGGL(k_sd_tables, dim3(SD_DOMAIN * SD_DOMAIN / TPB), dim3(TPB), 0, s, d_tables);
 }
 
+// Pass 1: the lookups.  One thread = one level-1 node = two leaves.  A wave whose 128 values are not all inside the
+// domain does nothing but append itself to the to-do list (kept out of this kernel so that it stays small: a few VGPRs,
+// full occupancy, HBM-write-bound).  Pass 2 (k_keccak_small_fallback) hashes the listed waves; it is always launched
+// with a small fixed grid that walks the list, and costs a few microseconds when the list is empty.
 __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
                                                           size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                           ColMap cmap, const uint8_t *__restrict__ tables,
-                                                          unsigned long long *__restrict__ fallbacks) {
+                                                          unsigned long long *__restrict__ todo_count,
+                                                          uint32_t *__restrict__ todo) {
     const size_t col = cmap.c[blockIdx.y];
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;  // level-1 node
-    const size_t n1 = npad / 2;
-    const bool live = i < n1;
+    const bool live = i < npad / 2;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
-    const uint32_t *v = vals + col * val_stride;
+    const uint2 *v = reinterpret_cast<const uint2 *>(vals + col * val_stride);
     // padding leaves hash the value 0 (merkle_tree.zig:302-306)
-    const uint32_t v0 = live && 2 * i < n_values ? v[2 * i] : 0, v1 = live && 2 * i + 1 < n_values ? v[2 * i + 1] : 0;
-    Digest l0, l1, nd;
-    if (__all(v0 < SD_DOMAIN && v1 < SD_DOMAIN)) {  // wave-uniform: every value under this wave's nodes is in the domain
-        l0 = load_digest(tables, v0);
-        l1 = load_digest(tables, v1);
-        nd = load_digest(tables + (size_t)SD_DOMAIN * 32, (size_t)v0 * SD_DOMAIN + v1);
-    } else {  // the bound does not hold here (a caller's hint was wrong): hash, same digests
-        l0 = sha3_leaf(v0);
-        l1 = sha3_leaf(v1);
-        nd = sha3_node(l0, l1);
-        if ((threadIdx.x & 63) == 0 && fallbacks) atomicAdd(fallbacks, 1ull);
-    }
-    if (live) {
-        store_digest(t, 2 * i, l0);
-        store_digest(t, 2 * i + 1, l1);
-        store_digest(t, npad + i, nd);  // level 1 starts at node offset 2*npad - 2*(npad/2) = npad
+    uint2 x = make_uint2(0, 0);
+    if (live && 2 * i + 1 < n_values) x = v[i];
+    else if (live && 2 * i < n_values) x.x = vals[col * val_stride + 2 * i];
+    if (__all(x.x < SD_DOMAIN && x.y < SD_DOMAIN)) {  // wave-uniform: every value under this wave's nodes is in the domain
+        if (live) {
+            const Digest l0 = load_digest(tables, x.x), l1 = load_digest(tables, x.y);
+            const Digest nd = load_digest(tables + (size_t)SD_DOMAIN * 32, (size_t)x.x * SD_DOMAIN + x.y);
+            store_digest(t, 2 * i, l0);
+            store_digest(t, 2 * i + 1, l1);
+            store_digest(t, npad + i, nd);  // level 1 starts at node offset 2*npad - 2*(npad/2) = npad
+        }
+    } else if ((threadIdx.x & 63) == 0) {  // the bound does not hold here (a caller's hint was wrong): leave it to pass 2
+        const unsigned long long k = atomicAdd(todo_count, 1ull);
+        todo[2 * k] = (uint32_t)blockIdx.y;
+        todo[2 * k + 1] = (uint32_t)(i >> 6);
     }
 }
+
+__global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *__restrict__ vals, size_t val_stride,
+                                                               size_t n_values, size_t npad, uint8_t *__restrict__ tree,
+                                                               size_t tree_stride_nodes, ColMap cmap,
+                                                               const unsigned long long *__restrict__ todo_count,
+                                                               const uint32_t *__restrict__ todo) {
+    const unsigned long long count = *todo_count;
+    const unsigned lane = threadIdx.x & 63;
+    for (unsigned long long w = (unsigned long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); w < count;
+         w += (unsigned long long)gridDim.x * (TPB / 64)) {
+        const size_t col = cmap.c[todo[2 * w]];
+        const size_t i = (size_t)todo[2 * w + 1] * 64 + lane;
+        if (i >= npad / 2) continue;
+        uint8_t *t = tree + col * tree_stride_nodes * 32;
+        const uint32_t *v = vals + col * val_stride;
+        const uint64_t v0 = 2 * i < n_values ? v[2 * i] : 0, v1 = 2 * i + 1 < n_values ? v[2 * i + 1] : 0;
+        const Digest l0 = sha3_leaf(v0), l1 = sha3_leaf(v1);
+        store_digest(t, 2 * i, l0);
+        store_digest(t, 2 * i + 1, l1);
+        store_digest(t, npad + i, sha3_node(l0, l1));
+    }
+}
+
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
-                             unsigned long long *d_fallbacks, hipStream_t s, const KTime *kt) {
+                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt) {
     if (cols.n == 0 || npad < 2) return;
     dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
     ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
-              d_tables, d_fallbacks);
+              d_tables, d_todo_count, d_todo);
+    hipLaunchKernelGGL(k_keccak_small_fallback, dim3(2048), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                       tree_stride_nodes, cols, d_todo_count, d_todo);
 }
 
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,

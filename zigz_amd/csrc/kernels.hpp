@@ -132,10 +132,12 @@ void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_of
 constexpr unsigned SD_DOMAIN = 128;
 constexpr size_t SD_TABLE_BYTES = (size_t)(SD_DOMAIN + SD_DOMAIN * SD_DOMAIN) * 32;
 void launch_sd_tables(uint8_t *d_tables, hipStream_t s);
-// levels 0 and 1 of the columns in `cols` (npad >= 2); d_fallbacks: count of waves that had to hash (diagnostics)
+// levels 0 and 1 of the columns in `cols` (npad >= 2).  d_todo_count (zeroed by the caller) / d_todo: the waves that found
+// a value outside the domain, hashed by a second launch; sd_todo_words(npad, ncols) u32 of list space
+inline size_t sd_todo_words(size_t npad, size_t ncols) { return 2 * ncols * ((npad / 2 + 63) / 64) + 2; }
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
-                             unsigned long long *d_fallbacks, hipStream_t s, const KTime *kt = nullptr);
+                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
