@@ -598,6 +598,11 @@ __device__ __forceinline__ void store_digest(uint8_t *tree, size_t node, const D
     __builtin_nontemporal_store(d.w[2], q + 2);
     __builtin_nontemporal_store(d.w[3], q + 3);
 }
+typedef unsigned int zk_v4u __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void nt_store16(uint4 *dst, const uint4 &v) {  // global_store_dwordx4 ... nt
+    zk_v4u x = {v.x, v.y, v.z, v.w};
+    __builtin_nontemporal_store(x, reinterpret_cast<zk_v4u *>(dst));
+}
 __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) {
     const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(tree + node * 32);
     ulonglong2 x = q[0], y = q[1];
@@ -866,12 +871,30 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__rest
     if (live && 2 * i + 1 < n_values) x = v[i];
     else if (live && 2 * i < n_values) x.x = vals[col * val_stride + 2 * i];
     if (__all(x.x < SD_DOMAIN && x.y < SD_DOMAIN)) {  // wave-uniform: every value under this wave's nodes is in the domain
+        // (npad >= 1024: a wave is entirely live or entirely past the end)
         if (live) {
-            const Digest l0 = load_digest(tables, x.x), l1 = load_digest(tables, x.y);
-            const Digest nd = load_digest(tables + (size_t)SD_DOMAIN * 32, (size_t)x.x * SD_DOMAIN + x.y);
-            store_digest(t, 2 * i, l0);
-            store_digest(t, 2 * i + 1, l1);
-            store_digest(t, npad + i, nd);  // level 1 starts at node offset 2*npad - 2*(npad/2) = npad
+            // the wave's 128 leaf digests are 4 KiB of contiguous tree, its 64 nodes 2 KiB: hand them through LDS so every
+            // store instruction writes 1 KiB of consecutive bytes (32-byte digests stored lane by lane are quarter-line
+            // partial writes: 1.1 TB/s instead of HBM rate)
+            __shared__ uint4 sh[TPB / 64][64 * 6];
+            uint4 *mine = sh[threadIdx.x >> 6];
+            const unsigned lane = threadIdx.x & 63;
+            const uint4 *t0 = reinterpret_cast<const uint4 *>(tables);
+            const uint4 *t1 = reinterpret_cast<const uint4 *>(tables + (size_t)SD_DOMAIN * 32);
+            const size_t e = (size_t)x.x * SD_DOMAIN + x.y;
+            mine[4 * lane + 0] = t0[2 * x.x];
+            mine[4 * lane + 1] = t0[2 * x.x + 1];
+            mine[4 * lane + 2] = t0[2 * x.y];
+            mine[4 * lane + 3] = t0[2 * x.y + 1];
+            mine[256 + 2 * lane + 0] = t1[2 * e];
+            mine[256 + 2 * lane + 1] = t1[2 * e + 1];
+            __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave; keep the compiler from moving the reads up
+            const size_t w0 = i - lane;       // first node of this wave
+            uint4 *leaves = reinterpret_cast<uint4 *>(t + 2 * w0 * 32), *nodes = reinterpret_cast<uint4 *>(t + (npad + w0) * 32);
+#pragma unroll
+            for (int k = 0; k < 4; k++) nt_store16(leaves + 64 * k + lane, mine[64 * k + lane]);
+#pragma unroll
+            for (int k = 0; k < 2; k++) nt_store16(nodes + 64 * k + lane, mine[256 + 64 * k + lane]);
         }
     } else if ((threadIdx.x & 63) == 0) {  // the bound does not hold here (a caller's hint was wrong): leave it to pass 2
         const unsigned long long k = atomicAdd(todo_count, 1ull);
