@@ -622,44 +622,18 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
 #define ZK_HPT 4
 #endif
 constexpr int HPT = ZK_HPT;
-static int g_keccak_variant = 0;  // A/B switch of the digest-store path (set_keccak_variant)
-void set_keccak_variant(int v) { g_keccak_variant = v; }
-// The 64 digests a wave has just computed are 2 KiB of consecutive tree nodes.  Stored lane by lane they are two store
-// instructions of 16 B at a 32-byte lane stride -- half-line partial writes, which the memory side handles at a fraction
-// of the HBM rate (1.1 TB/s measured on the lookup kernel below).  Handed through a wave-private slice of LDS they
-// become two store instructions of 1 KiB of consecutive bytes each.  No barrier: LDS is in order within a wave.
-__device__ __forceinline__ void store_digests_wave(uint8_t *tree, size_t first_node, const Digest &d, uint4 *lds_wave) {
-    const unsigned lane = threadIdx.x & 63;
-    lds_wave[2 * lane] = make_uint4((uint32_t)d.w[0], (uint32_t)(d.w[0] >> 32), (uint32_t)d.w[1], (uint32_t)(d.w[1] >> 32));
-    lds_wave[2 * lane + 1] = make_uint4((uint32_t)d.w[2], (uint32_t)(d.w[2] >> 32), (uint32_t)d.w[3], (uint32_t)(d.w[3] >> 32));
-    __builtin_amdgcn_wave_barrier();
-    uint4 *dst = reinterpret_cast<uint4 *>(tree + first_node * 32);
-    nt_store16(dst + lane, lds_wave[lane]);
-    nt_store16(dst + 64 + lane, lds_wave[64 + lane]);
-    __builtin_amdgcn_wave_barrier();
-}
-
-// V: 0 = digests stored lane by lane; 1 = through wave-private LDS (store_digests_wave)
-template <int V>
 __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                        size_t tree_stride_nodes, ColMap cmap) {
-    __shared__ uint4 out_stage[V ? TPB / 64 : 1][V ? 128 : 1];
     const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
     const uint32_t *v = vals + col * val_stride;
 #pragma unroll 1
     for (int h = 0; h < HPT; h++) {
         const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
-        const size_t first = i - (threadIdx.x & 63);  // wave-uniform
-        if (first >= npad) return;
+        if (i >= npad) return;
         const uint64_t x = i < n_values ? v[i] : 0;  // pad with hashLeaf(0), merkle_tree.zig:302-306
-        if (V && first + 64 <= npad) {
-            store_digests_wave(t, first, sha3_leaf(x), out_stage[threadIdx.x >> 6]);
-        } else {
-            if (i >= npad) return;
-            store_digest(t, i, sha3_leaf(x));
-        }
+        store_digest(t, i, sha3_leaf(x));
     }
 }
 
@@ -667,7 +641,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restric
 // coalesced 16-byte loads (1 KiB per wave instruction) and handed to their lanes through LDS (rows padded to 80 B so
 // the per-lane 4 x ds_read_b128 are bank-conflict free), instead of four 64-byte-strided loads per lane.
 // Requires n_out % 64 == 0 (levels handled here have >= 512 nodes).
-template <int H, int V>
+template <int H>
 __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                       size_t in_off, size_t out_off, size_t n_out, ColMap cmap) {
     __shared__ uint4 stage[TPB / 64][64 * 5];
@@ -687,10 +661,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree
                 // Infinity Cache for the eval pass, 28 us instead of 33, but slow this kernel by 3 %: not taken)
             }
         }
-        // stage[wave] is private to the wave: V = 0 keeps round 1's workgroup barriers around it, V = 1 only orders the
-        // wave's own LDS traffic (no coupling of the four waves of a workgroup) and stores the digests through the slice
-        if (V) __builtin_amdgcn_wave_barrier();
-        else __syncthreads();
+        __syncthreads();
         if (active) {
             const uint4 *r = &stage[wave][lane * 5];
             const uint4 a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3];
@@ -698,10 +669,11 @@ __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree
                       ((uint64_t)a1.w << 32) | a1.z}};
             Digest rr{{((uint64_t)b0.y << 32) | b0.x, ((uint64_t)b0.w << 32) | b0.z, ((uint64_t)b1.y << 32) | b1.x,
                        ((uint64_t)b1.w << 32) | b1.z}};
-            if (V) store_digests_wave(t, out_off + first, sha3_node(l, rr), stage[wave]);
-            else store_digest(t, out_off + first + lane, sha3_node(l, rr));
+            // (staging the 32-byte digest stores through LDS as well was measured slower: the extra barriers cost
+            // more than the half-coalesced stores)
+            store_digest(t, out_off + first + lane, sha3_node(l, rr));
         }
-        if (!V) __syncthreads();
+        __syncthreads();
     }
 }
 
@@ -845,12 +817,8 @@ void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_va
     if (cols) cm = *cols;
     if (cols && cm.n == 0) return;  // an explicit, empty column list
     dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)(cols ? cm.n : ncols));
-    if (g_keccak_variant)
-        ZK_LAUNCH(kt, k_keccak_leaves<1>, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
-                  tree_stride_nodes, cm);
-    else
-        ZK_LAUNCH(kt, k_keccak_leaves<0>, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
-                  tree_stride_nodes, cm);
+    ZK_LAUNCH(kt, k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
+              tree_stride_nodes, cm);
 }
 
 bool keccak_level_is_wide(size_t n_out, size_t ncols) { return n_out * ncols >= (size_t)TPB * HPT * 4096; }
@@ -864,12 +832,10 @@ void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_of
     // several hashes per thread only while that still leaves >= 16 workgroups per CU (small levels need the waves)
     if (keccak_level_is_wide(n_out, nc)) {
         dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)nc);
-        if (g_keccak_variant) ZK_LAUNCH(kt, (k_keccak_level<HPT, 1>), grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
-        else ZK_LAUNCH(kt, (k_keccak_level<HPT, 0>), grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
+        ZK_LAUNCH(kt, k_keccak_level<HPT>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
     } else {
         dim3 grid((unsigned)((n_out + TPB - 1) / TPB), (unsigned)nc);
-        if (g_keccak_variant) ZK_LAUNCH(kt, (k_keccak_level<1, 1>), grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
-        else ZK_LAUNCH(kt, (k_keccak_level<1, 0>), grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
+        ZK_LAUNCH(kt, k_keccak_level<1>, grid, dim3(TPB), ZK_LEVEL_DYN_LDS, s, d_tree, tree_stride_nodes, in_off, out_off, n_out, cm);
     }
 }
 

@@ -118,8 +118,6 @@ struct ColMap {
     uint8_t n;
     uint8_t c[64];
 };
-// experiments: 0 = digests stored lane by lane, 1 = through wave-private LDS (process-wide)
-void set_keccak_variant(int v);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,
