@@ -84,8 +84,17 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) 
 // Digests stay in this form inside the tree (node input = output of the children, no conversion); they are
 // converted to canonical SHA3 bytes only where they leave the device (roots, authentication paths).
 #if defined(__HIP_DEVICE_COMPILE__)
-#define ZK_X3(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96)
-#define ZK_CHI(a, b, c) __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2)
+// v_bitop3_b32 through the builtin: the compiler neither folds it with constant operands nor merges it with its neighbours,
+// while it does both for plain C operators (but then breaks XOR3 into two v_xor).  So: plain operators exactly where an
+// operand is a compile-time constant after unrolling (the zero / padding lanes of the first round of a leaf or node hash
+// fold away), the builtin everywhere else.
+#ifdef ZK_BITOP3_ALWAYS  // A/B: the round-1 form (builtin everywhere)
+#define ZK_ANYCONST(a, b, c) 0
+#else
+#define ZK_ANYCONST(a, b, c) (__builtin_constant_p(a) || __builtin_constant_p(b) || __builtin_constant_p(c))
+#endif
+#define ZK_X3(a, b, c) (ZK_ANYCONST(a, b, c) ? ((a) ^ (b) ^ (c)) : __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
+#define ZK_CHI(a, b, c) (ZK_ANYCONST(a, b, c) ? ((a) ^ (~(b) & (c))) : __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2))
 #define ZK_ROT32(x, k) __builtin_amdgcn_alignbit((x), (x), 32 - (k))
 #ifndef ZK_REARM_A_ASM
 #define ZK_REARM_A_ASM "s_sleep 2"  // after the 5 rotates of theta
