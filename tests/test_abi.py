@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def declared(header):
     text = open(os.path.join(ROOT, "include", header)).read()
     text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(zigzh?_[a-z0-9_]+)\s*\(", text)))
+    names = set(re.findall(r"\b(zigzh?_[a-z0-9_]+)\s*\(", text))
+    return sorted(names - {"zigz_status"})  # `zigz_status (*callback)(...)` members of zigz_radix_ops
 
 
 def exported(so):
