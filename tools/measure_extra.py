@@ -53,7 +53,11 @@ def main():
                                          bind_vec_GBs=(st["bind_vec_bytes"] / 1e9) / (st["bind_vec_us"] / 1e6) if st["bind_vec_us"] else None,
                                          bind_vec_launches=st["bind_vec_launches"])
         ctx.dev_free(d)
-    # (2) Prover.prove end to end from program bytes at a 2^20 trace (VM + rows H2D + K8 + hot path + serialise)
+    if "--sumcheck-only" in sys.argv:
+        print(json.dumps(out, indent=1))
+        ctx.close()
+        return
+    # (2) Prover.prove end to end from program bytes at a 2^20 trace (VM + compact-trace H2D + K8 + hot path + serialise)
     for nv in (16, 20):
         prog = programs.add_xor_loop(((1 << nv) - 3) // 4)
         tmin, tmed = best(lambda: host.prove(ctx, prog, 0x1000, None, 1 << (nv + 1)), reps=3)
@@ -67,7 +71,14 @@ def main():
         tr.witness_to_device(ctx, d, N)
         tmin3, _ = best(lambda: tr.prove(ctx, d, N, want_bytes="borrow"), reps=5)
         out["prove_trace_resident_2^%d" % nv] = dict(ms_min=tmin3 * 1e3, steps_per_s=tr.num_steps / tmin3)
-        t0 = time.perf_counter(); tr.witness_to_device(ctx, d, N); out["witness_rows_to_device_2^%d_ms" % nv] = (time.perf_counter() - t0) * 1e3
+        t0 = time.perf_counter(); tr.witness_to_device(ctx, d, N); out["witness_steps_to_device_pageable_2^%d_ms" % nv] = (time.perf_counter() - t0) * 1e3
+        tr.pin(ctx)
+        tr.witness_to_device(ctx, d, N)
+        t0 = time.perf_counter(); tr.witness_to_device(ctx, d, N); out["witness_steps_to_device_pinned_2^%d_ms" % nv] = (time.perf_counter() - t0) * 1e3
+        rows = tr.rows()
+        ctx.witness_from_rows(rows, nv, d, N)
+        t0 = time.perf_counter(); ctx.witness_from_rows(rows, nv, d, N); out["witness_rows_to_device_2^%d_ms" % nv] = (time.perf_counter() - t0) * 1e3
+        del rows
         ctx.dev_free(d)
     print(json.dumps(out, indent=1))
     ctx.close()

@@ -1,21 +1,32 @@
+# Round-2 profile run: everything profiles/r02_* comes from (one gpurun call:  gpurun --timeout 1200 -- 'bash tools/regen_profiles.sh').
+# Under rocprofv3 the program itself follows `--` and bench.py gets --no-cpu-baseline (its CPU baseline is a child process,
+# and a process the profiler has attached to must not start other programs).  PMC counters in passes of their own.
 set -e
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
-rm -rf gpurun_out/fin_* 
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fin_b1 -- python3 bench.py --steps 5 --warmup 1 --batch 1 --no-cpu-baseline > gpurun_out/fin_b1.log 2>&1
-rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/fin_bdef -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/fin_bdef.log 2>&1
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/fin_pmc_FETCH_SIZE -- python3 bench.py --steps 2 --warmup 1 --batch 1 --no-cpu-baseline > gpurun_out/fin_pmc_FETCH_SIZE.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/fin_pmc_WRITE_SIZE -- python3 bench.py --steps 2 --warmup 1 --batch 1 --no-cpu-baseline > gpurun_out/fin_pmc_WRITE_SIZE.log 2>&1
-python bench.py > gpurun_out/fin_bench.json 2> gpurun_out/fin_bench.err
-python bench.py --batch 1 --no-cpu-baseline > gpurun_out/fin_bench_b1.json 2>> gpurun_out/fin_bench.err
-python bench.py --batch 6 --no-cpu-baseline > gpurun_out/fin_bench_b6.json 2>> gpurun_out/fin_bench.err
-python bench.py --dedup --batch 8 --no-cpu-baseline > gpurun_out/fin_bench_dedup8.json 2>> gpurun_out/fin_bench.err
-python tools/measure_extra.py > gpurun_out/fin_extra.json 2>> gpurun_out/fin_bench.err
-hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc -I include tools/merkle_rate.hip -o /tmp/merkle_rate 2>/dev/null && /tmp/merkle_rate > gpurun_out/fin_merkle_rate.txt
-hipcc --offload-arch=gfx950 -O3 -I zigz_amd/csrc tools/fold_rate.hip -o /tmp/fold_rate 2>/dev/null && /tmp/fold_rate > gpurun_out/fin_fold_rate.txt
-hipcc --offload-arch=gfx950 -O3 tools/valu_rate.hip -o /tmp/valu_rate 2>/dev/null && /tmp/valu_rate > gpurun_out/fin_valu_rate.txt
-hipcc --offload-arch=gfx950 -O3 tools/bank_rate.hip -o /tmp/bank_rate 2>/dev/null && /tmp/bank_rate > gpurun_out/fin_bank_rate.txt
-python3 tools/gen_valu2_rate.py && hipcc --offload-arch=gfx950 -O3 -I tools tools/valu2_rate.hip -o /tmp/valu2_rate 2>/dev/null && /tmp/valu2_rate > gpurun_out/fin_valu2_rate.txt
-python bench.py --batch 8 --no-cpu-baseline > gpurun_out/fin_bench_b8.json 2>> gpurun_out/fin_bench.err
-rm -f gpurun_out/fin_configs.jsonl
-for c in 2 3 4 5; do python tests/run_config.py --config $c --check-cols 1 >> gpurun_out/fin_configs.jsonl 2>> gpurun_out/fin_bench.err; done
-tail -c 600 gpurun_out/fin_bench.json
+rm -rf gpurun_out/p2_*
+K="python3 bench.py --kernels --kernel-iters 10"
+# (1) the per-kernel leg: cold-HBM launches of the MLE and Keccak kernels (K1/K2/K3/K4, K5/K6)
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_kernels -- $K > gpurun_out/p2_kernels.json 2> gpurun_out/p2_kernels.err
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/p2_pmc_FETCH_SIZE -- $K > /dev/null 2> gpurun_out/p2_pmc_fetch.err
+rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d gpurun_out/p2_pmc_WRITE_SIZE -- $K > /dev/null 2> gpurun_out/p2_pmc_write.err
+rocprofv3 --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU2 --kernel-trace --output-format csv -d gpurun_out/p2_pmc_VALU -- $K > /dev/null 2> gpurun_out/p2_pmc_valu.err
+python3 bench.py --kernels --kernel-iters 10 > gpurun_out/p2_kernels_plain.json 2>> gpurun_out/p2_kernels.err
+# (2) whole proofs: one at a time (kernel quality inside a proof) and the default bench workload
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_b1 -- python3 bench.py --steps 5 --warmup 1 --batch 1 --no-cpu-baseline --no-extras > gpurun_out/p2_b1.json 2> gpurun_out/p2_b1.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_bdef -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/p2_bdef.json 2> gpurun_out/p2_bdef.err
+# (3) Lasso and the real sumcheck
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_lasso -- python3 bench.py --lasso > gpurun_out/p2_lasso.json 2> gpurun_out/p2_lasso.err
+rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_sumcheck -- python3 tools/measure_extra.py --sumcheck-only > gpurun_out/p2_sumcheck.json 2> gpurun_out/p2_sumcheck.err
+# (4) bench lines
+python3 bench.py > gpurun_out/p2_bench.json 2> gpurun_out/p2_bench.err
+python3 bench.py --batch 1 --no-cpu-baseline > gpurun_out/p2_bench_b1.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 4 --no-cpu-baseline > gpurun_out/p2_bench_b4.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_b8.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --dense-merkle --no-cpu-baseline > gpurun_out/p2_bench_dense.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --dedup --batch 8 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_dedup8.json 2>> gpurun_out/p2_bench.err
+ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 3 --no-extras > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
+python3 tools/measure_extra.py > gpurun_out/p2_extra.json 2>> gpurun_out/p2_bench.err
+# (5) BASELINE configs 2-5 at full size on one GPU
+rm -f gpurun_out/p2_configs.jsonl
+for c in 2 3 4 5; do python3 tests/run_config.py --config $c --check-cols 1 >> gpurun_out/p2_configs.jsonl 2>> gpurun_out/p2_bench.err; done
+tail -c 400 gpurun_out/p2_bench.json
