@@ -457,8 +457,11 @@ def main():
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                roof["traffic"] = tj.get("hbm_bytes_per_launch")
-                roof["traffic_source"] = tj.get("source", "profiles/keccak_traffic.json") + " (rocprofv3 PMC passes of this command; not re-measured in this run)"
+                roof["traffic"] = tj["hbm_bytes_per_hash"] * perms_leaves / nproofs  # per launch, like `achieved`
+                roof["traffic_algorithmic"] = 36.0 * perms_leaves / nproofs
+                roof["traffic_source"] = (tj.get("source", "profiles/keccak_traffic.json") + ": HBM bytes per hash from the rocprofv3 "
+                                          "FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernels`, times the hashes of one launch here "
+                                          "(not re-measured in this run)")
             except Exception:
                 pass
         if solo:

@@ -69,7 +69,8 @@ def main():
     if "k_keccak_leaves[43x2^20]" in traffic:
         t = traffic["k_keccak_leaves[43x2^20]"]
         json.dump({"kernel": "k_keccak_leaves", "source": "profiles/%s_pmc_fetch_size.csv + %s_pmc_write_size.csv" % (ROUND, ROUND),
-                   "hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"]},
+                   "hbm_bytes_per_launch": t["hbm_bytes_per_launch"], "algorithmic_bytes_per_launch": t["algorithmic_bytes_per_launch"],
+                   "hashes_per_launch": 43 * N, "hbm_bytes_per_hash": t["hbm_bytes_per_launch"] / (43 * N), "algorithmic_bytes_per_hash": 36},
                   open("profiles/keccak_traffic.json", "w"), indent=1)
     valu = {}
     for k in V1:
