@@ -179,8 +179,13 @@ class Trace:
         """ONE proof over dist.get_world_size() GPUs, sharded by column (zigzh_prove_trace_sharded): every rank holds
         the same trace and a resident copy of the 43 columns, commits / opens its own block, and returns the complete
         proof (BorrowedProof; identical on every rank and to the unsharded proof)."""
-        cb = allgather or make_allgather(dist)
+        from .shard import ShmComm
         out, n = u8p(), C.c_size_t()
+        if isinstance(allgather, ShmComm):  # the built-in same-node transport: no torch / RCCL involved
+            _check(lib.zigzh_prove_trace_sharded(self.h, ctx.h, vp(d_cols), stride, allgather.rank, allgather.world,
+                                                 C.cast(allgather.hook, vp), allgather.user, C.byref(out), C.byref(n)))
+            return BorrowedProof(out, n.value)
+        cb = allgather or make_allgather(dist)
         _check(lib.zigzh_prove_trace_sharded(self.h, ctx.h, vp(d_cols), stride, dist.get_rank(), dist.get_world_size(),
                                              C.cast(cb, vp), None, C.byref(out), C.byref(n)))
         return BorrowedProof(out, n.value)
