@@ -191,7 +191,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
         fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_dedup_count, 64)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
-        fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32, hipHostMallocDefault)))
+        fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
@@ -1071,6 +1071,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
     unsigned l_start = 0;
+    ctx->stats.small_domain_columns = 0;
     if (record) ctx->kev_n = 0;
     // timing mode: every dense Keccak launch carries its own begin / end timestamps, by class
     KTime kt_store;
@@ -1109,7 +1110,6 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             use_sd = H.n != 0;
         }
         ctx->stats.merkle_blocks = 0;
-        ctx->stats.small_domain_columns = 0;
         if (use_sd) {
             if (!ctx->d_sd_tables) {
                 HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
@@ -1320,6 +1320,13 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
                             ncols, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
+        // the two diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later
+        unsigned long long *h_cnt = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
+        h_cnt[0] = h_cnt[1] = 0;
+        if (ctx->stats.merkle_blocks)
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_dedup_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->stats.small_domain_columns)
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
         return ZIGZ_OK;
     };
@@ -1373,20 +1380,9 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
     HIPCHK(ctx, hipEventSynchronize(job->built));
     memcpy(roots, ctx->h_roots, job->ncols * 32);
-    if (ctx->stats.merkle_blocks) {
-        unsigned long long cnt = 0;
-        HIPCHK(ctx, hipMemcpy(&cnt, ctx->d_dedup_count, 8, hipMemcpyDeviceToHost));
-        ctx->stats.merkle_uniform_blocks = cnt;
-    } else {
-        ctx->stats.merkle_uniform_blocks = 0;
-    }
-    if (ctx->stats.small_domain_columns) {
-        unsigned long long fb = 0;
-        HIPCHK(ctx, hipMemcpy(&fb, ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost));
-        ctx->stats.small_domain_fallback_waves = fb;
-    } else {
-        ctx->stats.small_domain_fallback_waves = 0;
-    }
+    const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
+    ctx->stats.merkle_uniform_blocks = ctx->stats.merkle_blocks ? h_cnt[0] : 0;
+    ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
     if (ctx->timing) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));
