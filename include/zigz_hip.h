@@ -196,7 +196,7 @@ typedef struct zigz_trace_step {
     uint64_t mem_value; /* memory_access.value   (0 when none) */
     int64_t imm;        /* instruction.imm */
     uint8_t opcode, rd, rs1, rs2, funct3, funct7; /* @intFromEnum(opcode) and the raw fields, witness.zig:164-169 */
-    uint8_t wr_reg;      /* 1..31: the register this step wrote; 0: none */
+    uint8_t wr_reg;      /* 1..31: the register this step wrote; 0 (or any value >= 32): none */
     uint8_t mem_is_read; /* 1 = load, 0 = store or no access */
 } zigz_trace_step;
 /* initial_regs: the 32 register values before the first step (NULL = all zero); x0 is forced to 0.  h_steps may be

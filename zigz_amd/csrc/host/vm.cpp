@@ -268,7 +268,7 @@ std::vector<uint64_t> ExecutionTrace::expandRows() const {
     regs[0] = 0;
     for (size_t i = 0; i < ns; i++) {
         const zigz_trace_step &st = steps[i];
-        if (st.wr_reg) regs[st.wr_reg & 31] = st.rd_value;
+        if (st.wr_reg && st.wr_reg < 32) regs[st.wr_reg] = st.rd_value;  // like the device: 0 and values >= 32 mean no write
         uint64_t *row = rows.data() + i * ROW_WORDS;
         row[0] = st.pc;
         memcpy(row + 1, regs, sizeof(regs));  // regs_after

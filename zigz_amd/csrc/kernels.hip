@@ -490,35 +490,53 @@ __global__ __launch_bounds__(TPB) void k_steps_summary(const TraceStep *__restri
     if (lane == 0) sum_has[chunk] = (uint32_t)has;
 }
 
-// one workgroup per register: every thread fill-forwards a contiguous range of chunks, thread 0 chains the 256 ranges
+// One workgroup per register.  The chunks are taken in rounds of TPB consecutive chunks (coalesced reads and writes);
+// inside a round an inclusive "last defined value" scan runs over the 256 lanes (shuffles inside a wave, LDS across the
+// four waves), and the value after the round is carried into the next.  carry[r][chunk] = value of r BEFORE the chunk.
 __global__ __launch_bounds__(TPB) void k_steps_scan(const uint32_t *__restrict__ sum_val, const uint32_t *__restrict__ sum_has,
                                                     size_t nchunks, Regs32 init, uint32_t *__restrict__ carry) {
-    __shared__ uint32_t last_val[TPB];
-    __shared__ uint32_t last_has[TPB];
+    __shared__ uint32_t w_val[TPB / 64], w_has[TPB / 64];
+    __shared__ uint32_t round_carry;
     const unsigned r = blockIdx.x + 1;
-    const size_t per = (nchunks + TPB - 1) / TPB;
-    const size_t lo = (size_t)threadIdx.x * per, hi = lo + per < nchunks ? lo + per : nchunks;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const uint32_t *sv = sum_val + (size_t)r * nchunks;
-    uint32_t v = 0, h = 0;
-    for (size_t c = lo; c < hi; c++)
-        if ((sum_has[c] >> r) & 1u) { v = sv[c]; h = 1; }
-    last_val[threadIdx.x] = v;
-    last_has[threadIdx.x] = h;
-    __syncthreads();
-    if (threadIdx.x == 0) {  // exclusive fill-forward over the 256 ranges, starting from the initial register value
-        uint32_t cur = init.v[r];
-        for (int t = 0; t < TPB; t++) {
-            const uint32_t nv = last_has[t] ? last_val[t] : cur;
-            last_val[t] = cur;
-            cur = nv;
-        }
-    }
-    __syncthreads();
-    uint32_t cur = last_val[threadIdx.x];
     uint32_t *cr = carry + (size_t)r * nchunks;
-    for (size_t c = lo; c < hi; c++) {
-        cr[c] = cur;
-        if ((sum_has[c] >> r) & 1u) cur = sv[c];
+    if (threadIdx.x == 0) round_carry = init.v[r];
+    __syncthreads();
+    for (size_t base = 0; base < nchunks; base += TPB) {
+        const size_t c = base + threadIdx.x;
+        const bool live = c < nchunks;
+        uint32_t h = live ? (sum_has[c] >> r) & 1u : 0u;
+        uint32_t v = h ? sv[c] : 0u;
+        const uint32_t own_h = h, own_v = v;
+        // inclusive scan inside the wave: (h, v) <- the nearest defined entry at or before this lane
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const uint32_t ph = __shfl_up(h, off, 64), pv = __shfl_up(v, off, 64);
+            if (lane >= (unsigned)off && !h) { h = ph; v = pv; }
+        }
+        if (lane == 63) { w_has[wave] = h; w_val[wave] = v; }
+        __syncthreads();
+        // value before this lane's chunk: the previous lane's inclusive result, else the previous waves', else the carry
+        uint32_t ph = __shfl_up(h, 1, 64), pv = __shfl_up(v, 1, 64);
+        if (lane == 0) { ph = 0; pv = 0; }
+        uint32_t before = round_carry;
+        bool found = false;
+        if (ph) { before = pv; found = true; }
+        for (int w = (int)wave - 1; w >= 0 && !found; w--)
+            if (w_has[w]) { before = w_val[w]; found = true; }
+        if (live) cr[c] = before;
+        __syncthreads();
+        if (threadIdx.x == TPB - 1) {  // the value after this round
+            uint32_t nv = round_carry;
+            bool f = false;
+            if (h) { nv = v; f = true; }
+            for (int w = (int)wave - 1; w >= 0 && !f; w--)
+                if (w_has[w]) { nv = w_val[w]; f = true; }
+            round_carry = nv;
+        }
+        (void)own_h; (void)own_v;
+        __syncthreads();
     }
 }
 
