@@ -26,7 +26,8 @@ def assembly(extra=()):
     with tempfile.TemporaryDirectory() as d:
         s = os.path.join(d, "kernels.s")
         subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}",
-                               "--cuda-device-only", "-S", "-o", s, os.path.join(CSRC, "kernels.hip"), *extra],
+                               "--cuda-device-only", "-S", "-o", s, os.path.join(CSRC, "kernels.hip"), *extra,
+                               *os.environ.get("ZIGZ_EXTRA_HIPCC_FLAGS", "").split()],
                               stderr=subprocess.DEVNULL)
         return open(s).read()
 
