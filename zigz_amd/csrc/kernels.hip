@@ -666,44 +666,6 @@ __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree
     const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#ifdef ZK_LEVEL_PREFETCH
-    // software pipeline: the children of iteration h + 1 are requested before the hash of iteration h (16 VGPRs), so the
-    // ~2 us of load latency of a wave's 4 KiB lie underneath the ~10 us permutation instead of in front of it
-    uint4 pre[4];
-    auto fetch = [&](int h) {
-        const size_t first = ((size_t)blockIdx.x * H + h) * TPB + (size_t)wave * 64;
-        if (h < H && first < n_out) {
-            const uint4 *g = reinterpret_cast<const uint4 *>(t + (in_off + 2 * first) * 32);
-#pragma unroll
-            for (int k = 0; k < 4; k++) pre[k] = g[lane + 64 * k];
-        }
-    };
-    fetch(0);
-#pragma unroll 1
-    for (int h = 0; h < H; h++) {
-        const size_t first = ((size_t)blockIdx.x * H + h) * TPB + (size_t)wave * 64;  // first output node of this wave
-        const bool active = first < n_out;                                          // wave-uniform
-        if (active) {
-#pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const unsigned c = lane + 64 * k;
-                stage[wave][(c >> 2) * 5 + (c & 3)] = pre[k];
-            }
-        }
-        __builtin_amdgcn_wave_barrier();  // stage[wave] is private to the wave; LDS is in order within a wave
-        if (active) {
-            const uint4 *r = &stage[wave][lane * 5];
-            const uint4 a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3];
-            fetch(h + 1);
-            Digest l{{((uint64_t)a0.y << 32) | a0.x, ((uint64_t)a0.w << 32) | a0.z, ((uint64_t)a1.y << 32) | a1.x,
-                      ((uint64_t)a1.w << 32) | a1.z}};
-            Digest rr{{((uint64_t)b0.y << 32) | b0.x, ((uint64_t)b0.w << 32) | b0.z, ((uint64_t)b1.y << 32) | b1.x,
-                       ((uint64_t)b1.w << 32) | b1.z}};
-            store_digest(t, out_off + first + lane, sha3_node(l, rr));
-        }
-        __builtin_amdgcn_wave_barrier();
-    }
-#else
 #pragma unroll 1
     for (int h = 0; h < H; h++) {
         const size_t first = ((size_t)blockIdx.x * H + h) * TPB + (size_t)wave * 64;  // first output node of this wave
@@ -725,13 +687,12 @@ __global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree
                       ((uint64_t)a1.w << 32) | a1.z}};
             Digest rr{{((uint64_t)b0.y << 32) | b0.x, ((uint64_t)b0.w << 32) | b0.z, ((uint64_t)b1.y << 32) | b1.x,
                        ((uint64_t)b1.w << 32) | b1.z}};
-            // (staging the 32-byte digest stores through LDS as well was measured slower: the extra barriers cost
-            // more than the half-coalesced stores)
+            // (measured and not kept: digest stores through wave-private LDS, 1 805 vs 1 797 us; wave barriers instead of
+            // the workgroup barriers, same; requesting the next iteration's children before the hash, 1 975 vs 1 853 us)
             store_digest(t, out_off + first + lane, sha3_node(l, rr));
         }
         __syncthreads();
     }
-#endif
 }
 
 // Finishes a tree from a level of at most 2*TPB nodes up to the root in ONE launch (one workgroup
