@@ -96,11 +96,19 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) 
 #define ZK_X3(a, b, c) (ZK_ANYCONST(a, b, c) ? ((a) ^ (b) ^ (c)) : __builtin_amdgcn_bitop3_b32((a), (b), (c), 0x96))
 #define ZK_CHI(a, b, c) (ZK_ANYCONST(a, b, c) ? ((a) ^ (~(b) & (c))) : __builtin_amdgcn_bitop3_b32((a), (b), (c), 0xD2))
 #define ZK_ROT32(x, k) __builtin_amdgcn_alignbit((x), (x), 32 - (k))
+#define ZK_STR2(x) #x
+#define ZK_STR(x) ZK_STR2(x)
+#ifndef ZK_SLEEP_A
+#define ZK_SLEEP_A 2  // s_sleep argument after the 5 rotates of theta (64 clocks each)
+#endif
+#ifndef ZK_SLEEP_B
+#define ZK_SLEEP_B 2  // ... after the 47 rotates of rho
+#endif
 #ifndef ZK_REARM_A_ASM
-#define ZK_REARM_A_ASM "s_sleep 2"  // after the 5 rotates of theta
+#define ZK_REARM_A_ASM "s_sleep " ZK_STR(ZK_SLEEP_A)
 #endif
 #ifndef ZK_REARM_B_ASM
-#define ZK_REARM_B_ASM "s_sleep 2"  // after the 47 rotates of rho
+#define ZK_REARM_B_ASM "s_sleep " ZK_STR(ZK_SLEEP_B)
 #endif
 #ifndef ZK_KECCAK_PHASED
 #define ZK_KECCAK_PHASED 1  // 0 = leave the instruction order to the compiler (A/B experiments)
