@@ -99,10 +99,11 @@ __device__ __forceinline__ uint64_t rotl64(uint64_t x, int n) { return (x << n) 
 #define ZK_STR2(x) #x
 #define ZK_STR(x) ZK_STR2(x)
 #ifndef ZK_SLEEP_A
-#define ZK_SLEEP_A 2  // s_sleep argument after the 5 rotates of theta (64 clocks each)
+#define ZK_SLEEP_A 4  // s_sleep argument after the 5 rotates of theta (64 clocks each)
 #endif
 #ifndef ZK_SLEEP_B
-#define ZK_SLEEP_B 2  // ... after the 47 rotates of rho
+#define ZK_SLEEP_B 4  // ... after the 47 rotates of rho (round 2 sweep on two boxes: 2 -> 4 is 2-2.5 % faster now that
+                      // the leaf kernel holds 7 waves per SIMD; 1 is 6 % slower, 8 is 1 % slower, 12 is 3 % slower)
 #endif
 #ifndef ZK_REARM_A_ASM
 #define ZK_REARM_A_ASM "s_sleep " ZK_STR(ZK_SLEEP_A)

@@ -640,7 +640,10 @@ __device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) 
 #define ZK_HPT 4
 #endif
 constexpr int HPT = ZK_HPT;
-__global__ __launch_bounds__(TPB) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
+#ifndef ZK_LEAVES_MIN_WAVES
+#define ZK_LEAVES_MIN_WAVES 1
+#endif
+__global__ __launch_bounds__(TPB, ZK_LEAVES_MIN_WAVES) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                        size_t tree_stride_nodes, ColMap cmap) {
     const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
