@@ -662,8 +662,11 @@ __global__ __launch_bounds__(TPB, ZK_LEAVES_MIN_WAVES) void k_keccak_leaves(cons
 // coalesced 16-byte loads (1 KiB per wave instruction) and handed to their lanes through LDS (rows padded to 80 B so
 // the per-lane 4 x ds_read_b128 are bank-conflict free), instead of four 64-byte-strided loads per lane.
 // Requires n_out % 64 == 0 (levels handled here have >= 512 nodes).
+#ifndef ZK_LEVEL_MIN_WAVES
+#define ZK_LEVEL_MIN_WAVES 1
+#endif
 template <int H>
-__global__ __launch_bounds__(TPB) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
+__global__ __launch_bounds__(TPB, ZK_LEVEL_MIN_WAVES) void k_keccak_level(uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                       size_t in_off, size_t out_off, size_t n_out, ColMap cmap) {
     __shared__ uint4 stage[TPB / 64][64 * 5];
     const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
