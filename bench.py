@@ -5,7 +5,7 @@
                     [--no-cpu-baseline] [--kernels]
 
 A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces
-(default 6 per GPU; every trace gets its own complete proof) whose 43 witness columns each are already
+(default 8 per GPU; every trace gets its own complete proof) whose 43 witness columns each are already
 resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of Prover.prove
 (public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v
 challenges, OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and
@@ -216,9 +216,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=6, help="independent traces proven concurrently per GPU per step "
-                    "(one proof alone is bound by its sequential host transcript, ~28 ms on one core against ~6.5 ms of GPU "
-                    "work: 4 lanes are host-bound at ~140 M steps/s, 5-6 saturate the GPU, 8 add ~3 %%)")
+    ap.add_argument("--batch", type=int, default=8, help="independent traces proven concurrently per GPU per step "
+                    "(one proof alone is bound by its sequential host transcript, ~28 ms on one core against ~6 ms of GPU "
+                    "work: 4 lanes are host-bound at ~137 M steps/s, 6 reach 160-163 M, 8 keep the GPU saturated: 165-180 M)")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "

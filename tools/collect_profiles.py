@@ -89,7 +89,7 @@ def main():
         shutil.copy(newest("gpurun_out/p2_%s/*/*kernel_stats.csv" % tag), "profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))
     for src_, dst in (("p2_kernels.json", "kernels.json"), ("p2_kernels_plain.json", "kernels_unprofiled.json"),
                       ("p2_bench.json", "final_bench.json"), ("p2_bench_b1.json", "final_bench_b1.json"),
-                      ("p2_bench_b4.json", "final_bench_b4.json"), ("p2_bench_b8.json", "final_bench_b8.json"),
+                      ("p2_bench_b4.json", "final_bench_b4.json"), ("p2_bench_b6.json", "final_bench_b6.json"),
                       ("p2_bench_dense.json", "final_bench_dense_merkle.json"), ("p2_bench_dedup8.json", "final_bench_dedup_b8.json"),
                       ("p2_bench_gpus2_rehearsal.json", "bench_gpus2_rehearsal.json"), ("p2_lasso.json", "lasso.json"),
                       ("p2_sumcheck.json", "sumcheck.json"), ("p2_extra.json", "extra.json"), ("p2_configs.jsonl", "configs.jsonl")):
@@ -99,7 +99,7 @@ def main():
         print(tag)
         for r in list(csv.DictReader(open("profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))))[:8]:
             print("  %-60s calls=%5s avg_us=%10.2f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, r.get("Percentage")))
-    for name in ("final_bench", "final_bench_b1", "final_bench_b4", "final_bench_b8", "final_bench_dense_merkle"):
+    for name in ("final_bench", "final_bench_b1", "final_bench_b4", "final_bench_b6", "final_bench_dense_merkle"):
         pth = "profiles/%s_%s.json" % (ROUND, name)
         if not os.path.exists(pth):
             continue

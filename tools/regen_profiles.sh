@@ -21,7 +21,7 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_sumcheck -
 python3 bench.py > gpurun_out/p2_bench.json 2> gpurun_out/p2_bench.err
 python3 bench.py --batch 1 --no-cpu-baseline > gpurun_out/p2_bench_b1.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --batch 4 --no-cpu-baseline > gpurun_out/p2_bench_b4.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_b8.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 6 --no-cpu-baseline > gpurun_out/p2_bench_b6.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --dense-merkle --no-cpu-baseline > gpurun_out/p2_bench_dense.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --dedup --batch 8 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_dedup8.json 2>> gpurun_out/p2_bench.err
 ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 3 --no-extras > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
