@@ -24,7 +24,7 @@ python3 bench.py --batch 4 --no-cpu-baseline > gpurun_out/p2_bench_b4.json 2>> g
 python3 bench.py --batch 6 --no-cpu-baseline > gpurun_out/p2_bench_b6.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --dense-merkle --no-cpu-baseline > gpurun_out/p2_bench_dense.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --dedup --batch 8 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_dedup8.json 2>> gpurun_out/p2_bench.err
-ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 3 --no-extras > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
+ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 3 > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
 python3 tools/measure_extra.py > gpurun_out/p2_extra.json 2>> gpurun_out/p2_bench.err
 # (5) BASELINE configs 2-5 at full size on one GPU
 rm -f gpurun_out/p2_configs.jsonl
