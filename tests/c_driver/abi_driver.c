@@ -6,10 +6,7 @@
  *   abi_driver gpu    -- the reference's own small known answers through the GPU path:
  *                        [1,2,3,4] sum = 10, roundPolynomial = [3,4], partialEval(0) = [1,2]
  *                        (src/poly/multilinear.zig:436-506), the derived sumcheck vector of SURVEY s8c,
- *                        Merkle commit / open of 5 values (pad to 8, height 3; merkle_tree.zig:425-571),
- *                        the witness KATs of witness.zig:384-464 from compact trace records (pc = 0x1000, x10 = 42;
- *                        store -> is_read 0, load -> 1), the same sumcheck through the sharded entry with the
- *                        shared-memory hook (world 1)
+ *                        Merkle commit / open of 5 values (pad to 8, height 3; merkle_tree.zig:425-571)
  * Exit code 0 = every check passed; each failure prints a line.
  */
 #include <stdio.h>
@@ -136,54 +133,6 @@ static int gpu_checks(void) {
             CHECK(st == ZIGZ_ERR_INDEX_OUT_OF_BOUNDS, "open(8) -> %s", zigz_status_name(st));
             zigz_merkle_destroy(ctx, tree);
         }
-    }
-    {
-        /* witness.zig:384-413 "generate from simple trace": ADDI x10, x0, 42 at 0x1000, one step, as ONE compact record;
-         * witness.zig:431-464 "memory access encoding": ADDI / SW / LW -> is_read 0 for the store, 1 for the load.
-         * 4 steps together (nv = 2): columns come back through the packed-u32 download. */
-        zigz_trace_step steps[4];
-        void *d_cols = NULL;
-        uint64_t col[4];
-        memset(steps, 0, sizeof(steps));
-        steps[0].pc = 0x1000; steps[0].opcode = 0x13; steps[0].rd = 10; steps[0].imm = 42; steps[0].wr_reg = 10; steps[0].rd_value = 42;
-        steps[1].pc = 0x1004; steps[1].opcode = 0x13; steps[1].rd = 11; steps[1].imm = 100; steps[1].wr_reg = 11; steps[1].rd_value = 100;
-        steps[2].pc = 0x1008; steps[2].opcode = 0x23; steps[2].funct3 = 2; steps[2].rs2 = 11; steps[2].mem_value = 100; /* SW: store */
-        steps[3].pc = 0x100c; steps[3].opcode = 0x03; steps[3].funct3 = 2; steps[3].rd = 12; steps[3].wr_reg = 12; steps[3].rd_value = 100;
-        steps[3].mem_value = 100; steps[3].mem_is_read = 1;                                                          /* LW: load */
-        st = zigz_dev_alloc(ctx, 43 * 4 * sizeof(uint32_t), &d_cols);
-        CHECK(st == ZIGZ_OK, "dev_alloc: %s", zigz_status_name(st));
-        st = zigz_dev_witness_from_steps(ctx, steps, 4, 2, NULL, (uint32_t *)d_cols, 4);
-        CHECK(st == ZIGZ_OK, "witness_from_steps: %s", zigz_status_name(st));
-        st = zigz_dev_download_u64(ctx, (const uint32_t *)d_cols + 0 * 4, 4, col); /* pc */
-        CHECK(st == ZIGZ_OK && col[0] == 0x1000 && col[3] == 0x100c, "pc column %llu", (unsigned long long)col[0]);
-        st = zigz_dev_download_u64(ctx, (const uint32_t *)d_cols + 11 * 4, 4, col); /* x10 = column 1 + 10 */
-        CHECK(st == ZIGZ_OK && col[0] == 42 && col[1] == 42 && col[3] == 42, "x10 column %llu", (unsigned long long)col[0]);
-        st = zigz_dev_download_u64(ctx, (const uint32_t *)d_cols + 12 * 4, 4, col); /* x11 written at step 1 */
-        CHECK(st == ZIGZ_OK && col[0] == 0 && col[1] == 100 && col[3] == 100, "x11 column");
-        st = zigz_dev_download_u64(ctx, (const uint32_t *)d_cols + 42 * 4, 4, col); /* mem.is_read */
-        CHECK(st == ZIGZ_OK && col[2] == 0 && col[3] == 1, "is_read column [%llu,%llu]", (unsigned long long)col[2],
-              (unsigned long long)col[3]);
-        st = zigz_dev_witness_from_steps(ctx, steps, 0, 0, NULL, (uint32_t *)d_cols, 4); /* error.EmptyTrace, prover.zig:147-149 */
-        CHECK(st == ZIGZ_ERR_EMPTY_TRACE, "0 steps -> %s", zigz_status_name(st));
-        zigz_dev_free(ctx, d_cols);
-    }
-    {
-        /* the derived sumcheck vector once more through the row-sharded entry (world 1, shared-memory hook bound) */
-        zigz_shm_comm *comm = NULL;
-        void *d_t = NULL;
-        uint64_t r2[4], p2[2], fe2 = 0;
-        st = zigz_shm_comm_create("zigz_abi_driver", 0, 1, 4096, 5.0, &comm);
-        CHECK(st == ZIGZ_OK && comm != NULL, "shm_comm_create: %s", zigz_status_name(st));
-        st = zigz_dev_alloc(ctx, 16, &d_t);
-        CHECK(st == ZIGZ_OK, "dev_alloc");
-        st = zigz_dev_upload_u64(ctx, evals, 4, (uint32_t *)d_t);
-        CHECK(st == ZIGZ_OK, "upload");
-        st = zigz_dev_sumcheck_prove_sharded(ctx, (const uint32_t *)d_t, 4, 0, 1, zigz_shm_allgather, comm, r2, p2, &fe2);
-        CHECK(st == ZIGZ_OK && r2[0] == 3 && r2[1] == 4 && r2[2] == 42686404ull && r2[3] == 1 && p2[0] == 1027976162ull &&
-                  p2[1] == 792614669ull && fe2 == 835301073ull, "sharded sumcheck (world 1): %s final %llu", zigz_status_name(st),
-              (unsigned long long)fe2);
-        zigz_dev_free(ctx, d_t);
-        zigz_shm_comm_destroy(comm);
     }
     zigz_ctx_destroy(ctx);
     return failures;
