@@ -39,7 +39,6 @@ struct zigz_ctx {
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
     bool merkle_dedup;        // run-aware Merkle build (uniform 256-leaf blocks are chained, not hashed densely)
-    bool unfused_levels;      // one launch per small level (round 1's form) instead of four levels per launch (A/B, tests)
     unsigned long long *d_dedup_count;
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
@@ -278,7 +277,6 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "merkle_dedup") == 0) { ctx->merkle_dedup = value != 0; return ZIGZ_OK; }
-    if (strcmp(name, "unfused_levels") == 0) { ctx->unfused_levels = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1133,21 +1131,14 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
         }
     }
-    for (unsigned l = l_start; l < height;) {
-        const size_t n_in = npad >> l, n_out = n_in / 2;
+    for (unsigned l = l_start; l < height; l++) {
+        const size_t n_out = npad >> (l + 1);
         if (n_out <= 256) {
             launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
             break;
         }
-        if (!keccak_level_is_wide(n_out, ncols) && n_in >= 1024 && !ctx->unfused_levels) {
-            // a level too small to fill the chip on its own: four levels per launch (15/16 of n_in hashes)
-            launch_keccak_subtree4(d_tree, stride, npad, l, ncols, ctx->stream, stamp(2, (uint64_t)ncols * (n_in - n_in / 16)));
-            l += 4;
-            continue;
-        }
         launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols,
                             ctx->stream, stamp(keccak_level_is_wide(n_out, ncols) ? 1 : 2, (uint64_t)ncols * n_out));
-        l++;
     }
     HIPCHK(ctx, hipGetLastError());
     return ZIGZ_OK;

@@ -701,78 +701,6 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_MIN_WAVES) void k_keccak_level(uint8_
     }
 }
 
-// Four levels in one launch, for the levels too small to fill the chip with one launch each.  A workgroup takes 1024
-// consecutive nodes of level l of one column (32 KiB) and writes the 512 + 256 + 128 + 64 nodes above them; every wave
-// hash has 64 live lanes (15 wave-hashes for 960 hashes).  Digests are handed upward through LDS in rows of one sibling
-// pair (80-byte pitch: a lane's 64 B of children read conflict-free); wave w produces exactly the pairs it consumes at the
-// second level, so only the last two levels need workgroup barriers.
-__device__ __forceinline__ void lds_put_digest(uint4 *rows, size_t i, const Digest &d) {
-    uint4 *r = rows + (i >> 1) * 5 + (i & 1) * 2;
-    r[0] = make_uint4((uint32_t)d.w[0], (uint32_t)(d.w[0] >> 32), (uint32_t)d.w[1], (uint32_t)(d.w[1] >> 32));
-    r[1] = make_uint4((uint32_t)d.w[2], (uint32_t)(d.w[2] >> 32), (uint32_t)d.w[3], (uint32_t)(d.w[3] >> 32));
-}
-__device__ __forceinline__ Digest lds_hash_pair(const uint4 *rows, size_t parent) {
-    const uint4 *r = rows + parent * 5;
-    const uint4 a0 = r[0], a1 = r[1], b0 = r[2], b1 = r[3];
-    const Digest l{{((uint64_t)a0.y << 32) | a0.x, ((uint64_t)a0.w << 32) | a0.z, ((uint64_t)a1.y << 32) | a1.x,
-                    ((uint64_t)a1.w << 32) | a1.z}};
-    const Digest rr{{((uint64_t)b0.y << 32) | b0.x, ((uint64_t)b0.w << 32) | b0.z, ((uint64_t)b1.y << 32) | b1.x,
-                     ((uint64_t)b1.w << 32) | b1.z}};
-    return sha3_node(l, rr);
-}
-__global__ __launch_bounds__(TPB) void k_keccak_subtree4(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                                         unsigned l) {
-    __shared__ uint4 stage[TPB / 64][64 * 5];
-    __shared__ uint4 lv1[256 * 5], lv2[128 * 5], lv3[64 * 5];
-    const size_t col = blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t in0 = (size_t)blockIdx.x * 1024;  // first input node (level l) of this workgroup
-    const size_t off0 = 2 * npad - 2 * (npad >> l), off1 = 2 * npad - 2 * (npad >> (l + 1)), off2 = 2 * npad - 2 * (npad >> (l + 2));
-    const size_t off3 = 2 * npad - 2 * (npad >> (l + 3)), off4 = 2 * npad - 2 * (npad >> (l + 4));
-    // level l + 1: 512 outputs, 128 per wave in two iterations; children through the wave's staging rows
-#pragma unroll 1
-    for (int it = 0; it < 2; it++) {
-        const size_t o = (size_t)wave * 128 + (size_t)it * 64;  // first local output of this wave iteration
-        const uint4 *g = reinterpret_cast<const uint4 *>(t + (off0 + in0 + 2 * o) * 32);
-#pragma unroll
-        for (int k = 0; k < 4; k++) {
-            const unsigned c = lane + 64 * k;
-            stage[wave][(c >> 2) * 5 + (c & 3)] = g[c];
-        }
-        __builtin_amdgcn_wave_barrier();
-        const Digest d = lds_hash_pair(stage[wave], lane);
-        __builtin_amdgcn_wave_barrier();
-        store_digest(t, off1 + in0 / 2 + o + lane, d);
-        lds_put_digest(lv1, o + lane, d);
-    }
-    __builtin_amdgcn_wave_barrier();
-    {   // level l + 2: 256 outputs, 64 per wave, from the pairs this same wave has just written
-        const size_t o = (size_t)wave * 64 + lane;
-        const Digest d = lds_hash_pair(lv1, o);
-        store_digest(t, off2 + in0 / 4 + o, d);
-        lds_put_digest(lv2, o, d);
-    }
-    __syncthreads();
-    if (wave < 2) {  // level l + 3: 128 outputs
-        const size_t o = (size_t)wave * 64 + lane;
-        const Digest d = lds_hash_pair(lv2, o);
-        store_digest(t, off3 + in0 / 8 + o, d);
-        lds_put_digest(lv3, o, d);
-    }
-    __syncthreads();
-    if (wave == 0) {  // level l + 4: 64 outputs
-        const Digest d = lds_hash_pair(lv3, lane);
-        store_digest(t, off4 + in0 / 16 + lane, d);
-    }
-}
-void launch_keccak_subtree4(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned in_level, size_t ncols,
-                            hipStream_t s, const KTime *kt) {
-    const size_t n_in = npad >> in_level;  // a multiple of 1024
-    dim3 grid((unsigned)(n_in / 1024), (unsigned)ncols);
-    ZK_LAUNCH(kt, k_keccak_subtree4, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, in_level);
-}
-
 // Finishes a tree from a level of at most 2*TPB nodes up to the root in ONE launch (one workgroup
 // per column; levels hand over through global memory + workgroup barrier on the same CU).
 __global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,

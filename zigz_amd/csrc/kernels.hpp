@@ -140,9 +140,6 @@ void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n
                              unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
-// K6, four levels per launch: from the nodes of level `in_level` (a multiple of 1024 per column) to level in_level + 4
-void launch_keccak_subtree4(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned in_level, size_t ncols,
-                            hipStream_t s, const KTime *kt = nullptr);
 // K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
                        size_t ncols, hipStream_t s);
