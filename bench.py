@@ -490,9 +490,8 @@ def main():
                 tj = json.load(open(tpath))
                 roof["traffic"] = tj["hbm_bytes_per_hash"] * perms_leaves / nproofs  # per launch, like `achieved`
                 roof["traffic_algorithmic"] = 36.0 * perms_leaves / nproofs
-                roof["traffic_source"] = (tj.get("source", "profiles/keccak_traffic.json") + ": HBM bytes per hash from the rocprofv3 "
-                                          "FETCH_SIZE / WRITE_SIZE passes of `bench.py --kernels`, times the hashes of one launch here "
-                                          "(not re-measured in this run)")
+                roof["traffic_source"] = ("profiles/keccak_traffic.json: HBM bytes per hash from the rocprofv3 FETCH_SIZE / WRITE_SIZE "
+                                          "passes of `bench.py --kernels` x the hashes of one launch (not re-measured in this run)")
             except Exception:
                 pass
         if solo:
@@ -523,10 +522,9 @@ def main():
         if kl:  # the kernel itself: back-to-back launches on 43 x 2^nv leaves in this process, kernel timestamps
             roof.update({"achieved": kl["achieved_Tinstr_s"], "frac": kl["frac"], "avg_launch_us": kl["avg_us"],
                          "gperm_per_s": kl["gperm_per_s"], "hbm_frac": kl["hbm_frac"], "launches": kl["launches"],
-                         "measured": "kernel timestamps of %d k_keccak_leaves launches over 43 x 2^%d leaves (the shape of one "
-                                     "proof's build), each behind a 1 GiB cache-flush sweep, in this process right after the timed "
-                                     "region; `rocprofv3 --kernel-trace --stats -- python3 bench.py --kernels` shows the same "
-                                     "launches (profiles/r02_kernels_kernel_stats.csv)" % (kl["launches"], nv)})
+                         "measured": "kernel timestamps of %d back-to-back k_keccak_leaves launches over 43 x 2^%d leaves in this "
+                                     "process after the timed region (the launches of `bench.py --kernels`; "
+                                     "profiles/r02_kernels_kernel_stats.csv)" % (kl["launches"], nv)})
         elif solo:
             roof.update({"achieved": roof["in_proof_achieved"], "frac": roof["in_proof_frac"], "measured": roof["in_proof_note"]})
         else:
@@ -593,8 +591,9 @@ def main():
             "small_domain_fallback_waves": acc["small_domain_fallback_waves"],
             "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
             "gpu_busy_keccak_gperm_per_s": (acc["keccak_permutations"] / 1e9) / dt},
-            "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode(),
-            "cold_hbm_launches": kern}
+            "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode()}
+        # (the per-launch details of the kernel leg are what `bench.py --kernels` prints; the fractions are flat keys of
+        # `roofline` above)
         if cpu is not None:
             out["cpu_baseline"] = cpu
         print(json.dumps(out), flush=True)
