@@ -464,10 +464,11 @@ static zigz_status timed_end(zigz_ctx *ctx, int ev, double *us_out) {
 
 // launch_bind with a private HIP event pair around every vector-path launch (timing mode only)
 static zigz_status bind_launch(zigz_ctx *ctx, const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride,
-                               size_t half, size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums) {
+                               size_t half, size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums,
+                               const SumsLayout *lay = nullptr) {
     const bool rec = ctx->timing && ctx->pool_used < 64 && bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride, d_in, d_out);
     if (rec) HIPCHK(ctx, hipEventRecord(ctx->pool[2 * ctx->pool_used], ctx->stream));
-    launch_bind(d_in, in_stride, d_out, out_stride, half, ncols, r_m, d_r_m, d_sums, ctx->stream);
+    launch_bind(d_in, in_stride, d_out, out_stride, half, ncols, r_m, d_r_m, d_sums, ctx->stream, nullptr, lay);
     if (rec) {
         HIPCHK(ctx, hipEventRecord(ctx->pool[2 * ctx->pool_used + 1], ctx->stream));
         ctx->pool_used++;
@@ -495,6 +496,26 @@ static zigz_status bind_pool_collect(zigz_ctx *ctx) {
     return ZIGZ_OK;
 }
 
+// bind of ONE table fused with the half sums of the result: the counters of a large table are padded and replicated
+// (k_bind_vec<true> adds one partial sum per workgroup), read back through the pinned buffer and added here
+static zigz_status bind_with_sums(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint32_t *d_out, uint32_t r_m, uint64_t out[2]) {
+    const size_t half = n / 2;
+    const bool vec = bind_uses_vec(half, true, n, half, d_in, d_out);
+    const SumsLayout lay = vec ? bind_sums_layout(half, 1, 2048) : SumsLayout{2, 1, 0, 1};
+    const size_t words = lay.col_stride != 2 ? (size_t)lay.nslots * 32 : 2;
+    unsigned long long *d_s = ctx->d_sums + 4096;  // the scratch half of d_sums: [0, 4096) holds per-round results
+    HIPCHK(ctx, hipMemsetAsync(d_s, 0, words * 8, ctx->stream));
+    CHK(bind_launch(ctx, d_in, n, d_out, half, half, 1, r_m, nullptr, d_s, &lay));
+    HIPCHK(ctx, hipGetLastError());
+    CHK(read_u64(ctx, d_s, words, ctx->h_sums));
+    out[0] = out[1] = 0;
+    for (unsigned k = 0; k < lay.nslots; k++) {
+        out[0] += ctx->h_sums[k * lay.slot_stride];
+        out[1] += ctx->h_sums[k * lay.slot_stride + lay.bin_stride];
+    }
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_dev_mle_bind(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t r, uint32_t *d_out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !d_in || !d_out) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -518,16 +539,13 @@ extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_i
     CHK(mle_check(n));
     if (n == 1) return ZIGZ_ERR_NO_VARIABLES_TO_FIX;
     if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, 16, ctx->stream));
     bind_pool_reset(ctx);
+    uint64_t s[2];
     CHK(timed_begin(ctx, 0));
-    CHK(bind_launch(ctx, d_in, n, d_out, n / 2, n / 2, 1, host_to_mont(r), nullptr, ctx->d_sums));
-    HIPCHK(ctx, hipGetLastError());
+    CHK(bind_with_sums(ctx, d_in, n, d_out, host_to_mont(r), s));
     CHK(timed_end(ctx, 0, &ctx->stats.bind_us));
     CHK(bind_pool_collect(ctx));
     ctx->stats.bind_launches = 1;
-    uint64_t s[2];
-    CHK(read_u64(ctx, ctx->d_sums, 2, s));
     half_sums[0] = s[0] % P;
     half_sums[1] = s[1] % P;
     return ZIGZ_OK;
@@ -684,10 +702,13 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
         point[round] = ch;
         uint32_t *dst = (round % 2 == 0) ? bufA : bufB;
         const bool last = (len == 2);
-        unsigned long long *d_s = last ? nullptr : ctx->d_sums + 2 * (round + 1);
         if (ctx->timing) CHK(timed_begin(ctx, 0));
-        CHK(bind_launch(ctx, cur, len, dst, len / 2, len / 2, 1, host_to_mont(ch), nullptr, d_s));
-        HIPCHK(ctx, hipGetLastError());
+        if (last) {
+            CHK(bind_launch(ctx, cur, len, dst, len / 2, len / 2, 1, host_to_mont(ch), nullptr, nullptr));
+            HIPCHK(ctx, hipGetLastError());
+        } else {
+            CHK(bind_with_sums(ctx, cur, len, dst, host_to_mont(ch), s));  // bind + the next round's half sums, read back
+        }
         if (ctx->timing) {
             double us = 0;
             CHK(timed_end(ctx, 0, &us));
@@ -695,7 +716,6 @@ static zigz_status sumcheck_core(zigz_ctx *ctx, const uint32_t *d_in, size_t n, 
         }
         cur = dst;
         len /= 2;
-        if (!last) CHK(read_u64(ctx, d_s, 2, s));
     }
     if (len != 1) return ZIGZ_ERR_PROTOCOL_ERROR;  // sumcheck_prover.zig:80-82
     uint32_t *h = (uint32_t *)ctx->h_pin;
@@ -1604,8 +1624,11 @@ extern "C" zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size
             launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, nullptr, ctx->stream, &kt);
             break;
         case K_BIND_SUMS:
-            launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, ctx->d_sums, ctx->stream, &kt);
+        {   // as bind_with_sums launches it
+            const SumsLayout bl = bind_sums_layout(N / 2, ncols, 4096);
+            launch_bind(d_in, N, (uint32_t *)d_out_v, N / 2, N / 2, ncols, r_m, nullptr, ctx->d_sums, ctx->stream, &kt, &bl);
             break;
+        }
         case K_HALF: {  // as dev_half_sums launches it: padded, replicated counters
             const SumsLayout lay = half_sums_layout(N, ncols, 4096);
             launch_half_sums(d_in, N, N, ncols, ctx->d_sums, ctx->stream, &kt, &lay);

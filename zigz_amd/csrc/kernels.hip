@@ -78,7 +78,7 @@ template <bool SUMS>
 __global__ __launch_bounds__(TPB) void k_bind_vec(const uint32_t *__restrict__ in, size_t in_stride,
                                                   uint32_t *__restrict__ out, size_t out_stride, size_t half,
                                                   uint32_t r_m_scalar, const uint32_t *__restrict__ d_r_m,
-                                                  unsigned long long *__restrict__ sums) {
+                                                  unsigned long long *__restrict__ sums, SumsLayout lay) {
     const size_t col = blockIdx.y;
     const uint32_t r_m = d_r_m ? d_r_m[col] : r_m_scalar;
     const uint4 *lo = reinterpret_cast<const uint4 *>(in + col * in_stride);
@@ -107,7 +107,8 @@ __global__ __launch_bounds__(TPB) void k_bind_vec(const uint32_t *__restrict__ i
         // a tile never straddles the middle of the output (tiles are 4096 outputs, half/2 % 4096 == 0
         // on this path), so the whole block adds to one of the two sums.
         const bool upper = (size_t)blockIdx.x * (TPB * UNROLL * 4) >= half / 2;
-        block_add1(acc, sums + 2 * col + (upper ? 1 : 0));
+        // counter of (column, half) in copy (workgroup mod nslots): see SumsLayout
+        block_add1(acc, sums + (size_t)(blockIdx.x % lay.nslots) * lay.slot_stride + col * lay.col_stride + (upper ? lay.bin_stride : 0));
     }
 }
 
@@ -141,13 +142,16 @@ bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_str
 }
 
 void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
-                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s, const KTime *kt) {
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s, const KTime *kt,
+                 const SumsLayout *lay_in) {
     if (half == 0 || ncols == 0) return;
+    SumsLayout lay = lay_in ? *lay_in : SumsLayout{2, 1, 0, 1};
+    if (lay.nslots == 0) lay.nslots = 1;
     const bool vec = bind_uses_vec(half, d_sums != nullptr, in_stride, out_stride, d_in, d_out);
     if (vec) {
         dim3 grid((unsigned)(half / (4 * TPB * UNROLL)), (unsigned)ncols);
-        if (d_sums) ZK_LAUNCH(kt, k_bind_vec<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
-        else ZK_LAUNCH(kt, k_bind_vec<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
+        if (d_sums) ZK_LAUNCH(kt, k_bind_vec<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums, lay);
+        else ZK_LAUNCH(kt, k_bind_vec<false>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums, lay);
     } else {
         dim3 grid(1, (unsigned)ncols);
         if (d_sums) ZK_LAUNCH(kt, k_bind_small<true>, grid, dim3(TPB), 0, s, d_in, in_stride, d_out, out_stride, half, r_m, d_r_m, d_sums);
@@ -222,6 +226,16 @@ SumsLayout half_sums_layout(size_t n, size_t ncols, size_t max_words) {
     while (slots > 1 && slots * ncols * 32 > max_words) slots--;
     if (ncols * 32 > max_words) return SumsLayout{2, 1, 0, 1};
     return SumsLayout{32, 16, ncols * 32, (unsigned)(slots < 1 ? 1 : slots)};
+}
+
+SumsLayout bind_sums_layout(size_t half, size_t ncols, size_t max_words) {
+    // k_bind_vec<true>: one atomic per workgroup of 4096 outputs; (half/2)/4096 of them per counter
+    const size_t per_addr = half / 2 / 4096;
+    if (per_addr <= 64 || ncols * 32 > max_words) return SumsLayout{2, 1, 0, 1};
+    size_t slots = (per_addr + 63) / 64;
+    if (slots > 64) slots = 64;
+    while (slots > 1 && slots * ncols * 32 > max_words) slots--;
+    return SumsLayout{32, 16, ncols * 32, (unsigned)slots};
 }
 
 void launch_block_sums(const uint32_t *d_in, size_t in_stride, size_t n, unsigned log2_m, size_t ncols,

@@ -45,16 +45,6 @@ inline size_t witness_steps_ws_words(size_t npad) { return 65 * ((npad + 63) / 6
 void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
                           uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand = nullptr);
 
-// K1 (+K2 fused): batched MLE bind.  For column c in [0,ncols):
-//   out[c*out_stride + i] = in[c*in_stride + i] + r_c * (in[c*in_stride + i + half] - in[...+ i]),  i < half
-// r_c (Montgomery form) = d_r_m ? d_r_m[c] : r_m.  If d_sums: sums[2c] += sum of out[0..half/2),
-// sums[2c+1] += sum of out[half/2..half)  (exact u64 sums; must be zeroed by the caller).
-void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
-                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s,
-                 const KTime *kt = nullptr);
-// true when launch_bind takes the vectorised k_bind_vec path for these arguments
-bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out);
-inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // Where k_block_sums adds its partial sums: counter of (column c, block b, copy k) = sums[k*slot_stride + c*col_stride +
 // b*bin_stride], copy k = wave index mod nslots.  u64 atomics serialise per 128-byte cache line (~15 ns each), so when
 // few counters receive many partial sums they sit in lines of their own and are replicated; the consumer adds the copies.
@@ -62,6 +52,18 @@ struct SumsLayout {
     size_t col_stride, bin_stride, slot_stride;
     unsigned nslots;
 };
+// K1 (+K2 fused): batched MLE bind.  For column c in [0,ncols):
+//   out[c*out_stride + i] = in[c*in_stride + i] + r_c * (in[c*in_stride + i + half] - in[...+ i]),  i < half
+// r_c (Montgomery form) = d_r_m ? d_r_m[c] : r_m.  If d_sums: sums[2c] += sum of out[0..half/2),
+// sums[2c+1] += sum of out[half/2..half)  (exact u64 sums; must be zeroed by the caller).
+void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t out_stride, size_t half,
+                 size_t ncols, uint32_t r_m, const uint32_t *d_r_m, unsigned long long *d_sums, hipStream_t s,
+                 const KTime *kt = nullptr, const SumsLayout *lay = nullptr);
+// layout for the fused sums of launch_bind (plain {2, 1, 0, 1} unless one table feeds > 64 workgroups into a counter)
+SumsLayout bind_sums_layout(size_t half, size_t ncols, size_t max_words);
+// true when launch_bind takes the vectorised k_bind_vec path for these arguments
+bool bind_uses_vec(size_t half, bool with_sums, size_t in_stride, size_t out_stride, const void *in, const void *out);
+inline bool aligned16(const void *p) { return ((uintptr_t)p & 15) == 0; }
 // layout for half sums of ncols tables of n elements within max_words u64 of sums space: padded + replicated when the
 // vector path runs and the words suffice, the plain {2, 1, 0, 1} (sums[2c], sums[2c+1]) otherwise
 SumsLayout half_sums_layout(size_t n, size_t ncols, size_t max_words);
