@@ -409,6 +409,15 @@ def main():
         run_step(which=lanes[:1])
         dts, accs, _ = timed(ksolo, which=lanes[:1])           # one proof at a time on the GPU
         solo = {"dt": dts, "n": ksolo, "acc": accs}
+        if rank == 0:  # Prover.prove from program bytes: VM + compact trace upload + witness kernels + proof + serialisation
+            host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
+            t0 = time.perf_counter()
+            for _ in range(3):
+                host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
+            solo["from_program_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+            t0 = time.perf_counter()
+            host.Trace(lanes[0].prog, 0x1000, None, 2 * N)
+            solo["vm_ms"] = (time.perf_counter() - t0) * 1e3
         run_step(Lane.upload_and_prove)
         dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
         pcie = {"dt": dtp}
@@ -570,6 +579,9 @@ def main():
         if solo:
             out["config"]["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
             out["config"]["single_proof_steps_per_s"] = trace.num_steps * solo["n"] / solo["dt"]
+            if "from_program_ms" in solo:
+                out["config"]["from_program_bytes_ms"] = solo["from_program_ms"]  # one Prover.prove incl. VM execution
+                out["config"]["vm_ms"] = solo["vm_ms"]
         if shard_leg:
             for k, v in shard_leg.items():
                 out["config"]["one_proof_over_all_gpus_" + k] = v
