@@ -178,10 +178,11 @@ extern "C" int zigzh_prove(zigz_ctx *ctx, const uint8_t *program, size_t program
         if (has_initial_regs) regs.assign(initial_regs, initial_regs + n_initial_regs);
         if (input) in.assign(input, input + n_input);
         Prover prover(ctx, 0);  // main.cmdProve: Prover(F).init(allocator, 0), src/main.zig:148
-        Proof proof = prover.prove(prog, entry_pc, has_initial_regs ? &regs : nullptr, max_steps, nullptr, input ? &in : nullptr);
-        std::vector<uint8_t> b = BinarySerializer::serialize(proof);
-        *proof_out = dup_bytes(b);
-        *proof_len = b.size();
+        // serialisation overlapped with the transcript, into the thread's reusable buffer; one copy into the caller's
+        Proof proof = prover.prove(prog, entry_pc, has_initial_regs ? &regs : nullptr, max_steps, nullptr, input ? &in : nullptr,
+                                   &g_proof);
+        *proof_out = dup_bytes(g_proof);
+        *proof_len = g_proof.size();
         if (num_steps) *num_steps = proof.public_io.num_steps;
     });
 }

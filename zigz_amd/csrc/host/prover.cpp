@@ -293,7 +293,8 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
 }
 
 Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs,
-                    size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input) {
+                    size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input,
+                    std::vector<uint8_t> *serialized) {
     if (verbose) fprintf(stderr, "\n=== zkVM Prover ===\nProgram size: %zu bytes\nEntry PC: 0x%llx\n", program.size(),
                          (unsigned long long)entry_pc);
     PublicIO io;
@@ -338,7 +339,7 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     io.final_regs = fr;
     io.num_steps = num_steps;
     if (!vm->output_tape.empty()) io.outputs = vm->output_tape;
-    return proveWitness(io, L, nullptr, (const uint32_t *)dcols.p, stride, nv, initial_regs);
+    return proveWitnessImpl(io, L, nullptr, (const uint32_t *)dcols.p, stride, nv, initial_regs, serialized);
 }
 
 // ---------------------------------------------------------------- BinarySerializer (serialization.zig)

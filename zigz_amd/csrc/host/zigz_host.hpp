@@ -280,8 +280,10 @@ class Prover {  // src/prover/prover.zig
     Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
     void setShard(const ShardSpec &s) { shard_ = s; }
     // prove(program, entry_pc, initial_regs, max_steps, segments, input), :73-226
+    // serialized (optional): also BinarySerializer.serialize, with the early sections written underneath the transcript
     Proof prove(const std::vector<uint8_t> &program, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs,
-                size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input);
+                size_t max_steps, const std::vector<Segment> *segments, const std::vector<uint64_t> *input,
+                std::vector<uint8_t> *serialized = nullptr);
     // Steps [4/6]-[6/6] + packagePublicIO on an existing witness (the data-parallel part): the columns
     // may be host canonical u64 (`witness`) or already resident in HBM as packed u32 (`d_cols`).
     Proof proveWitness(const PublicIO &io_template, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
