@@ -284,7 +284,7 @@ def main():
     dist = None
     torch = None
     backend = os.environ.get("ZIGZ_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a 1-GPU box
-    if world > 1:
+    if world > 1 or os.environ.get("ZIGZ_BENCH_FORCE_DIST") == "1":  # (the env switch: the RCCL code path with one rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         import torch
         import torch.distributed as dist
