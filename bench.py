@@ -275,6 +275,15 @@ def main():
                               "launched_by_bench": os.environ.get("ZIGZ_BENCH_LAUNCHED") == "1"}), flush=True)
         return 0
 
+    # Only the result line may reach stdout: libraries print banners there (RCCL writes its version block to stdout when the
+    # first communicator is created), so fd 1 is pointed at stderr for the whole run and the line goes to the saved fd.
+    sys.stdout.flush()
+    result_fd = os.dup(1)
+    os.dup2(2, 1)
+
+    def emit(line):
+        os.write(result_fd, (line + "\n").encode())
+
     # ---- CPU baseline first (rank 0, N = 1 only), in a child of its own: the GPU phase that follows is then one
     # contiguous stretch, and this process never loads the oracle
     cpu = None
@@ -314,12 +323,12 @@ def main():
         ctx = zigz_amd.Context(local_rank)
         res = kernel_leg(ctx, nv, 43, args.kernel_iters)
         ctx.close()
-        print(json.dumps({"kernels": res, "cold": True, "iters": args.kernel_iters,
-                          "hbm_peak_GBs": HBM_PEAK_GBS, "valu_peak_Tinstr_s": VALU_PEAK_TOPS}), flush=True)
+        emit(json.dumps({"kernels": res, "cold": True, "iters": args.kernel_iters,
+                         "hbm_peak_GBs": HBM_PEAK_GBS, "valu_peak_Tinstr_s": VALU_PEAK_TOPS}))
         return 0
 
     if args.lasso:
-        print(json.dumps(lasso_leg(zigz_amd.Context(local_rank))), flush=True)
+        emit(json.dumps(lasso_leg(zigz_amd.Context(local_rank))))
         return 0
 
     shard = args.mode == "shard"
@@ -608,7 +617,7 @@ def main():
         # `roofline` above)
         if cpu is not None:
             out["cpu_baseline"] = cpu
-        print(json.dumps(out), flush=True)
+        emit(json.dumps(out))
     pool.shutdown()
     for l in lanes:
         l.ctx.dev_free(l.d_cols)
