@@ -361,7 +361,16 @@ def main():
             self.trace.witness_to_device(self.ctx, self.d_cols, N, wait=False)  # enqueued; the proof's builds follow on the stream
             return self.prove()
 
-    allgather_hook = host.make_allgather(dist) if (shard and dist is not None) else None
+    # --mode shard: the two exchanges of a column-sharded proof are host-resident and a few KiB -> the shared-memory hook
+    # (one node); ZIGZ_BENCH_SHARD_HOOK=torch binds torch.distributed (RCCL / gloo) instead
+    allgather_hook = None
+    if shard and dist is not None:
+        if os.environ.get("ZIGZ_BENCH_SHARD_HOOK") == "torch":
+            allgather_hook = host.make_allgather(dist)
+        else:
+            from zigz_amd.shard import ShmComm
+            allgather_hook = ShmComm("zigz_bench_shard_%s" % os.environ.get("MASTER_PORT", "0"), rank, world, max_bytes=1 << 16,
+                                     timeout_s=120.0)
     lanes = [Lane(k) for k in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
 
