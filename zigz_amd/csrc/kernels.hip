@@ -970,7 +970,8 @@ void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n
     dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
     ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
               d_tables, d_todo_count, d_todo);
-    hipLaunchKernelGGL(k_keccak_small_fallback, dim3(2048), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+    // list-driven; 512 workgroups walk the to-do list (empty unless a hint was wrong: then a few microseconds)
+    hipLaunchKernelGGL(k_keccak_small_fallback, dim3(512), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
                        tree_stride_nodes, cols, d_todo_count, d_todo);
 }
 
