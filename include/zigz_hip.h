@@ -275,9 +275,9 @@ void zigz_transcript_append_tagged_counter(zigz_transcript *t, const uint8_t *ta
 uint64_t zigz_transcript_challenge(zigz_transcript *t); /* BabyBear; hash.zig:301-316 */
 void zigz_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]);
 void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]);
-/* which single-state Keccak-f[1600] the host sponge uses ("scalar", "bmi2" or "avx512f": the fastest supported
- * variant, timed at load; env ZIGZ_HOST_KECCAK overrides), and one permutation through a chosen variant
- * (0 = the picked one, 1 = scalar, 2 = bmi2, 3 = avx512f) -- diagnostics / self-test */
+/* which single-state Keccak-f[1600] the host sponge uses ("scalar", "bmi2", "avx512f" or "avx512vl": the fastest
+ * supported variant, timed at load; env ZIGZ_HOST_KECCAK overrides), and one permutation through a chosen variant
+ * (0 = the picked one, 1 = scalar, 2 = bmi2, 3 = avx512f, 4 = avx512vl) -- diagnostics / self-test */
 const char *zigz_host_keccak_impl(void);
 void zigz_host_keccak_permute(uint64_t state[25], int which);
 

@@ -118,11 +118,11 @@ def test_host_keccak_dispatch_matches_portable_code():
     portable implementation and the oracle's on random states."""
     from zigz_amd._ffi import lib, u64p
     rng = np.random.default_rng(5)
-    assert lib.zigz_host_keccak_impl() in (b"avx512f", b"bmi2", b"scalar")
+    assert lib.zigz_host_keccak_impl() in (b"avx512vl", b"avx512f", b"bmi2", b"scalar")
     for _ in range(200):
         st = rng.integers(0, 2**64, 25, dtype=np.uint64)
         outs = []
-        for which in (0, 1, 2, 3):  # picked, scalar, bmi2, avx512f (unsupported ones fall back to the picked one)
+        for which in (0, 1, 2, 3, 4):  # picked, scalar, bmi2, avx512f, avx512vl (unsupported ones fall back to the picked one)
             a = st.copy()
             lib.zigz_host_keccak_permute(a.ctypes.data_as(u64p), which)
             outs.append(a)

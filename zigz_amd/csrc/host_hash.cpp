@@ -14,6 +14,8 @@ void keccak_f1600_avx512(uint64_t st[25]);  // host_keccak_avx512.cpp
 bool cpu_has_avx512f();
 void keccak_f1600_bmi(uint64_t st[25]);     // host_keccak_bmi.cpp
 bool cpu_has_bmi2();
+void keccak_f1600_avx512vl(uint64_t st[25]);  // host_keccak_avx512vl.cpp (one lane per vector register)
+bool cpu_has_avx512vl();
 
 static void permute_scalar(uint64_t st[25]) {
     for (int r = 0; r < 24; r++) ZK_KECCAK_ROUND(st, KECCAK_RC[r]);
@@ -25,11 +27,12 @@ static void permute_scalar(uint64_t st[25]) {
 namespace {
 struct Variant { const char *name; void (*fn)(uint64_t *); };
 Variant pick_variant() {
-    Variant cands[3];
+    Variant cands[4];
     int n = 0;
     cands[n++] = {"scalar", permute_scalar};
     if (cpu_has_bmi2()) cands[n++] = {"bmi2", keccak_f1600_bmi};
     if (cpu_has_avx512f()) cands[n++] = {"avx512f", keccak_f1600_avx512};
+    if (cpu_has_avx512vl()) cands[n++] = {"avx512vl", keccak_f1600_avx512vl};
     const char *force = getenv("ZIGZ_HOST_KECCAK");
     if (force)
         for (int i = 0; i < n; i++)
@@ -63,6 +66,7 @@ void host_keccak_permute(uint64_t st[25], int which) {
     if (which == 1) permute_scalar(st);
     else if (which == 2 && cpu_has_bmi2()) keccak_f1600_bmi(st);
     else if (which == 3 && cpu_has_avx512f()) keccak_f1600_avx512(st);
+    else if (which == 4 && cpu_has_avx512vl()) keccak_f1600_avx512vl(st);
     else g_variant.fn(st);
 }
 

@@ -35,8 +35,8 @@ class Transcript {
 };
 
 void sha3_256(const uint8_t *data, size_t len, uint8_t out[32]);
-const char *host_keccak_impl();  // "scalar", "bmi2" or "avx512f": the variant picked at load time
-// one Keccak-f[1600] through a chosen variant: 0 = picked, 1 = scalar, 2 = bmi2, 3 = avx512f (if supported)
+const char *host_keccak_impl();  // "scalar", "bmi2", "avx512f" or "avx512vl": the variant picked at load time
+// one Keccak-f[1600] through a chosen variant: 0 = picked, 1 = scalar, 2 = bmi2, 3 = avx512f, 4 = avx512vl (if supported)
 void host_keccak_permute(uint64_t st[25], int which);
 void sha256(const uint8_t *data, size_t len, uint8_t out[32]);
 
