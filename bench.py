@@ -448,7 +448,9 @@ def main():
     shard_leg = None
     if world > 1 and not shard and not args.no_extras:
         comm = None
-        try:
+        sd = None
+        ok = 1.0
+        try:  # set-up: nothing collective in here, so a rank that fails cannot desynchronise the others
             from zigz_amd.shard import ShmComm
             sctx = lanes[0].ctx
             sprog = programs.add_xor_loop((N - 3) // 4)  # the same trace on every rank
@@ -456,22 +458,32 @@ def main():
             sd = sctx.dev_alloc(43 * N * 4)
             strace.witness_to_device(sctx, sd, N)
             comm = ShmComm("zigz_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world, max_bytes=1 << 16, timeout_s=60.0)
-            strace.prove_sharded(sctx, sd, N, None, comm)  # warm-up
-            ks = max(3, min(args.steps, 10))
-            sync_all()
-            t0 = time.perf_counter()
-            for _ in range(ks):
-                sp = strace.prove_sharded(sctx, sd, N, None, comm)
-            sync_all()
-            sdt = time.perf_counter() - t0
-            shard_leg = {"ms_per_proof": sdt / ks * 1e3, "steps_per_s": strace.num_steps * ks / sdt, "proofs": ks,
-                         "proof_bytes": len(sp), "accepts": host.verify(sp.tobytes(), sprog) == "Accept" if rank == 0 else None}
-            sctx.dev_free(sd)
-        except Exception as e:  # keep the headline line whatever happens here
+        except Exception as e:
+            ok = 0.0
             shard_leg = {"error": repr(e)[:300]}
-        finally:
+        t = torch.tensor([ok], dtype=torch.float64, device=tdev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)  # every rank takes part; the leg runs only if all of them are ready
+        if float(t.item()) == 1.0:
+            try:
+                strace.prove_sharded(sctx, sd, N, None, comm)  # warm-up
+                ks = max(3, min(args.steps, 10))
+                t0 = time.perf_counter()
+                for _ in range(ks):
+                    sp = strace.prove_sharded(sctx, sd, N, None, comm)  # the exchanges inside synchronise the ranks
+                sdt = time.perf_counter() - t0
+                shard_leg = {"ms_per_proof": sdt / ks * 1e3, "steps_per_s": strace.num_steps * ks / sdt, "proofs": ks,
+                             "proof_bytes": len(sp), "accepts": host.verify(sp.tobytes(), sprog) == "Accept" if rank == 0 else None}
+            except Exception as e:  # a peer died: the shared-memory waits time out on every rank alike
+                shard_leg = {"error": repr(e)[:300]}
+        elif shard_leg is None:
+            shard_leg = {"error": "another rank could not set the leg up"}
+        try:
+            if sd is not None:
+                lanes[0].ctx.dev_free(sd)
             if comm is not None:
                 comm.close()
+        except Exception:
+            pass
 
     local_steps = float(sum(l.trace.num_steps for l in lanes))
     trace = lanes[0].trace
