@@ -209,3 +209,18 @@ def test_row_sharded_merkle_gloo(world, n):
             esib, edirs, eleaf = O.merkle_open(vals, idx)
             assert (sib, dirs, leaf) == (esib.hex(), edirs.hex(), eleaf), (rank, idx)
             assert O.merkle_verify(root, leaf, bytes.fromhex(sib), bytes.fromhex(dirs))
+
+
+def test_shm_comm_under_thread_sanitizer(tmp_path):
+    """The shared-memory transport's protocol (two slot sets, release / acquire on the sequence counters) with the ranks as
+    threads of one process under ThreadSanitizer: 2 000 back-to-back exchanges of varying size, every byte checked."""
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = str(tmp_path / "shm_tsan")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-g", "-fsanitize=thread", "-pthread", "-I", os.path.join(root, "include"),
+                           os.path.join(root, "tests", "c_driver", "shm_tsan.cpp"),
+                           os.path.join(root, "zigz_amd", "csrc", "shm_comm.cpp"), "-o", exe, "-lrt"])
+    for world in (2, 4):
+        r = subprocess.run([exe, str(world), "2000"], capture_output=True, text=True, timeout=300,
+                           env=dict(os.environ, TSAN_OPTIONS="halt_on_error=1"))
+        assert r.returncode == 0 and r.stdout.startswith("ok:"), r.stdout[-2000:] + r.stderr[-4000:]
