@@ -448,6 +448,15 @@ def main():
         run_step(Lane.upload_and_prove)
         dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
         pcie = {"dt": dtp}
+        if not args.dedup:  # same batch with the run-aware Merkle build (identical proofs; GPU time depends on the data)
+            for l in lanes:
+                l.ctx.set_option("merkle_dedup", 1)
+            run_step()
+            dtr, accr, _ = timed(args.steps)
+            for l in lanes:
+                l.ctx.set_option("merkle_dedup", 0)
+            pcie["run_aware_dt"] = dtr
+            pcie["run_aware_perms"] = accr["keccak_permutations"] / nproofs
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
 
@@ -506,6 +515,8 @@ def main():
         dt = allmax(dt)
         if pcie:
             pcie["dt"] = allmax(pcie["dt"])
+            if "run_aware_dt" in pcie:
+                pcie["run_aware_dt"] = allmax(pcie["run_aware_dt"])
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
@@ -635,6 +646,13 @@ def main():
             out["config"]["pcie_inclusive_ms_per_step"] = pcie["dt"] / args.steps * 1e3
             out["config"]["pcie_inclusive_note"] = ("same batch, but every proof first uploads its trace over PCIe and runs the "
                                                     "witness kernels inside the loop (never reported as value)")
+            if "run_aware_dt" in pcie:
+                out["config"]["run_aware_merkle_value"] = total_steps * args.steps / pcie["run_aware_dt"]
+                out["config"]["run_aware_merkle_permutations_per_proof"] = pcie["run_aware_perms"]
+                out["config"]["run_aware_merkle_note"] = ("same batch with option merkle_dedup (uniform 256-leaf blocks hashed "
+                                                          "once; byte-identical proofs): depends on the runs in the trace -- this "
+                                                          "ADD/XOR loop leaves 27 registers constant -- so it is off by default and "
+                                                          "never reported as value")
         out["kernels"] = {"timed_region": {
             "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,
             "keccak_leaves_ms_per_proof": acc["keccak_leaves_us"] / nproofs / 1e3,

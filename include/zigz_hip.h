@@ -290,7 +290,7 @@ typedef struct zigz_kernel_stats {
     double path_us;           /* path gather */
     double bind_us;           /* last zigz_dev_mle_bind / bind_sums launch, or all binds of the last sumcheck */
     uint64_t bind_launches;
-    uint64_t keccak_permutations;
+    uint64_t keccak_permutations; /* Keccak-f[1600] actually computed by the last commit (table look-ups and chained uniform blocks excluded) */
     /* the bulk MLE-bind launches of the last eval / sumcheck / bind call, each timed on its own: total device time,
      * launch count, algorithmic bytes.  Kernel k_radix_fold (one pass binding v-10 variables, 4 B read per element;
      * timed with the dispatch's own begin/end timestamps) for evals of tables >= 2^14, k_bind_vec (6 B per table

@@ -234,6 +234,9 @@ def test_prove_with_merkle_dedup_is_byte_identical(ctx):
     finally:
         ctx.set_option("merkle_dedup", 0)
     assert a == b and st["merkle_uniform_blocks"] > st["merkle_blocks"] // 2
+    # the permutation counter reports what was hashed: a uniform 256-leaf block costs 9 hashes instead of 511
+    assert st["merkle_blocks"] == 43 * (1 << 9)
+    assert st["keccak_permutations"] == 43 * ((2 << 17) - 1) - st["merkle_uniform_blocks"] * 502
     assert host.verify(b, prog) == "Accept"
 
 

@@ -1402,6 +1402,8 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     memcpy(roots, ctx->h_roots, job->ncols * 32);
     const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
     ctx->stats.merkle_uniform_blocks = ctx->stats.merkle_blocks ? h_cnt[0] : 0;
+    // a uniform 256-leaf block costs its chain of 9 hashes instead of 256 leaves + 255 nodes
+    ctx->stats.keccak_permutations -= ctx->stats.merkle_uniform_blocks * (uint64_t)((2u << DEDUP_BLOG) - 1 - (DEDUP_BLOG + 1));
     ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
     if (ctx->timing) {
         float ms = 0;
