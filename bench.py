@@ -61,6 +61,17 @@ def free_port():
     return p
 
 
+MERKLE_BUILDS = {  # --merkle: what config.merkle_build says
+    "regs": "leaf + level-1 digests of the 8 structurally small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, "
+            "is_read: values < 128 by construction) from constant tables; large levels of the 31 register columns x1..x31 (at "
+            "most one of them changes per step, whatever the program) run-aware: a node that repeats its left neighbour is "
+            "copied, decided from the values on the device; the other 4 columns dense; identical trees",
+    "all": "as regs, with every column that is not small-domain run-aware (pc, imm, mem.address, mem.value too)",
+    "tables": "dense; leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, identical trees",
+    "dense": "dense: every node of every column hashed",
+}
+
+
 def launch_ranks(n, argv):
     """Start n ranks as a child torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has
     imported torch or loaded HIP at this point (tests/test_bench_launch.py asserts it)."""
@@ -234,10 +245,14 @@ def main():
                     "GPUs (two all-gathers of 43 x 32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the "
                     "sequential host transcript that every rank replays (DESIGN.md s7)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
-    ap.add_argument("--dedup", action="store_true", help="run-aware Merkle build (option merkle_dedup); default off: "
-                    "the headline is measured with the dense, data-independent build")
-    ap.add_argument("--dense-merkle", action="store_true", help="hash every leaf and level-1 node of all 43 columns (turns off the "
-                    "table lookups for the 8 structurally small-domain columns: x0, opcode, rd, rs1, rs2, funct3, funct7, is_read)")
+    ap.add_argument("--merkle", choices=["regs", "all", "tables", "dense"], default="regs",
+                    help="Merkle build of the 43 columns (identical trees and proofs in every mode).  regs (the product's "
+                    "default): leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, and the 31 "
+                    "register columns x1..x31 -- at most one of them changes per step, whatever the program -- with run-aware "
+                    "large levels (a node that repeats its left neighbour is copied, not hashed).  all: every other column "
+                    "run-aware too.  tables: the tables only (round 2's first default).  dense: hash every node")
+    ap.add_argument("--dedup", action="store_true", help="same as --merkle all")
+    ap.add_argument("--dense-merkle", action="store_true", help="same as --merkle dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-cols", type=int, default=12, help="columns of the CPU baseline sample (~1.1 s each)")
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
@@ -296,7 +311,7 @@ def main():
     # ---- CPU baseline first (rank 0, N = 1 only), in a child of its own: the GPU phase that follows is then one
     # contiguous stretch, and this process never loads the oracle
     cpu = None
-    if world == 1 and not args.no_cpu_baseline and not args.kernels:
+    if world == 1 and not args.no_cpu_baseline and args.cpu_sample_cols > 0 and not args.kernels:
         cpu = run_cpu_baseline(args.nv, args.cpu_sample_cols)
 
     dist = None
@@ -318,7 +333,18 @@ def main():
     tdev = "cuda" if backend == "nccl" else "cpu"
 
     if args.dense_merkle:
-        os.environ["ZIGZ_DENSE_MERKLE"] = "1"
+        args.merkle = "dense"
+    if args.dedup:
+        args.merkle = "all"
+
+    def set_merkle_mode(mode):  # Prover reads these when a proof starts (host/prover.cpp)
+        os.environ.pop("ZIGZ_DENSE_MERKLE", None)
+        os.environ.pop("ZIGZ_RUN_AWARE", None)
+        if mode == "dense":
+            os.environ["ZIGZ_DENSE_MERKLE"] = "1"
+        else:
+            os.environ["ZIGZ_RUN_AWARE"] = {"regs": "regs", "all": "all", "tables": "off"}[mode]
+    set_merkle_mode(args.merkle)
     import zigz_amd
     from zigz_amd import host
     import programs
@@ -346,8 +372,6 @@ def main():
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
         def __init__(self, k):
             self.ctx = zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
-            if args.dedup:
-                self.ctx.set_option("merkle_dedup", 1)
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
             self.prog = programs.add_xor_loop((N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
             self.trace = host.Trace(self.prog, 0x1000, None, 2 * N)  # [1/6] VM execution: outside the timed region
@@ -363,6 +387,10 @@ def main():
                 self.proof = self.trace.prove_sharded(self.ctx, self.d_cols, N, dist, allgather_hook)
             else:
                 self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
+            return self.ctx.stats(), host.last_timings()
+
+        def prove_worst(self):  # the register-round-robin trace of the worst-case leg (resident in d_cols by then)
+            self.trace_w.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
 
         def upload_and_prove(self):  # PCIe-inclusive: the compact trace (48 B per step) crosses PCIe and the witness
@@ -448,17 +476,35 @@ def main():
         run_step(Lane.upload_and_prove)
         dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
         pcie = {"dt": dtp}
-        if not args.dedup:  # same batch with the run-aware Merkle build (identical proofs; GPU time depends on the data)
-            for l in lanes:
-                l.ctx.set_option("merkle_dedup", 1)
+        variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
+        for mode in ("regs", "all", "tables", "dense"):
+            if mode == args.merkle:
+                continue
+            set_merkle_mode(mode)
             run_step()
-            dtr, accr, _ = timed(args.steps)
-            for l in lanes:
-                l.ctx.set_option("merkle_dedup", 0)
-            pcie["run_aware_dt"] = dtr
-            pcie["run_aware_perms"] = accr["keccak_permutations"] / nproofs
+            ks = max(3, min(args.steps, 10))
+            dtv, accv, _ = timed(ks)
+            variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * B)}
+        set_merkle_mode(args.merkle)
+        pcie["variants"] = variants
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
+        if args.merkle in ("regs", "all"):
+            # The run-aware register levels make the GPU time depend on the trace.  Its worst case by construction: a loop
+            # that writes 30 different registers in turn, so the <= N change points of the 31 register columns are spread
+            # evenly over all of them (tests/programs.py register_round_robin).  Same batch, same everything else; the lanes'
+            # witness buffers are overwritten, so this is the last leg that uses them.
+            lanes[0].proof = lanes[0].proof.tobytes()  # the borrowed buffer is reused by the proofs below
+            for k, l in enumerate(lanes):
+                l.trace_w = host.Trace(programs.register_round_robin((N - 2) // 31 - (rank * B + k)), 0x1000, None, 2 * N)
+                assert l.trace_w.num_vars == nv
+                l.trace_w.witness_to_device(l.ctx, l.d_cols, N)
+                l.ctx.synchronize()
+            run_step(Lane.prove_worst)
+            ks = max(3, min(args.steps, 10))
+            dtw, accw, _ = timed(ks, Lane.prove_worst)
+            pcie["worst"] = {"dt": dtw, "steps": ks, "perms": accw["keccak_permutations"] / (ks * B),
+                             "trace_steps": float(sum(l.trace_w.num_steps for l in lanes))}
 
     # ---- N > 1, traces mode: also ONE proof per step sharded by column over the N ranks (the strong-scaling variant of
     # --mode shard), reported in the same line.  Exchanges go through the shared-memory hook (host-resident payloads of a
@@ -512,11 +558,18 @@ def main():
             t = torch.tensor([x], dtype=torch.float64, device=tdev)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             return float(t.item())
+        def allsum(x):
+            t = torch.tensor([x], dtype=torch.float64, device=tdev)
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            return float(t.item())
         dt = allmax(dt)
         if pcie:
             pcie["dt"] = allmax(pcie["dt"])
-            if "run_aware_dt" in pcie:
-                pcie["run_aware_dt"] = allmax(pcie["run_aware_dt"])
+            for vv in pcie.get("variants", {}).values():
+                vv["dt"] = allmax(vv["dt"])
+            if "worst" in pcie:
+                pcie["worst"]["dt"] = allmax(pcie["worst"]["dt"])
+                pcie["worst"]["trace_steps"] = allsum(pcie["worst"]["trace_steps"])
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
@@ -524,7 +577,7 @@ def main():
         total_steps = local_steps
 
     if rank == 0:
-        proof = proof.tobytes()
+        proof = proof if isinstance(proof, bytes) else proof.tobytes()
         assert host.verify(proof, prog) == "Accept"
         ic = isa_counts()
         perms_leaves = acc["keccak_leaves_perms"]
@@ -533,7 +586,7 @@ def main():
         keccak_us = acc["keccak_leaves_us"] + acc["keccak_level_wide_us"] + acc["keccak_level_small_us"]
         sa = solo["acc"] if solo else acc  # kernel-time shares from the single-proof leg (no overlap between proofs)
         share = sa["keccak_leaves_us"] / max(sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] +
-                                            sa["small_domain_us"] + sa["eval_us"], 1e-9)
+                                            sa["small_domain_us"] + sa["run_aware_us"] + sa["eval_us"], 1e-9)
         roof = {
             "kernel": "k_keccak_leaves (SHA3-256 leaf hashes of the densely hashed witness columns: 1 Keccak-f[1600] = %d VALU "
                       "instructions per 4 B read + 32 B written; the dominant kernel: %.0f %% of the kernel time of a proof, all "
@@ -565,12 +618,16 @@ def main():
                                  "build starts after ~20 ms of idle GPU while the host absorbs the transcript)" % solo["n"],
                 "in_proof_avg_launch_us": a["keccak_leaves_us"] / solo["n"],
                 "in_proof_gperm_per_s": a["keccak_leaves_perms"] / 1e9 / (a["keccak_leaves_us"] / 1e6),
-                "level_wide_gperm_per_s": a["keccak_level_wide_perms"] / 1e9 / (a["keccak_level_wide_us"] / 1e6),
-                "level_wide_frac": a["keccak_level_wide_perms"] * ic["level"] / (a["keccak_level_wide_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS,
+                "level_wide_gperm_per_s": (a["keccak_level_wide_perms"] / 1e9 / (a["keccak_level_wide_us"] / 1e6))
+                if a["keccak_level_wide_us"] else None,
+                "level_wide_frac": (a["keccak_level_wide_perms"] * ic["level"] / (a["keccak_level_wide_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
+                if a["keccak_level_wide_us"] else None,
                 "level_small_gperm_per_s": (a["keccak_level_small_perms"] / 1e9 / (a["keccak_level_small_us"] / 1e6))
                 if a["keccak_level_small_us"] else None,
                 "merkle_build_ms": a["merkle_build_us"] / solo["n"] / 1e3,
                 "small_domain_lookup_us": a["small_domain_us"] / solo["n"],
+                "run_aware_levels_us": a["run_aware_us"] / solo["n"],
+                "run_aware_hashed": a["run_aware_hashed"] / solo["n"],
                 "merkle_build_gperm_per_s": a["keccak_permutations"] / 1e9 / (a["merkle_build_us"] / 1e6),
                 "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1),
                 "eval_fold_hbm_frac": (a["bind_vec_bytes"] / 1e9) / (a["bind_vec_us"] / 1e6) / HBM_PEAK_GBS if a["bind_vec_us"] else None,
@@ -615,10 +672,7 @@ def main():
                                    "Prover.prove hot path incl. Fiat-Shamir transcript and ZIGZ v1 serialisation; "
                                    "%d independent traces (proofs) per GPU per step" % (nv, B),
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
-                       "merkle_build": "run-aware (merkle_dedup)" if args.dedup else
-                                       ("dense" if args.dense_merkle else "dense; leaf + level-1 digests of the 8 structurally "
-                                        "small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, is_read: values < 128 by "
-                                        "construction) from constant tables, identical trees"),
+                       "merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle],
                        "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
                        "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
                        "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
@@ -646,13 +700,20 @@ def main():
             out["config"]["pcie_inclusive_ms_per_step"] = pcie["dt"] / args.steps * 1e3
             out["config"]["pcie_inclusive_note"] = ("same batch, but every proof first uploads its trace over PCIe and runs the "
                                                     "witness kernels inside the loop (never reported as value)")
-            if "run_aware_dt" in pcie:
-                out["config"]["run_aware_merkle_value"] = total_steps * args.steps / pcie["run_aware_dt"]
-                out["config"]["run_aware_merkle_permutations_per_proof"] = pcie["run_aware_perms"]
-                out["config"]["run_aware_merkle_note"] = ("same batch with option merkle_dedup (uniform 256-leaf blocks hashed "
-                                                          "once; byte-identical proofs): depends on the runs in the trace -- this "
-                                                          "ADD/XOR loop leaves 27 registers constant -- so it is off by default and "
-                                                          "never reported as value")
+            if pcie.get("variants"):
+                out["config"]["merkle_variants"] = {
+                    m: {"value": total_steps * vv["steps"] / vv["dt"], "keccak_permutations_per_proof": vv["perms"]}
+                    for m, vv in pcie["variants"].items()}
+            if "worst" in pcie:
+                w = pcie["worst"]
+                out["config"]["register_worst_case_value"] = w["trace_steps"] * w["steps"] / w["dt"]
+                out["config"]["register_worst_case_keccak_permutations_per_proof"] = w["perms"]
+                out["config"]["register_worst_case_note"] = (
+                    "the same batch on the trace that is worst for the run-aware register levels: a loop writing 30 different "
+                    "registers in turn (each register column changes every 31 steps; tests/programs.py register_round_robin)")
+                out["config"]["merkle_variants_note"] = ("the same batch under the other Merkle builds of --merkle (identical "
+                                                         "proofs; regs = default, all = every column run-aware, tables = "
+                                                         "small-domain tables only, dense = every node hashed)")
         out["kernels"] = {"timed_region": {
             "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,
             "keccak_leaves_ms_per_proof": acc["keccak_leaves_us"] / nproofs / 1e3,
@@ -660,6 +721,9 @@ def main():
             "keccak_level_small_ms_per_proof": acc["keccak_level_small_us"] / nproofs / 1e3,
             "eval_ms_per_proof": acc["eval_us"] / nproofs / 1e3,
             "small_domain_lookup_ms_per_proof": acc["small_domain_us"] / nproofs / 1e3,
+            "run_aware_levels_ms_per_proof": acc["run_aware_us"] / nproofs / 1e3,
+            "run_aware_hashed_per_proof": acc["run_aware_hashed"] / nproofs,
+            "run_aware_dense_nodes_per_proof": acc["run_aware_dense_nodes"] / nproofs,
             "small_domain_fallback_waves": acc["small_domain_fallback_waves"],
             "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
             "gpu_busy_keccak_gperm_per_s": (acc["keccak_permutations"] / 1e9) / dt},

@@ -148,6 +148,10 @@ zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots);
  * dirs ncols*nv B (prover.zig:431 -> polynomial_commit.zig:86-115 -> merkle_tree.zig:324-360). */
 zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, uint64_t *values,
                                  uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);
+/* diagnostic (tests): device address of the job's trees once built -- per column `bytes_per_column` = 2 * 2^nv nodes x 32 B
+ * in the kernels' internal node form (level l at node offset 2N - 2(N >> l)); valid until zigz_commit_end.  Lets a test
+ * compare two builds of the same columns node for node (dense vs table / run-aware levels). */
+zigz_status zigz_commit_job_tree(zigz_commit_job *job, const void **d_tree, size_t *bytes_per_column);
 void zigz_commit_end(zigz_commit_job *job);
 
 /* ---------------------------------------------------------------- LassoProver(F)
@@ -298,10 +302,14 @@ typedef struct zigz_kernel_stats {
     double bind_vec_us;
     uint64_t bind_vec_launches;
     uint64_t bind_vec_bytes;
-    /* run-aware Merkle build (option "merkle_dedup"): 256-leaf blocks in the last batched commit and how many of
-     * them were uniform (0 / 0 when the option is off or the trees are smaller than 2^17 leaves) */
-    uint64_t merkle_blocks;
-    uint64_t merkle_uniform_blocks;
+    /* run-aware Merkle levels (option "run_aware_mask") of the last batched commit: columns built that way, the nodes
+     * of the levels they covered (what a dense build hashes there), how many of those were hashed rather than copied
+     * from the left neighbour, and the kernel time of those launches (timing mode).  0 when the option is off or the
+     * trees have fewer than 2^15 leaves. */
+    uint64_t run_aware_columns;
+    uint64_t run_aware_dense_nodes;
+    uint64_t run_aware_hashed;
+    double run_aware_us;
     /* Keccak launches of the last batched commit by class, each launch timed with its own begin / end timestamps
      * (kernel time as rocprofv3 --kernel-trace reports it; the gaps between launches are in merkle_build_us only):
      * k_keccak_leaves; k_keccak_level<4> (the large levels); k_keccak_level<1> (the small levels); hashes = permutations */
@@ -336,7 +344,13 @@ zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size_t nv, size
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
 /* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
  * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;
- * "merkle_dedup" = 1 enables the run-aware Merkle build (identical trees; fewer hashes on piecewise-constant columns);
+ * "run_aware_mask" = bit c set: column c of the following batched commits (<= 64 columns, 2^15 .. 2^26 rows) is expected to be
+ *   piecewise constant -- in the witness of prover.zig:376-390 the registers: every RV64IM step writes at most one of them
+ *   (state.zig writeReg), so the 31 columns x1..x31 together change at most once per step.  On the levels with >= 16384
+ *   nodes a node whose subtree and its left neighbour's are uniform with the same value takes the neighbour's digest
+ *   instead of being hashed.  Decided from the VALUES on the device, never from the hint: identical trees for ANY input;
+ *   with c change points in a column a level costs <= min(nodes, 2 c + nodes / 4096) hashes.
+ * "merkle_dedup" = 1 / 0 is shorthand for run_aware_mask = all ones / 0;
  * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
  *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the
  *   instruction fields opcode / rd / rs1 / rs2 / funct3 / funct7 (7-, 5-, 5-, 5-, 3-, 7-bit fields, rv64i.zig:124-151) and

@@ -32,6 +32,16 @@ def add_xor_loop(iterations):
     return _pack(w)
 
 
+def register_round_robin(iterations):
+    """The worst case for a run-aware build of the register columns: a loop that writes 30 DIFFERENT registers in turn
+    (x1..x29 += k, x31 = counter; x30 holds the bound), so every register column changes once every 31 steps and the
+    change points are spread evenly over all of them.  num_steps = 2 + 31*iterations."""
+    w = _li(30, iterations)
+    body = [_I(0x13, r, 0, r, r) for r in range(1, 30)] + [_I(0x13, 31, 0, 31, 1)]
+    w += body + [_B(1, 31, 30, -4 * len(body))]
+    return _pack(w)
+
+
 def mixed_loop(iterations):
     """RV64IM mix -- ADD/XOR/MUL/DIVU/REM, SD/LD, ADDIW, branch. 12 steps per iteration."""
     w = _li(5, iterations) + [_I(0x13, 1, 0, 0, 3), _I(0x13, 6, 0, 0, 7), _I(0x13, 8, 0, 0, 0x100)]

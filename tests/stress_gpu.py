@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """One-off GPU soak (not collected by pytest): random LOOPING RV64IM programs with ragged step counts up to 2^17, proved
-through every build variant of the HIP path -- packed rows / compact device trace, small-domain tables on / off, run-aware
-Merkle on / off -- and compared byte for byte with the oracle's literal proof.
+through every build variant of the HIP path -- packed rows / compact device trace; Merkle build dense, with the
+small-domain tables, with run-aware register columns, with every column run-aware -- and compared byte for byte with the oracle's literal proof.
 
     python tests/stress_gpu.py [--cases 12] [--seed 7] [--max-log 17]
 
@@ -66,23 +66,26 @@ def main():
         oproof, ons = O.prove(P, prog, 0x1000, iregs, 1 << 20)
         t_or = time.time() - t0
         variants = 0
-        for dense in (0, 1):
-            os.environ["ZIGZ_DENSE_MERKLE"] = str(dense)
-            for dedup in (0, 1):
-                ctx.set_option("merkle_dedup", dedup)
-                proof, ns = host.prove(ctx, prog, 0x1000, iregs, 1 << 20)
-                assert ns == ons and proof == oproof, ("rows", case, dense, dedup)
-                tr = host.Trace(prog, 0x1000, iregs, 1 << 20)
-                n = 1 << tr.num_vars
-                d = ctx.dev_alloc(43 * max(n, 4) * 4)
-                try:
-                    tr.witness_to_device(ctx, d, max(n, 4))
-                    assert tr.prove(ctx, d, max(n, 4)) == oproof, ("compact", case, dense, dedup)
-                finally:
-                    ctx.dev_free(d)
-                variants += 2
-        ctx.set_option("merkle_dedup", 0)
+        for mode in ("dense", "off", "regs", "all"):  # Merkle build: dense / small-domain tables / + run-aware registers / + all
+            os.environ.pop("ZIGZ_DENSE_MERKLE", None)
+            os.environ.pop("ZIGZ_RUN_AWARE", None)
+            if mode == "dense":
+                os.environ["ZIGZ_DENSE_MERKLE"] = "1"
+            else:
+                os.environ["ZIGZ_RUN_AWARE"] = mode
+            proof, ns = host.prove(ctx, prog, 0x1000, iregs, 1 << 20)
+            assert ns == ons and proof == oproof, ("rows", case, mode)
+            tr = host.Trace(prog, 0x1000, iregs, 1 << 20)
+            n = 1 << tr.num_vars
+            d = ctx.dev_alloc(43 * max(n, 4) * 4)
+            try:
+                tr.witness_to_device(ctx, d, max(n, 4))
+                assert tr.prove(ctx, d, max(n, 4)) == oproof, ("compact", case, mode)
+            finally:
+                ctx.dev_free(d)
+            variants += 2
         os.environ.pop("ZIGZ_DENSE_MERKLE", None)
+        os.environ.pop("ZIGZ_RUN_AWARE", None)
         assert host.verify(oproof, prog) == "Accept"
         print("case %2d  steps %7d  nv %2d  proof %8d B  oracle %.1f s  %d variants identical" %
               (case, ons, (ons - 1).bit_length() if ons > 1 else 0, len(oproof), t_or, variants), flush=True)

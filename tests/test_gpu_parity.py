@@ -613,45 +613,136 @@ def test_unaligned_device_pointers(ctx):
         ctx.dev_free(o)
 
 
-def test_merkle_dedup_identical_trees(ctx):
-    """Option "merkle_dedup": uniform 256-leaf blocks are chained instead of hashed densely.  Roots and every opened
-    path must equal the dense build and the oracle on columns with every kind of structure."""
+def _run_aware_hashed(cols, levels, tile=4096):
+    """numpy model of k_keccak_runs' flags: nodes hashed (not copied from the left neighbour) on levels 0..levels-1."""
+    total = 0
+    for col in np.asarray(cols):
+        uni = np.ones(col.size, dtype=bool)
+        for l in range(levels):
+            if l:
+                half = col[(1 << (l - 1))::(1 << l)]
+                uni = uni[0::2] & uni[1::2] & (col[::(1 << l)] == half)
+            val = col[::(1 << l)]
+            copy = np.zeros(val.size, dtype=bool)
+            copy[1:] = uni[1:] & uni[:-1] & (val[1:] == val[:-1])
+            copy[::tile] = False
+            total += int((~copy).sum())
+    return total
+
+
+def _tree_words(ctx, job, ncols):
+    d, per_col = job.tree()
+    return ctx.download(d, ncols * per_col // 4).astype(np.uint32)
+
+
+@pytest.mark.parametrize("nv", [15, 16, 18])
+def test_run_aware_levels_identical_trees(ctx, nv):
+    """Option "run_aware_mask": on the levels with >= 16384 nodes a node that is a copy of its left neighbour (both subtrees
+    uniform, same value) is copied instead of hashed.  EVERY node of EVERY tree must equal the dense build's (the device
+    trees are compared word for word), whatever the columns look like and whatever the hint says; roots also vs the oracle."""
     import zigz_amd
-    nv = 17
     N = 1 << nv
-    rng = np.random.default_rng(7)
-    cols = rnd(5150, 43 * N).reshape(43, N).copy()
-    cols[1, :] = 5                       # constant column
-    cols[2, :] = 0                       # all-zero column (e.g. an unused register)
-    cols[3, :] = np.repeat(rnd(1, N // 1000 + 1), 1000)[:N]      # runs of 1000 (not block aligned)
-    cols[4, :] = 9; cols[4, 70000] = 10  # uniform except one leaf
-    cols[5, : N // 2] = 123              # constant first half, random second half
-    cols[6, :] = np.repeat(rnd(2, N // 256), 256)                # every block uniform, all different
-    cols[7, :] = np.arange(N) % 4        # period-4 instruction-field pattern
-    cols[8, -300:] = 0                   # zero padding tail crossing a block boundary
-    points = rnd(77, 43 * nv).reshape(43, nv)
-    points[:, 0] = [int(x) for x in rng.integers(0, N, 43)]     # spread the opened indices
-    points[4, 0] = 70000; points[5, 0] = N // 2 - 1; points[8, 0] = N - 300
-    results = []
-    for dedup in (0, 1):
-        ctx.set_option("merkle_dedup", dedup)
+    nc = 16
+    cols = rnd(5150 + nv, nc * N).reshape(nc, N).copy()
+    cols[1, :] = 5                                               # constant
+    cols[2, :] = 0                                               # all zero (an unused register)
+    cols[3, :] = np.repeat(rnd(1, N // 1000 + 1), 1000)[:N]      # runs of 1000: boundaries anywhere
+    cols[4, :] = 9; cols[4, 70000 % N] = 10                      # uniform except one leaf
+    cols[5, : N // 2] = 123                                      # constant first half, random second half
+    cols[6, :] = np.repeat(rnd(2, N // 256), 256)                # aligned runs of 256, all different
+    cols[7, :] = np.arange(N) % 4                                # period 4: never uniform above the leaves
+    cols[8, -300:] = 0                                           # random, then a zero tail
+    cols[9, :] = np.repeat(rnd(3, N // 4096), 4096)              # runs that are exactly the kernel's tiles
+    cols[10, :] = 1
+    for pos in (63, 64, 65, 4095, 4096, 4097, N - 1, N // 2, N // 2 + 1):   # changes next to chunk / tile boundaries
+        cols[10, pos:] += 1
+    cols[11, :] = np.repeat(rnd(4, N // 2), 2)                   # runs of 2
+    cols[12, :] = np.repeat(rnd(5, N // 3 + 1), 3)[:N]           # runs of 3
+    cols[14, :] = np.repeat(np.arange(N // 512) % 128, 512)      # small-domain AND piecewise constant
+    cols[15, :] = 7                                              # constant but not hinted: dense
+    run_mask = sum(1 << c for c in range(13)) | (1 << 14)
+    trees = []
+    for masks in ((0, 0), (run_mask, 0), (run_mask, 1 << 14), (~0 & ((1 << nc) - 1), 0)):
+        ctx.set_option("run_aware_mask", masks[0])
+        ctx.set_option("small_domain_mask", masks[1])
+        try:
+            job = zigz_amd.CommitJob(ctx, cols=cols)
+            roots = job.roots()
+            st = ctx.stats()
+            trees.append((roots.copy(), _tree_words(ctx, job, nc), st))
+            job.end()
+        finally:
+            ctx.set_option("run_aware_mask", 0)
+            ctx.set_option("small_domain_mask", 0)
+    r0, t0, s0 = trees[0]
+    assert s0["run_aware_columns"] == 0 and s0["keccak_permutations"] == nc * (2 * N - 1)
+    for k, (r, t, st) in enumerate(trees[1:], 1):
+        assert np.array_equal(r, r0), k
+        bad = np.nonzero(t != t0)[0]
+        assert bad.size == 0, (k, "first differing node", int(bad[0]) // 8, "of", t.size // 8)
+    s1 = trees[1][2]
+    levels = nv - 14 + 1                                         # the levels with >= 16384 nodes
+    assert s1["run_aware_columns"] == 14
+    assert s1["run_aware_dense_nodes"] == 14 * sum(N >> l for l in range(levels))
+    assert s1["run_aware_hashed"] == _run_aware_hashed(cols[[c for c in range(nc) if (run_mask >> c) & 1]], levels)
+    assert s1["run_aware_hashed"] < s1["run_aware_dense_nodes"] * 0.75
+    assert s1["keccak_permutations"] == nc * (2 * N - 1) - (s1["run_aware_dense_nodes"] - s1["run_aware_hashed"])
+    assert trees[2][2]["run_aware_columns"] == 13 and trees[2][2]["small_domain_columns"] == 1
+    for c in (1, 3, 4, 10, 12):
+        lv, h = O.merkle_levels(cols[c])
+        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r0[c].tobytes()
+
+
+def test_run_aware_hash_counts(ctx):
+    """What the run-aware levels cost: a constant column needs one hash per tile of 4096 nodes; a change point at most
+    two more per level."""
+    import zigz_amd
+    nv = 16
+    N = 1 << nv
+    levels = nv - 14 + 1                                         # 3 run-aware levels: 65536, 32768, 16384 nodes
+    tiles = sum((N >> l) // 4096 for l in range(levels))
+    cols = np.zeros((4, N), dtype=np.uint64)
+    cols[1, :] = 77
+    cols[2, 12345:] = 3                                          # one change point
+    cols[3, :] = np.repeat(rnd(9, 16), N // 16)                  # 15 change points, all on tile boundaries
+    ctx.set_option("run_aware_mask", 0xF)
+    try:
         job = zigz_amd.CommitJob(ctx, cols=cols)
         roots = job.roots()
         st = ctx.stats()
-        o = job.open_all(points)
         job.end()
-        results.append((roots, o, st))
-    ctx.set_option("merkle_dedup", 0)
-    (r0, o0, s0), (r1, o1, s1) = results
-    assert np.array_equal(r0, r1)
-    for k in o0:
-        assert np.array_equal(o0[k], o1[k]), k
-    assert s0["merkle_blocks"] == 0 and s1["merkle_blocks"] == 43 * (N >> 8)
-    assert s1["merkle_uniform_blocks"] >= 3 * (N >> 8)  # columns 1, 2, 6 at least
-    for c in (1, 3, 4, 5, 8):
+    finally:
+        ctx.set_option("run_aware_mask", 0)
+    assert st["run_aware_columns"] == 4
+    # one hash per tile for the constant columns; column 2's change point costs 1 leaf + 2 nodes on each higher level;
+    # column 3's 15 change points sit on tile starts at the leaves and cost one node each where they do not above
+    assert st["run_aware_hashed"] == 4 * tiles + (1 + 2 * 2) + (8 + 12)
+    assert st["run_aware_hashed"] == _run_aware_hashed(cols, levels)
+    for c in range(4):
         lv, h = O.merkle_levels(cols[c])
-        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r1[c].tobytes()
-        assert O.merkle_verify(r1[c].tobytes(), int(o1["leaves"][c]), o1["siblings"][c].tobytes(), o1["dirs"][c].tobytes())
+        assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == roots[c].tobytes()
+
+
+@pytest.mark.parametrize("n", [32769, 40000, 70001])
+def test_run_aware_single_tree_with_padding(ctx, n):
+    """SimpleMerkleTree.build with the hint set: fewer values than leaves (padding = hashLeaf(0)); root and openings vs the
+    oracle, including the last value, the first padding leaf's sibling and the far end."""
+    import zigz_amd
+    ev = np.repeat(rnd(n, n // 37 + 1), 37)[:n].astype(np.uint64)
+    ctx.set_option("run_aware_mask", 1)
+    try:
+        tree = zigz_amd.SimpleMerkleTree(ctx, ev)
+    finally:
+        ctx.set_option("run_aware_mask", 0)
+    lv, h = O.merkle_levels(ev)
+    npad = 1 << (n - 1).bit_length()
+    assert tree.root_hash == lv[(2 * npad - 2) * 32:(2 * npad - 1) * 32].tobytes()
+    for i in (0, 1, 36, 37, 4095, 4096, n - 2, n - 1):
+        o = tree.open(i)
+        assert o["value"] == int(ev[i])
+        assert O.merkle_verify(tree.root_hash, o["value"], o["siblings"], o["directions"])
+        assert (o["siblings"], o["directions"], o["value"]) == O.merkle_open(ev, i)
+    tree.deinit()
 
 
 # ---------------------------------------------------------------- reference-held KATs, second batch, on the HIP path

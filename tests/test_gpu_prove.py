@@ -220,23 +220,30 @@ def test_prove_random_programs_vs_oracle(ctx):
         assert host.verify(proof, prog) == "Accept"
 
 
-def test_prove_with_merkle_dedup_is_byte_identical(ctx):
-    """The run-aware Merkle build is an optimisation only: same proof bytes (2^17 ADD/XOR trace, 32 of 43 columns constant)."""
+def test_prove_with_run_aware_merkle_is_byte_identical(ctx):
+    """The run-aware Merkle levels are an optimisation only: same proof bytes with the option on every column, on the
+    register columns (Prover's default), and off (2^17 ADD/XOR trace: most registers never change)."""
     from zigz_amd import host
     prog = programs.add_xor_loop(((1 << 17) - 3) // 4)
     t = host.Trace(prog, 0x1000, None, 1 << 18)
     assert t.num_vars == 17
     a = t.prove(ctx)
-    ctx.set_option("merkle_dedup", 1)
+    st_default = ctx.stats()
+    os.environ["ZIGZ_DENSE_MERKLE"] = "1"
     try:
+        dense = t.prove(ctx)
+        st_dense = ctx.stats()
+        ctx.set_option("merkle_dedup", 1)
         b = t.prove(ctx)
         st = ctx.stats()
     finally:
         ctx.set_option("merkle_dedup", 0)
-    assert a == b and st["merkle_uniform_blocks"] > st["merkle_blocks"] // 2
-    # the permutation counter reports what was hashed: a uniform 256-leaf block costs 9 hashes instead of 511
-    assert st["merkle_blocks"] == 43 * (1 << 9)
-    assert st["keccak_permutations"] == 43 * ((2 << 17) - 1) - st["merkle_uniform_blocks"] * 502
+        os.environ.pop("ZIGZ_DENSE_MERKLE", None)
+    assert a == b == dense
+    assert st_dense["run_aware_columns"] == 0 and st_dense["keccak_permutations"] == 43 * ((2 << 17) - 1)
+    assert st_default["run_aware_columns"] == 31 and st["run_aware_columns"] == 43
+    assert st["run_aware_hashed"] < st["run_aware_dense_nodes"] // 2
+    assert st["keccak_permutations"] == 43 * ((2 << 17) - 1) - (st["run_aware_dense_nodes"] - st["run_aware_hashed"])
     assert host.verify(b, prog) == "Accept"
 
 

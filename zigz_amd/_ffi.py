@@ -24,7 +24,8 @@ class KernelStats(C.Structure):
     _fields_ = [("merkle_build_us", C.c_double), ("eval_us", C.c_double), ("path_us", C.c_double),
                 ("bind_us", C.c_double), ("bind_launches", C.c_uint64), ("keccak_permutations", C.c_uint64),
                 ("bind_vec_us", C.c_double), ("bind_vec_launches", C.c_uint64), ("bind_vec_bytes", C.c_uint64),
-                ("merkle_blocks", C.c_uint64), ("merkle_uniform_blocks", C.c_uint64),
+                ("run_aware_columns", C.c_uint64), ("run_aware_dense_nodes", C.c_uint64),
+                ("run_aware_hashed", C.c_uint64), ("run_aware_us", C.c_double),
                 ("keccak_leaves_us", C.c_double), ("keccak_leaves_perms", C.c_uint64),
                 ("keccak_level_wide_us", C.c_double), ("keccak_level_wide_perms", C.c_uint64),
                 ("keccak_level_small_us", C.c_double), ("keccak_level_small_perms", C.c_uint64),
@@ -77,6 +78,7 @@ SIGNATURES = {
     "zigz_commit_begin_dev": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
     "zigz_commit_roots": (C.c_int32, [vp, u8p]),
     "zigz_commit_open_all": (C.c_int32, [vp, u64p, u64p, u64p, u64p, u8p, u8p]),
+    "zigz_commit_job_tree": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),
     "zigz_commit_end": (None, [vp]),
     "zigz_lasso_prove": (C.c_int32, [vp, u64p, C.c_size_t, u64p, C.c_size_t, C.c_size_t, C.c_size_t, szp, u64p, u64p,
                                      u64p, u8p, u8p]),

@@ -20,8 +20,9 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_SLOTS };
 
+constexpr int KEV_MAX = 56;
 struct zigz_ctx {
     int device;
     hipStream_t own_stream;
@@ -38,16 +39,18 @@ struct zigz_ctx {
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
-    bool merkle_dedup;        // run-aware Merkle build (uniform 256-leaf blocks are chained, not hashed densely)
-    unsigned long long *d_dedup_count;
+    uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
+                              // are copied, not hashed); "merkle_dedup" = 1 is all columns
+    unsigned long long *d_run_count;  // nodes hashed by the run-aware launches of the last build
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
     int pool_used;
     uint64_t pool_bytes;
     // kernel-exact timestamps of the Keccak launches of the last batched commit (timing mode): pair i = kev[2i], kev[2i+1]
-    hipEvent_t kev[2 * 40];
-    uint8_t kev_class[40];  // 0 leaves, 1 level (HPT hashes per thread), 2 level (1 hash per thread), 3 top
-    uint64_t kev_perms[40];
+    hipEvent_t kev[2 * KEV_MAX];
+    uint8_t kev_class[KEV_MAX];  // 0 leaves, 1 level (HPT hashes per thread), 2 level (1 hash per thread), 3 table look-ups,
+                                 // 4 run-aware levels
+    uint64_t kev_perms[KEV_MAX];
     int kev_n;
     void *d_flush;          // 1 GiB read-only scratch of zigz_bench_kernel (cold-HBM runs), allocated on first use
     uint64_t small_domain_mask;  // option: columns (bit c) whose values are < 128 by construction -> levels 0-1 by table
@@ -189,7 +192,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     auto fail = [&](hipError_t e) { return e != hipSuccess; };
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
-        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_dedup_count, 64)) ||
+        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTRS * 8)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
@@ -197,7 +200,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 128; i++)
         if (fail(hipEventCreate(&ctx->pool[i]))) st = ZIGZ_ERR_HIP;
-    for (int i = 0; st == ZIGZ_OK && i < 80; i++)
+    for (int i = 0; st == ZIGZ_OK && i < 2 * KEV_MAX; i++)
         if (fail(hipEventCreate(&ctx->kev[i]))) st = ZIGZ_ERR_HIP;
     if (st != ZIGZ_OK) {
         zigz_ctx_destroy(ctx);
@@ -217,14 +220,14 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
         if (ctx->ws[i]) (void)hipFree(ctx->ws[i]);
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
-    if (ctx->d_dedup_count) (void)hipFree(ctx->d_dedup_count);
+    if (ctx->d_run_count) (void)hipFree(ctx->d_run_count);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_roots) (void)hipHostFree(ctx->h_roots);
     for (int i = 0; i < 6; i++)
         if (ctx->ev[i]) (void)hipEventDestroy(ctx->ev[i]);
     for (int i = 0; i < 128; i++)
         if (ctx->pool[i]) (void)hipEventDestroy(ctx->pool[i]);
-    for (int i = 0; i < 80; i++)
+    for (int i = 0; i < 2 * KEV_MAX; i++)
         if (ctx->kev[i]) (void)hipEventDestroy(ctx->kev[i]);
     if (ctx->d_flush) (void)hipFree(ctx->d_flush);
     if (ctx->d_sd_tables) (void)hipFree(ctx->d_sd_tables);
@@ -276,7 +279,8 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (!ctx || !name) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (strcmp(name, "per_round_sumcheck") == 0) { ctx->per_round_sumcheck = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
-    if (strcmp(name, "merkle_dedup") == 0) { ctx->merkle_dedup = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "merkle_dedup") == 0) { ctx->run_aware_mask = value != 0 ? ~0ull : 0; return ZIGZ_OK; }
+    if (strcmp(name, "run_aware_mask") == 0) { ctx->run_aware_mask = (uint64_t)value; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1090,75 +1094,94 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
                                uint8_t *d_tree, size_t ncols, bool record = false) {
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
-    unsigned l_start = 0;
     ctx->stats.small_domain_columns = 0;
+    ctx->stats.run_aware_columns = 0;
+    ctx->stats.run_aware_dense_nodes = 0;
     if (record) ctx->kev_n = 0;
-    // timing mode: every dense Keccak launch carries its own begin / end timestamps, by class
+    // timing mode: every Keccak launch carries its own begin / end timestamps, by class
     KTime kt_store;
     auto stamp = [&](int cls, uint64_t perms) -> const KTime * {
-        if (!record || ctx->kev_n >= 40) return nullptr;
+        if (!record || ctx->kev_n >= KEV_MAX) return nullptr;
         kt_store = KTime{ctx->kev[2 * ctx->kev_n], ctx->kev[2 * ctx->kev_n + 1]};
         ctx->kev_class[ctx->kev_n] = (uint8_t)cls;
         ctx->kev_perms[ctx->kev_n] = perms;
         ctx->kev_n++;
         return &kt_store;
     };
-    if (ctx->merkle_dedup && height >= 17) {  // levels 0..8 run-aware; above the 256-leaf blocks the build is dense
-        const size_t nblocks = npad >> DEDUP_BLOG;
-        void *w;
-        CHK(ws_get(ctx, WS_DEDUP, ncols * nblocks * (1 + (DEDUP_BLOG + 1) * 32) + 256, &w));
-        uint8_t *d_utab = (uint8_t *)w, *d_flags = d_utab + ncols * nblocks * (DEDUP_BLOG + 1) * 32;
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_dedup_count, 0, 8, ctx->stream));
-        launch_dedup_flags(d_vals, val_stride, n_values, npad, d_flags, ctx->d_dedup_count, ncols, ctx->stream);
-        launch_dedup_chains(d_vals, val_stride, n_values, npad, d_flags, d_utab, ncols, ctx->stream);
-        launch_keccak_leaves_dedup(d_vals, val_stride, n_values, npad, d_tree, stride, d_flags, d_utab, ncols, ctx->stream);
-        for (unsigned L = 1; L <= DEDUP_BLOG; L++)
-            launch_keccak_level_dedup(d_tree, stride, npad, L, d_flags, d_utab, ncols, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        ctx->stats.merkle_blocks = (uint64_t)ncols * nblocks;
-        l_start = DEDUP_BLOG;
-    } else {
-        // columns hinted as small-domain (values < 128 by construction): levels 0 and 1 come from two constant tables,
-        // checked per wave and hashed where the bound does not hold; the other columns are hashed densely
-        ColMap H{}, D{};
-        bool use_sd = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
-        if (use_sd) {
-            for (size_t c = 0; c < ncols; c++) {
-                ColMap &m = (ctx->small_domain_mask >> c) & 1 ? H : D;
-                m.c[m.n++] = (uint8_t)c;
-            }
-            use_sd = H.n != 0;
+    // Three kinds of columns:
+    //   H  hinted small-domain (values < 128 by construction): levels 0 and 1 from two constant tables, checked per wave
+    //      and hashed where the bound does not hold;
+    //   R  hinted run-aware (piecewise constant): the levels with >= RUN_TILE nodes by k_keccak_runs, which hashes a node
+    //      only where it is not a copy of its left neighbour -- decided from the values, so the hint cannot make a tree wrong;
+    //   D  the rest: hashed densely.
+    // From the level where every column is complete the launches cover all columns together.
+    ColMap H{}, R{}, D{};
+    const bool sd_ok = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
+    const bool run_ok = ctx->run_aware_mask && npad >= 2 * RUN_MIN_NODES && npad <= ((size_t)1 << 26) && ncols <= 64;
+    if (sd_ok || run_ok)
+        for (size_t c = 0; c < ncols; c++) {
+            ColMap &m = sd_ok && ((ctx->small_domain_mask >> c) & 1) ? H : run_ok && ((ctx->run_aware_mask >> c) & 1) ? R : D;
+            m.c[m.n++] = (uint8_t)c;
         }
-        ctx->stats.merkle_blocks = 0;
-        if (use_sd) {
-            if (!ctx->d_sd_tables) {
-                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
-                HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_fallbacks, 64));
-                launch_sd_tables(ctx->d_sd_tables, ctx->stream);
-            }
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
-            void *todo;
-            CHK(ws_get(ctx, WS_DEDUP, sd_todo_words(npad, H.n) * 4, &todo));
-            launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
-                                    (uint32_t *)todo, ctx->stream, stamp(3, 0));
-            launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
-                                 stamp(0, (uint64_t)D.n * npad), &D);
-            launch_keccak_level(d_tree, stride, tree_level_offset(npad, 0), tree_level_offset(npad, 1), npad / 2, ncols, ctx->stream,
-                                stamp(keccak_level_is_wide(npad / 2, D.n) ? 1 : 2, (uint64_t)D.n * (npad / 2)), &D);
-            ctx->stats.small_domain_columns = H.n;
-            l_start = 1;
-        } else {
-            launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
-        }
+    if (H.n == 0 && R.n == 0) {
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
+    } else if (D.n) {
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
+                             stamp(0, (uint64_t)D.n * npad), &D);
     }
-    for (unsigned l = l_start; l < height; l++) {
+    if (H.n) {
+        if (!ctx->d_sd_tables) {
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
+            HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_fallbacks, 64));
+            launch_sd_tables(ctx->d_sd_tables, ctx->stream);
+        }
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
+        void *todo;
+        CHK(ws_get(ctx, WS_DEDUP, sd_todo_words(npad, H.n) * 4, &todo));
+        launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
+                                (uint32_t *)todo, ctx->stream, stamp(3, 0));
+        ctx->stats.small_domain_columns = H.n;
+    }
+    unsigned run_top = 0;  // R columns: levels 0..run_top come from the run-aware kernel
+    if (R.n) {
+        run_top = height - log2_floor(RUN_MIN_NODES);  // the last level with RUN_MIN_NODES nodes per column
+        // workspace: uniform flags (1 B per node of the levels >= 1) | listed-node bitmap of the current level | its list
+        const size_t uni_bytes = (size_t)ncols * npad, bm_bytes = runs_bitmap_words(npad, R.n) * 8;
+        void *w;
+        CHK(ws_get(ctx, WS_RUNS, uni_bytes + bm_bytes + runs_list_entries(npad, R.n) * 4, &w));
+        uint8_t *uni = (uint8_t *)w;
+        unsigned long long *bitmap = (unsigned long long *)(uni + uni_bytes);
+        uint32_t *list = (uint32_t *)(uni + uni_bytes + bm_bytes);
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
+        for (unsigned l = 0; l <= run_top; l++) {
+            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, npad, bitmap, list, ctx->d_run_count, R,
+                               ctx->stream, stamp(4, 0));
+            ctx->stats.run_aware_dense_nodes += (uint64_t)R.n * (npad >> l);
+        }
+        ctx->stats.run_aware_columns = R.n;
+    }
+    for (unsigned l = 0; l < height; l++) {  // level l + 1 from level l, for the columns that do not have it yet
         const size_t n_out = npad >> (l + 1);
-        if (n_out <= 256) {
+        const bool with_h = l >= 1, with_r = l >= run_top;
+        if (n_out <= 256) {  // all columns are complete here: run_top < height - 9, and H stops at level 1
             launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
             break;
         }
-        launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols,
-                            ctx->stream, stamp(keccak_level_is_wide(n_out, ncols) ? 1 : 2, (uint64_t)ncols * n_out));
+        ColMap m{};
+        const ColMap *pm = nullptr;
+        size_t nc = ncols;
+        if ((H.n && !with_h) || (R.n && !with_r)) {  // a subset: the sorted union of the kinds that take part
+            for (size_t c = 0; c < ncols; c++) {
+                const bool in_h = sd_ok && ((ctx->small_domain_mask >> c) & 1);
+                const bool in_r = !in_h && run_ok && ((ctx->run_aware_mask >> c) & 1);
+                if ((in_h && with_h) || (in_r && with_r) || (!in_h && !in_r)) m.c[m.n++] = (uint8_t)c;
+            }
+            if (m.n == 0) continue;
+            pm = &m;
+            nc = m.n;
+        }
+        launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols, ctx->stream,
+                            stamp(keccak_level_is_wide(n_out, nc) ? 1 : 2, (uint64_t)nc * n_out), pm);
     }
     HIPCHK(ctx, hipGetLastError());
     return ZIGZ_OK;
@@ -1166,8 +1189,8 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
 
 // after the stream has passed the last recorded launch: per-class device time of the last recorded build
 static zigz_status keccak_times_collect(zigz_ctx *ctx) {
-    double us[4] = {0, 0, 0, 0};  // 0 leaves, 1 wide levels, 2 small levels, 3 small-domain table lookups
-    uint64_t perms[4] = {0, 0, 0, 0};
+    double us[5] = {0, 0, 0, 0, 0};  // 0 leaves, 1 wide levels, 2 small levels, 3 small-domain table lookups, 4 run-aware levels
+    uint64_t perms[5] = {0, 0, 0, 0, 0};
     for (int i = 0; i < ctx->kev_n; i++) {
         float ms = 0;
         HIPCHK(ctx, hipEventSynchronize(ctx->kev[2 * i + 1]));
@@ -1182,6 +1205,7 @@ static zigz_status keccak_times_collect(zigz_ctx *ctx) {
     ctx->stats.keccak_level_small_us = us[2];
     ctx->stats.keccak_level_small_perms = perms[2];
     ctx->stats.small_domain_us = us[3];
+    ctx->stats.run_aware_us = us[4];
     ctx->kev_n = 0;
     return ZIGZ_OK;
 }
@@ -1343,8 +1367,8 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         // the two diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later
         unsigned long long *h_cnt = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
         h_cnt[0] = h_cnt[1] = 0;
-        if (ctx->stats.merkle_blocks)
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_dedup_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->stats.run_aware_columns)
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_run_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->stats.small_domain_columns)
             HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
@@ -1401,9 +1425,9 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     HIPCHK(ctx, hipEventSynchronize(job->built));
     memcpy(roots, ctx->h_roots, job->ncols * 32);
     const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
-    ctx->stats.merkle_uniform_blocks = ctx->stats.merkle_blocks ? h_cnt[0] : 0;
-    // a uniform 256-leaf block costs its chain of 9 hashes instead of 256 leaves + 255 nodes
-    ctx->stats.keccak_permutations -= ctx->stats.merkle_uniform_blocks * (uint64_t)((2u << DEDUP_BLOG) - 1 - (DEDUP_BLOG + 1));
+    // the run-aware levels hashed h_cnt[0] of their run_aware_dense_nodes nodes
+    ctx->stats.run_aware_hashed = ctx->stats.run_aware_columns ? h_cnt[0] : 0;
+    ctx->stats.keccak_permutations -= ctx->stats.run_aware_dense_nodes - ctx->stats.run_aware_hashed;
     ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
     if (ctx->timing) {
         float ms = 0;
@@ -1443,6 +1467,15 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
     job->state = 2;
     return ZIGZ_OK;
     ZIGZ_NOTHROW_END(job->ctx)
+}
+
+extern "C" zigz_status zigz_commit_job_tree(zigz_commit_job *job, const void **d_tree, size_t *bytes_per_column) {
+    if (job) ZIGZ_ENTER(job->ctx);
+    if (!job || !d_tree || !bytes_per_column) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(job->ctx, hipEventSynchronize(job->built));
+    *d_tree = job->d_tree;
+    *bytes_per_column = tree_nodes(job->N) * 32;
+    return ZIGZ_OK;
 }
 
 extern "C" void zigz_commit_end(zigz_commit_job *job) {

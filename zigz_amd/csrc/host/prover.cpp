@@ -86,6 +86,13 @@ bool Prover::defaultSmallDomain() {
     return !(e && e[0] == '1');
 }
 
+int Prover::defaultRunAware() {
+    if (!defaultSmallDomain()) return 0;
+    const char *e = getenv("ZIGZ_RUN_AWARE");
+    if (!e || !e[0]) return 1;
+    return strcmp(e, "off") == 0 ? 0 : strcmp(e, "all") == 0 ? 2 : 1;
+}
+
 void Prover::bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs) {
     transcript_.reset();                                   // prover.zig:91
     transcript_.appendBytes(program_hash.data(), 32);      // :98-100
@@ -244,11 +251,23 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
         check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
     }
+    // The register columns x1..x31 are piecewise constant by construction: a step writes at most one register
+    // (VMState.writeReg, src/vm/state.zig), so together they change at most once per step.  Their large Merkle levels are
+    // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
+    // the values on the device; identical trees for any input).  run_aware == 2 hints every column that is not small-domain.
+    if (run_aware) {
+        const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
+        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : 0x7fffffffull << 2;
+        check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
+    }
     struct MaskReset {
         zigz_ctx *ctx;
-        bool on;
-        ~MaskReset() { if (on) (void)zigz_ctx_set_option(ctx, "small_domain_mask", 0); }
-    } mask_reset{ctx_, small_domain_tables};
+        bool sd, ra;
+        ~MaskReset() {
+            if (sd) (void)zigz_ctx_set_option(ctx, "small_domain_mask", 0);
+            if (ra) (void)zigz_ctx_set_option(ctx, "run_aware_mask", 0);
+        }
+    } mask_reset{ctx_, small_domain_tables, run_aware != 0};
     if (witness)
         check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
                                       (size_t)1 << num_vars, num_vars, &guard.job));

@@ -301,6 +301,11 @@ class Prover {  // src/prover/prover.zig
     // environment variable ZIGZ_DENSE_MERKLE=1 turns it off process-wide (A/B measurements)
     bool small_domain_tables = defaultSmallDomain();
     static bool defaultSmallDomain();
+    // run-aware Merkle levels (identical trees): 0 off, 1 the register columns x1..x31 (at most one of them changes per
+    // step, whatever the program), 2 every column that is not small-domain.  Environment: ZIGZ_RUN_AWARE=off|regs|all
+    // (default regs); ZIGZ_DENSE_MERKLE=1 turns this off too
+    int run_aware = defaultRunAware();
+    static int defaultRunAware();
 
   private:
     void bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs);  // :91-110

@@ -734,119 +734,236 @@ __global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, 
     }
 }
 
-// ------------------------------------------------------------------ run-aware Merkle build (optional)
-// one wave per 256-leaf block: uniform iff all 256 (padded) values are equal
-__global__ __launch_bounds__(TPB) void k_dedup_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                     size_t npad, uint8_t *__restrict__ flags,
-                                                     unsigned long long *__restrict__ count) {
-    const size_t col = blockIdx.y;
-    const size_t blk = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
-    const size_t nblocks = npad >> DEDUP_BLOG;
-    if (blk >= nblocks) return;
-    const unsigned lane = threadIdx.x & 63;
+// ------------------------------------------------------------------ run-aware Merkle levels (node-granular)
+// A node whose subtree holds one value everywhere ("uniform") has the same digest as its left neighbour when that one is
+// uniform with the same value.  Per level, three launches over the hinted columns:
+//   k_runs_flags  one workgroup per tile of RUN_TILE consecutive nodes: uniform?  (children uniform + the two halves' first
+//                 values equal; leaves are uniform), copy-of-left?  The nodes that are NOT copies go onto ONE device-wide
+//                 list (a tile reserves its block with one atomic); the first node of a tile is always listed, so the
+//                 copies of a tile never depend on another tile.  The per-chunk "listed" masks go to a bitmap.
+//   k_runs_hash   a fixed grid strides over the list: one hash per thread with every lane busy, whatever mix of constant
+//                 and busy columns produced the list (tile-local hashing left the chip idle behind the few busy tiles:
+//                 2.2 ms for the leaves of 31 columns, 0.22 ms for a level of 4096 nodes)
+//   k_runs_fill   per tile: every node takes the digest of the nearest listed node at or before it (find-last-set in
+//                 the chunk's mask, else the last listed node before the chunk); each store instruction writes 1 KiB of
+//                 consecutive tree (16 B per lane, two lanes per node), chunks without copies are skipped.
+// Every digest of the level ends up in HBM, so the tree is the dense one, bit for bit, for ANY input: the values decide,
+// not a hint.  Cost: (change points + tiles) hashes per level instead of one per node, + 32 B written per node.
+__device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, const Digest &d) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
+    q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
+}
+constexpr unsigned RUN_NODE_BITS = 26;  // list entry = column << 26 | node
+constexpr unsigned RUN_SUBS = 32;       // sub-lists per level (power of two)
+
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                    size_t npad, unsigned L, uint8_t *__restrict__ uni, size_t uni_stride,
+                                                    unsigned long long *__restrict__ bitmap, uint32_t *__restrict__ list,
+                                                    size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap cmap) {
+    constexpr int CH = RUN_TILE / 64;  // chunks of 64 nodes per tile
+    constexpr int NPT = RUN_TILE / TPB;  // nodes per thread
+    static_assert(CH == 64, "one lane per chunk in the scan");
+    __shared__ uint32_t s_x[RUN_TILE];  // first value of every node of the tile
+    __shared__ uint8_t s_u[RUN_TILE];   // uniform?
+    __shared__ unsigned long long s_need[CH];
+    __shared__ unsigned s_off[CH + 1];
+    __shared__ unsigned long long s_base;
+    const size_t col = cmap.c[blockIdx.y];
     const uint32_t *v = vals + col * val_stride;
-    const size_t base = (blk << DEDUP_BLOG) + (size_t)lane * 4;
-    uint32_t x[4];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
+    const size_t n_nodes = npad >> L;
+    // uniform flags of level l >= 1 live at uni[col][npad - (npad >> (l - 1)) + k]
+    const uint8_t *u_in = uni + col * uni_stride + (L >= 2 ? npad - (npad >> (L - 2)) : 0);
+    uint8_t *u_out = uni + col * uni_stride + (L >= 1 ? npad - (npad >> (L - 1)) : 0);
+    // all loads of the thread's 16 nodes first (independent, in flight together), then the flags
+    uint32_t x[NPT], y[NPT];
+    unsigned short uu[NPT];
 #pragma unroll
-    for (int j = 0; j < 4; j++) x[j] = base + j < n_values ? v[base + j] : 0;
-    const uint32_t first = __builtin_amdgcn_readfirstlane(x[0]);
-    const bool eq = x[0] == first && x[1] == first && x[2] == first && x[3] == first;
-    const bool uni = __all(eq);
-    if (lane == 0) {
-        flags[col * nblocks + blk] = uni ? 1 : 0;
-        if (uni) atomicAdd(count, 1ull);
+    for (int j = 0; j < NPT; j++) {
+        const size_t i = (tile_base + j * TPB + threadIdx.x) << L;
+        x[j] = i < n_values ? v[i] : 0u;  // padding leaves are hashLeaf(0), merkle_tree.zig:302-306
+    }
+    if (!LEAF) {
+#pragma unroll
+        for (int j = 0; j < NPT; j++) {
+            const size_t k = tile_base + j * TPB + threadIdx.x;
+            const size_t i1 = (k << L) + ((size_t)1 << (L - 1));  // first value of the right half
+            y[j] = i1 < n_values ? v[i1] : 0u;
+            uu[j] = L >= 2 ? *reinterpret_cast<const unsigned short *>(u_in + 2 * k) : (unsigned short)0x0101;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const unsigned li = j * TPB + threadIdx.x;
+        const bool u = LEAF ? true : (x[j] == y[j] && uu[j] == 0x0101);  // both children uniform and the halves agree
+        s_x[li] = x[j];
+        s_u[li] = u ? 1 : 0;
+        if (!LEAF) u_out[tile_base + li] = u ? 1 : 0;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const unsigned li = j * TPB + threadIdx.x;
+        // a copy of its left neighbour: both uniform, same value (the first node of a tile is always listed)
+        const bool copy = li != 0 && s_u[li] && s_u[li - 1] && s_x[li] == s_x[li - 1];
+        const unsigned long long need = __ballot(!copy);
+        if (lane == 0) {
+            s_need[j * (TPB / 64) + wave] = need;
+            bitmap[(blockIdx.y * n_nodes + tile_base) / 64 + j * (TPB / 64) + wave] = need;
+        }
+    }
+    __syncthreads();
+    if (wave == 0) {
+        const unsigned cnt = (unsigned)__builtin_popcountll(s_need[lane]);
+        unsigned incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned a = __shfl_up(incl, off, 64);
+            if (lane >= (unsigned)off) incl += a;
+        }
+        s_off[lane] = incl - cnt;
+        if (lane == 63) {
+            s_off[CH] = incl;
+            // this tile's block of the level's list.  The list is split into RUN_SUBS sub-lists with a counter each, every
+            // counter in a 128-byte line of its own: reservations into ONE word serialise at ~15 ns each (8 k tiles: 0.2 ms)
+            const unsigned sub = (blockIdx.y * gridDim.x + blockIdx.x) % RUN_SUBS;
+            s_base = (size_t)sub * sub_cap + atomicAdd(&ctr[(1 + sub) * 16], (unsigned long long)incl);
+        }
+    }
+    __syncthreads();
+    const size_t base = s_base;
+#pragma unroll
+    for (int j = 0; j < NPT; j++) {
+        const unsigned c = j * (TPB / 64) + wave;
+        const unsigned long long m = s_need[c];
+        if ((m >> lane) & 1)
+            list[base + s_off[c] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] =
+                ((uint32_t)col << RUN_NODE_BITS) | (uint32_t)(tile_base + c * 64 + lane);
     }
 }
 
-// one thread per block: the 9-hash chain of a uniform block (masked for the others)
-__global__ __launch_bounds__(TPB) void k_dedup_chains(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                      size_t npad, const uint8_t *__restrict__ flags,
-                                                      uint8_t *__restrict__ utab) {
-    const size_t col = blockIdx.y;
-    const size_t blk = (size_t)blockIdx.x * TPB + threadIdx.x;
-    const size_t nblocks = npad >> DEDUP_BLOG;
-    if (blk >= nblocks || !flags[col * nblocks + blk]) return;
-    const size_t i0 = blk << DEDUP_BLOG;
-    const uint64_t x = i0 < n_values ? vals[col * val_stride + i0] : 0;
-    uint8_t *u = utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32;
-    Digest d = sha3_leaf(x);
-    store_digest(u, 0, d);
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_runs_hash(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                   size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes, unsigned L,
+                                                   const uint32_t *__restrict__ list, size_t sub_cap,
+                                                   unsigned long long *__restrict__ ctr) {
+    __shared__ unsigned long long s_start[RUN_SUBS + 1];  // exclusive prefix of the sub-list lengths
+    if (threadIdx.x < 64) {
+        static_assert(RUN_SUBS <= 64, "one lane per sub-list");
+        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + threadIdx.x) * 16] : 0;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long a = __shfl_up(incl, off, 64);
+            if (threadIdx.x >= (unsigned)off) incl += a;
+        }
+        if (threadIdx.x < RUN_SUBS) s_start[threadIdx.x] = incl - c;
+        if (threadIdx.x == RUN_SUBS - 1) {
+            s_start[RUN_SUBS] = incl;
+            if (blockIdx.x == 0) atomicAdd(&ctr[0], incl);  // nodes hashed by the whole build
+        }
+    }
+    __syncthreads();
+    const size_t cnt = s_start[RUN_SUBS];
+    const size_t out_off = 2 * npad - 2 * (npad >> L);
+    const size_t in_off = LEAF ? 0 : 2 * npad - 2 * (npad >> (L - 1));
 #pragma unroll 1
-    for (unsigned l = 1; l <= DEDUP_BLOG; l++) {
-        d = sha3_node(d, d);
-        store_digest(u, l, d);
+    for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < cnt; e += (size_t)gridDim.x * TPB) {
+        unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
+#pragma unroll
+        for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
+            if (s_start[sub + step] <= e) sub += step;
+        const uint32_t ent = list[(size_t)sub * sub_cap + (e - s_start[sub])];
+        const size_t col = ent >> RUN_NODE_BITS, k = ent & ((1u << RUN_NODE_BITS) - 1);
+        uint8_t *t = tree + col * tree_stride_nodes * 32;
+        Digest d;
+        if (LEAF) d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
+        else d = sha3_node(load_digest(t, in_off + 2 * k), load_digest(t, in_off + 2 * k + 1));
+        store_digest_plain(t, out_off + k, d);
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_keccak_leaves_dedup(const uint32_t *__restrict__ vals, size_t val_stride,
-                                                             size_t n_values, size_t npad, uint8_t *__restrict__ tree,
-                                                             size_t tree_stride_nodes, const uint8_t *__restrict__ flags,
-                                                             const uint8_t *__restrict__ utab) {
-    const size_t col = blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
-    const uint32_t *v = vals + col * val_stride;
-    const size_t nblocks = npad >> DEDUP_BLOG;
+__global__ __launch_bounds__(TPB) void k_runs_fill(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad, unsigned L,
+                                                   const unsigned long long *__restrict__ bitmap, ColMap cmap) {
+    constexpr int CH = RUN_TILE / 64;
+    __shared__ unsigned long long s_need[CH];
+    __shared__ int s_prev[CH];
+    const size_t col = cmap.c[blockIdx.y];
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const size_t n_nodes = npad >> L;
+    const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
+    uint8_t *out = tree + (col * tree_stride_nodes + 2 * npad - 2 * n_nodes + tile_base) * 32;  // this tile's digests
+    if (wave == 0) {
+        const unsigned long long m = bitmap[(blockIdx.y * n_nodes + tile_base) / 64 + lane];
+        s_need[lane] = m;
+        int last = m ? (int)(lane * 64 + 63 - __builtin_clzll(m)) : -1;  // last listed node at or before the end of the chunk
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int b = __shfl_up(last, off, 64);
+            if (lane >= (unsigned)off) last = last > b ? last : b;
+        }
+        int prev = __shfl_up(last, 1, 64);
+        if (lane == 0) prev = 0;
+        s_prev[lane] = prev;
+    }
+    __syncthreads();
 #pragma unroll 1
-    for (int h = 0; h < HPT; h++) {
-        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
-        if (i >= npad) return;
-        const size_t blk = i >> DEDUP_BLOG;  // wave-uniform: a wave's 64 leaves lie in one block
-        if (flags[col * nblocks + blk]) {
-            store_digest(t, i, load_digest(utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32, 0));
-        } else {
-            const uint64_t x = i < n_values ? v[i] : 0;
-            store_digest(t, i, sha3_leaf(x));
+    for (int j = 0; j < RUN_TILE / TPB; j++) {
+        const unsigned c = j * (TPB / 64) + wave;
+        const unsigned long long m = s_need[c];
+        if (m == ~0ull) continue;  // wave-uniform: every node of the chunk was hashed
+#pragma unroll
+        for (int h = 0; h < 2; h++) {  // 32 nodes x 2 halves of 16 B per store instruction: 1 KiB of consecutive tree
+            const unsigned q = 32 * h + (lane >> 1);
+            const unsigned long long mm = m & (q == 63 ? ~0ull : ((2ull << q) - 1));  // listed nodes at or before q
+            const int leader = mm ? (int)(c * 64 + 63 - __builtin_clzll(mm)) : s_prev[c];
+            const uint4 piece = *reinterpret_cast<const uint4 *>(out + (size_t)leader * 32 + (lane & 1) * 16);
+            nt_store16(reinterpret_cast<uint4 *>(out + (size_t)(c * 64 + q) * 32 + (lane & 1) * 16), piece);
         }
     }
 }
 
-__global__ __launch_bounds__(TPB) void k_keccak_level_dedup(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                                            unsigned L, const uint8_t *__restrict__ flags,
-                                                            const uint8_t *__restrict__ utab) {
-    const size_t col = blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
-    const size_t n_out = npad >> L, nblocks = npad >> DEDUP_BLOG;
-    const size_t in_off = 2 * npad - 2 * (npad >> (L - 1)), out_off = 2 * npad - 2 * n_out;
-#pragma unroll 1
-    for (int h = 0; h < HPT; h++) {
-        const size_t i = ((size_t)blockIdx.x * HPT + h) * TPB + threadIdx.x;
-        const bool live = i < n_out;
-        const size_t blk = live ? i >> (DEDUP_BLOG - L) : 0;
-        const bool uni = live && flags[col * nblocks + blk];
-        if (__all(uni || !live)) {  // the whole wave lies in uniform blocks: copy the chain digests
-            if (live) store_digest(t, out_off + i, load_digest(utab + (col * nblocks + blk) * (DEDUP_BLOG + 1) * 32, L));
-        } else if (live) {
-            Digest l = load_digest(t, in_off + 2 * i), r = load_digest(t, in_off + 2 * i + 1);
-            store_digest(t, out_off + i, sha3_node(l, r));
-        }
-    }
+// capacity of one sub-list: its share of the tiles of the widest level (the leaves), every node listed
+static size_t runs_sub_cap(size_t npad, size_t ncols) {
+    const size_t tiles = ncols * (npad / RUN_TILE);
+    return (tiles + RUN_SUBS - 1) / RUN_SUBS * RUN_TILE;
 }
+size_t runs_list_entries(size_t npad, size_t ncols) { return runs_sub_cap(npad, ncols) * RUN_SUBS; }
+size_t runs_bitmap_words(size_t npad, size_t ncols) { return ncols * npad / 64; }
 
-void launch_dedup_flags(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_flags,
-                        unsigned long long *d_count, size_t ncols, hipStream_t s) {
-    const size_t nblocks = npad >> DEDUP_BLOG;
-    dim3 grid((unsigned)((nblocks + TPB / 64 - 1) / (TPB / 64)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_dedup_flags, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_flags, d_count);
-}
-void launch_dedup_chains(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, const uint8_t *d_flags,
-                         uint8_t *d_utab, size_t ncols, hipStream_t s) {
-    const size_t nblocks = npad >> DEDUP_BLOG;
-    dim3 grid((unsigned)((nblocks + TPB - 1) / TPB), (unsigned)ncols);
-    hipLaunchKernelGGL(k_dedup_chains, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_flags, d_utab);
-}
-void launch_keccak_leaves_dedup(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                                size_t tree_stride_nodes, const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols,
-                                hipStream_t s) {
-    dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_keccak_leaves_dedup, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                       tree_stride_nodes, d_flags, d_utab);
-}
-void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned out_level,
-                               const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols, hipStream_t s) {
-    const size_t n_out = npad >> out_level;
-    dim3 grid((unsigned)((n_out + TPB * HPT - 1) / (TPB * HPT)), (unsigned)ncols);
-    hipLaunchKernelGGL(k_keccak_level_dedup, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, out_level, d_flags,
-                       d_utab);
+void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, size_t uni_stride,
+                        unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
+                        hipStream_t s, const KTime *kt) {
+    if (cols.n == 0) return;
+    const size_t n_nodes = npad >> level;  // caller: n_nodes >= RUN_TILE (a power of two, so a multiple of it)
+    const size_t sub_cap = runs_sub_cap(npad, cols.n);
+    dim3 grid((unsigned)(n_nodes / RUN_TILE), (unsigned)cols.n);
+    size_t hash_wgs = (n_nodes * cols.n + TPB - 1) / TPB;
+    if (hash_wgs > 16384) hash_wgs = 16384;  // one hash per thread for lists up to 4 M entries; longer lists are strided over
+    // the sub-list counters restart at every level (word 0, the build's total, stays)
+    (void)hipMemsetAsync(d_ctr + 16, 0, RUN_SUBS * 128, s);
+    // timing: the three launches of a level are bracketed as one (start of the first, stop of the last)
+    if (level == 0) {
+        if (kt) hipExtLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
+                                      npad, level, d_uni, uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+        else hipLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
+                                uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+        hipLaunchKernelGGL(k_runs_hash<true>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                           tree_stride_nodes, level, d_list, sub_cap, d_ctr);
+    } else {
+        if (kt) hipExtLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
+                                      npad, level, d_uni, uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+        else hipLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
+                                uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+        hipLaunchKernelGGL(k_runs_hash<false>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                           tree_stride_nodes, level, d_list, sub_cap, d_ctr);
+    }
+    if (kt) hipExtLaunchKernelGGL(k_runs_fill, grid, dim3(TPB), 0, s, nullptr, kt->stop, 0, d_tree, tree_stride_nodes, npad, level,
+                                  d_bitmap, cols);
+    else hipLaunchKernelGGL(k_runs_fill, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, level, d_bitmap, cols);
 }
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,

@@ -98,28 +98,26 @@ void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint3
 void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
                          uint32_t *d_out, size_t ncols, hipStream_t s);
 
-// Optional run-aware Merkle build ("merkle_dedup").  zkVM witness columns are mostly piecewise constant (unused or
-// rarely written registers, constant instruction fields, zero padding), and the subtree over 256 equal leaves is a
-// chain of 9 hashes instead of 511.  flags[c][k] = 1 when block k (256 leaves) of column c is uniform; utab[c][k][l],
-// l = 0..8, are the digests of the uniform subtree of 2^l leaves of that value.  The leaf / level kernels then copy
-// utab instead of hashing wherever a whole wave lies in uniform blocks.  Output trees are bit-identical.
-constexpr unsigned DEDUP_BLOG = 8;  // log2 of the block size
-void launch_dedup_flags(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_flags,
-                        unsigned long long *d_count, size_t ncols, hipStream_t s);
-void launch_dedup_chains(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, const uint8_t *d_flags,
-                         uint8_t *d_utab, size_t ncols, hipStream_t s);
-void launch_keccak_leaves_dedup(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                                size_t tree_stride_nodes, const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols,
-                                hipStream_t s);
-// level `out_level` (1..8) from level out_level-1
-void launch_keccak_level_dedup(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned out_level,
-                               const uint8_t *d_flags, const uint8_t *d_utab, size_t ncols, hipStream_t s);
-
 // The columns a Keccak launch works on: blockIdx.y = k -> column c[k] (n == 0: identity, column = blockIdx.y).
 struct ColMap {
     uint8_t n;
     uint8_t c[64];
 };
+// Run-aware level `level` (0 = leaves) of the columns in `cols` (three launches: flags + list, hash the list, fill the
+// copies): identical digests, but a node that is a copy of its left neighbour (both subtrees uniform, same value) is
+// copied instead of hashed.  d_uni: per column `uni_stride` >= npad bytes of uniform flags for the levels >= 1;
+// d_bitmap: runs_bitmap_words() u64; d_list: runs_list_entries() u32; d_ctr: RUN_CTRS u64, d_ctr[0] += nodes hashed
+// (zeroed by the caller before level 0; the rest are the level's list counters).  Requires (npad >> level) >= RUN_TILE and npad <= 2^26
+// (the caller stops at RUN_MIN_NODES).
+constexpr unsigned RUN_TILE = 4096;
+constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
+constexpr unsigned RUN_CTRS = 33 * 16;  // u64 words: the build's total + 32 sub-list counters, each in a 128-byte line
+size_t runs_list_entries(size_t npad, size_t ncols);
+size_t runs_bitmap_words(size_t npad, size_t ncols);
+void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, size_t uni_stride,
+                        unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
+                        hipStream_t s, const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,

@@ -359,6 +359,12 @@ class CommitJob:
         return dict(values=values[:nc], indices=idx[:nc], leaves=leaves[:nc],
                     siblings=sib[: nc * nv * 32].reshape(nc, nv, 32), dirs=dirs[: nc * nv].reshape(nc, nv))
 
+    def tree(self):
+        """(device address, bytes per column) of the built trees, internal node form -- for node-by-node comparisons."""
+        d, n = vp(), C.c_size_t()
+        self.ctx.check(lib.zigz_commit_job_tree(self.j, C.byref(d), C.byref(n)))
+        return d.value, n.value
+
     def end(self):
         if self.j:
             lib.zigz_commit_end(self.j)
