@@ -236,9 +236,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=8, help="independent traces proven concurrently per GPU per step "
-                    "(one proof alone is bound by its sequential host transcript, ~28 ms on one core against ~6 ms of GPU "
-                    "work: 4 lanes are host-bound at ~137 M steps/s, 6 reach 160-163 M, 8 keep the GPU saturated: 165-180 M)")
+    ap.add_argument("--batch", type=int, default=16, help="independent traces proven concurrently per GPU per step.  One proof "
+                    "alone is bound by its sequential host transcript (~27 ms on one core) against ~2.7 ms of GPU work with the "
+                    "default Merkle build, so a proving service runs one host thread + one HIP stream per trace: 8 lanes "
+                    "~290 M steps/s (host-bound), 12 ~430 M, 16 ~500 M; more lanes than the 16 cores of one GPU's share of the "
+                    "host gain nothing")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
@@ -587,10 +589,15 @@ def main():
         sa = solo["acc"] if solo else acc  # kernel-time shares from the single-proof leg (no overlap between proofs)
         share = sa["keccak_leaves_us"] / max(sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] +
                                             sa["small_domain_us"] + sa["run_aware_us"] + sa["eval_us"], 1e-9)
+        hash_share = (sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] + sa["run_aware_us"]) / max(
+            sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] + sa["small_domain_us"] +
+            sa["run_aware_us"] + sa["eval_us"], 1e-9)
         roof = {
-            "kernel": "k_keccak_leaves (SHA3-256 leaf hashes of the densely hashed witness columns: 1 Keccak-f[1600] = %d VALU "
-                      "instructions per 4 B read + 32 B written; the dominant kernel: %.0f %% of the kernel time of a proof, all "
-                      "Keccak kernels together 97 %%)" % (ic["leaves"], 100.0 * share),
+            "kernel": "k_keccak_leaves (SHA3-256 leaf hashes: 1 Keccak-f[1600] = %d VALU instructions per 4 B read + 32 B written), "
+                      "measured back to back over 43 x 2^%d leaves.  The same permutation code is every hashing kernel of a proof "
+                      "(k_keccak_leaves %.0f %% of the kernel time of a lone proof under --merkle %s; with k_keccak_level, "
+                      "k_keccak_top and the run-aware levels -- k_runs_flags / _hash / _fill -- %.0f %%)"
+                      % (ic["leaves"], nv, 100.0 * share, args.merkle, 100.0 * hash_share),
             "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
             "valu_instr_per_hash": ic["leaves"],
             "timed_region_achieved": tr_ach, "timed_region_frac": tr_ach / VALU_PEAK_TOPS,

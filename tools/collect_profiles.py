@@ -89,8 +89,9 @@ def main():
         shutil.copy(newest("gpurun_out/p2_%s/*/*kernel_stats.csv" % tag), "profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))
     for src_, dst in (("p2_kernels.json", "kernels.json"), ("p2_kernels_plain.json", "kernels_unprofiled.json"),
                       ("p2_bench.json", "final_bench.json"), ("p2_bench_b1.json", "final_bench_b1.json"),
-                      ("p2_bench_b4.json", "final_bench_b4.json"), ("p2_bench_b6.json", "final_bench_b6.json"),
-                      ("p2_bench_dense.json", "final_bench_dense_merkle.json"), ("p2_bench_dedup8.json", "final_bench_dedup_b8.json"),
+                      ("p2_bench_b8.json", "final_bench_b8.json"), ("p2_bench_b12.json", "final_bench_b12.json"),
+                      ("p2_bench_tables_b8.json", "final_bench_merkle_tables_b8.json"),
+                      ("p2_bench_dense_b8.json", "final_bench_merkle_dense_b8.json"), ("p2_bench_all.json", "final_bench_merkle_all.json"),
                       ("p2_bench_gpus2_rehearsal.json", "bench_gpus2_rehearsal.json"), ("p2_lasso.json", "lasso.json"),
                       ("p2_sumcheck.json", "sumcheck.json"), ("p2_extra.json", "extra.json"), ("p2_configs.jsonl", "configs.jsonl")):
         if os.path.exists(os.path.join("gpurun_out", src_)):
@@ -99,7 +100,20 @@ def main():
         print(tag)
         for r in list(csv.DictReader(open("profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))))[:8]:
             print("  %-60s calls=%5s avg_us=%10.2f pct=%s" % (r["Name"][:60], r["Calls"], float(r["AverageNs"]) / 1e3, r.get("Percentage")))
-    for name in ("final_bench", "final_bench_b1", "final_bench_b4", "final_bench_b6", "final_bench_dense_merkle"):
+    one = glob.glob("gpurun_out/p2_one/**/*kernel_trace.csv", recursive=True)
+    if one:  # the launches of the last of three lone proofs, in order: name, grid, start (us from the first), duration (us)
+        rows = sorted(csv.DictReader(open(max(one, key=os.path.getmtime))), key=lambda r: int(r["Start_Timestamp"]))
+        rows = [r for r in rows if "keccak" in r["Kernel_Name"] or "k_runs" in r["Kernel_Name"]]
+        last = rows[-(len(rows) // 3):]
+        t0 = int(last[0]["Start_Timestamp"])
+        with open("profiles/%s_one_proof_launches.csv" % ROUND, "w") as f:
+            f.write("kernel,grid_x,grid_y,start_us,duration_us\n")
+            for r in last:
+                f.write("%s,%s,%s,%.1f,%.1f\n" % (r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size_X", ""),
+                                                  r.get("Grid_Size_Y", ""), (int(r["Start_Timestamp"]) - t0) / 1e3,
+                                                  (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
+    for name in ("final_bench", "final_bench_b1", "final_bench_b8", "final_bench_b12", "final_bench_merkle_tables_b8",
+                 "final_bench_merkle_dense_b8", "final_bench_merkle_all"):
         pth = "profiles/%s_%s.json" % (ROUND, name)
         if not os.path.exists(pth):
             continue

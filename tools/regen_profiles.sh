@@ -14,17 +14,19 @@ python3 bench.py --kernels --kernel-iters 10 > gpurun_out/p2_kernels_plain.json 
 # (2) whole proofs: one at a time (kernel quality inside a proof) and the default bench workload
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_b1 -- python3 bench.py --steps 5 --warmup 1 --batch 1 --no-cpu-baseline --no-extras > gpurun_out/p2_b1.json 2> gpurun_out/p2_b1.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_bdef -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/p2_bdef.json 2> gpurun_out/p2_bdef.err
+rocprofv3 --kernel-trace --output-format csv -d gpurun_out/p2_one -o t -- python3 tools/trace_one_proof.py > /dev/null 2> gpurun_out/p2_one.err
 # (3) Lasso and the real sumcheck
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_lasso -- python3 bench.py --lasso > gpurun_out/p2_lasso.json 2> gpurun_out/p2_lasso.err
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p2_sumcheck -- python3 tools/measure_extra.py --sumcheck-only > gpurun_out/p2_sumcheck.json 2> gpurun_out/p2_sumcheck.err
 # (4) bench lines
 python3 bench.py > gpurun_out/p2_bench.json 2> gpurun_out/p2_bench.err
 python3 bench.py --batch 1 --no-cpu-baseline > gpurun_out/p2_bench_b1.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --batch 4 --no-cpu-baseline > gpurun_out/p2_bench_b4.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --batch 6 --no-cpu-baseline > gpurun_out/p2_bench_b6.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --dense-merkle --no-cpu-baseline > gpurun_out/p2_bench_dense.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --dedup --batch 8 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_dedup8.json 2>> gpurun_out/p2_bench.err
-ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 3 > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_b8.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 12 --no-cpu-baseline > gpurun_out/p2_bench_b12.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --merkle tables --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_tables_b8.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --merkle dense --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_dense_b8.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --merkle all --no-cpu-baseline --no-extras > gpurun_out/p2_bench_all.json 2>> gpurun_out/p2_bench.err
+ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --batch 6 > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
 python3 tools/measure_extra.py > gpurun_out/p2_extra.json 2>> gpurun_out/p2_bench.err
 # (5) BASELINE configs 2-5 at full size on one GPU
 rm -f gpurun_out/p2_configs.jsonl

@@ -1145,16 +1145,18 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     unsigned run_top = 0;  // R columns: levels 0..run_top come from the run-aware kernel
     if (R.n) {
         run_top = height - log2_floor(RUN_MIN_NODES);  // the last level with RUN_MIN_NODES nodes per column
-        // workspace: uniform flags (1 B per node of the levels >= 1) | listed-node bitmap of the current level | its list
-        const size_t uni_bytes = (size_t)ncols * npad, bm_bytes = runs_bitmap_words(npad, R.n) * 8;
+        // workspace: per hinted column and node of the levels >= 1 a "uniform?" byte and a "first value" word | the
+        // listed-node bitmap of the current level | its list
+        const size_t uni_bytes = (size_t)R.n * npad, fv_bytes = uni_bytes * 4, bm_bytes = runs_bitmap_words(npad, R.n) * 8;
         void *w;
-        CHK(ws_get(ctx, WS_RUNS, uni_bytes + bm_bytes + runs_list_entries(npad, R.n) * 4, &w));
-        uint8_t *uni = (uint8_t *)w;
-        unsigned long long *bitmap = (unsigned long long *)(uni + uni_bytes);
-        uint32_t *list = (uint32_t *)(uni + uni_bytes + bm_bytes);
+        CHK(ws_get(ctx, WS_RUNS, fv_bytes + bm_bytes + runs_list_entries(npad, R.n) * 4 + uni_bytes, &w));
+        uint32_t *fv = (uint32_t *)w;
+        unsigned long long *bitmap = (unsigned long long *)((uint8_t *)w + fv_bytes);
+        uint32_t *list = (uint32_t *)((uint8_t *)w + fv_bytes + bm_bytes);
+        uint8_t *uni = (uint8_t *)(list + runs_list_entries(npad, R.n));
         HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
         for (unsigned l = 0; l <= run_top; l++) {
-            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, npad, bitmap, list, ctx->d_run_count, R,
+            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, fv, bitmap, list, ctx->d_run_count, R,
                                ctx->stream, stamp(4, 0));
             ctx->stats.run_aware_dense_nodes += (uint64_t)R.n * (npad >> l);
         }

@@ -758,7 +758,7 @@ constexpr unsigned RUN_SUBS = 32;       // sub-lists per level (power of two)
 
 template <bool LEAF>
 __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                    size_t npad, unsigned L, uint8_t *__restrict__ uni, size_t uni_stride,
+                                                    size_t npad, unsigned L, uint8_t *__restrict__ uni, uint32_t *__restrict__ fv,
                                                     unsigned long long *__restrict__ bitmap, uint32_t *__restrict__ list,
                                                     size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap cmap) {
     constexpr int CH = RUN_TILE / 64;  // chunks of 64 nodes per tile
@@ -774,24 +774,31 @@ __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
     const size_t n_nodes = npad >> L;
-    // uniform flags of level l >= 1 live at uni[col][npad - (npad >> (l - 1)) + k]
-    const uint8_t *u_in = uni + col * uni_stride + (L >= 2 ? npad - (npad >> (L - 2)) : 0);
-    uint8_t *u_out = uni + col * uni_stride + (L >= 1 ? npad - (npad >> (L - 1)) : 0);
+    // Per hinted column (blockIdx.y) and level l >= 1, at offset npad - (npad >> (l - 1)): one byte "uniform?" and one word
+    // "first value" per node, written by this kernel for the next level -- so a level reads 10 contiguous bytes per node
+    // instead of two values 2^l words apart in the column.
+    const size_t lvl_in = L >= 2 ? npad - (npad >> (L - 2)) : 0, lvl_out = L >= 1 ? npad - (npad >> (L - 1)) : 0;
+    const uint8_t *u_in = uni + blockIdx.y * npad + lvl_in;
+    uint8_t *u_out = uni + blockIdx.y * npad + lvl_out;
+    const uint32_t *f_in = fv + blockIdx.y * npad + lvl_in;
+    uint32_t *f_out = fv + blockIdx.y * npad + lvl_out;
     // all loads of the thread's 16 nodes first (independent, in flight together), then the flags
     uint32_t x[NPT], y[NPT];
     unsigned short uu[NPT];
 #pragma unroll
     for (int j = 0; j < NPT; j++) {
-        const size_t i = (tile_base + j * TPB + threadIdx.x) << L;
-        x[j] = i < n_values ? v[i] : 0u;  // padding leaves are hashLeaf(0), merkle_tree.zig:302-306
-    }
-    if (!LEAF) {
-#pragma unroll
-        for (int j = 0; j < NPT; j++) {
-            const size_t k = tile_base + j * TPB + threadIdx.x;
-            const size_t i1 = (k << L) + ((size_t)1 << (L - 1));  // first value of the right half
-            y[j] = i1 < n_values ? v[i1] : 0u;
-            uu[j] = L >= 2 ? *reinterpret_cast<const unsigned short *>(u_in + 2 * k) : (unsigned short)0x0101;
+        const size_t k = tile_base + j * TPB + threadIdx.x;
+        if (LEAF) {
+            x[j] = k < n_values ? v[k] : 0u;  // padding leaves are hashLeaf(0), merkle_tree.zig:302-306
+        } else if (L == 1) {
+            x[j] = 2 * k < n_values ? v[2 * k] : 0u;
+            y[j] = 2 * k + 1 < n_values ? v[2 * k + 1] : 0u;
+            uu[j] = 0x0101;  // leaves are uniform
+        } else {
+            const uint2 p = *reinterpret_cast<const uint2 *>(f_in + 2 * k);  // first values of the two children
+            x[j] = p.x;
+            y[j] = p.y;
+            uu[j] = *reinterpret_cast<const unsigned short *>(u_in + 2 * k);
         }
     }
 #pragma unroll
@@ -800,7 +807,10 @@ __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__
         const bool u = LEAF ? true : (x[j] == y[j] && uu[j] == 0x0101);  // both children uniform and the halves agree
         s_x[li] = x[j];
         s_u[li] = u ? 1 : 0;
-        if (!LEAF) u_out[tile_base + li] = u ? 1 : 0;
+        if (!LEAF) {
+            u_out[tile_base + li] = u ? 1 : 0;
+            f_out[tile_base + li] = x[j];
+        }
     }
     __syncthreads();
 #pragma unroll
@@ -934,7 +944,7 @@ size_t runs_list_entries(size_t npad, size_t ncols) { return runs_sub_cap(npad, 
 size_t runs_bitmap_words(size_t npad, size_t ncols) { return ncols * npad / 64; }
 
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, size_t uni_stride,
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv,
                         unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
                         hipStream_t s, const KTime *kt) {
     if (cols.n == 0) return;
@@ -948,16 +958,16 @@ void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_valu
     // timing: the three launches of a level are bracketed as one (start of the first, stop of the last)
     if (level == 0) {
         if (kt) hipExtLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
-                                      npad, level, d_uni, uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+                                      npad, level, d_uni, d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
         else hipLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
-                                uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+                                d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
         hipLaunchKernelGGL(k_runs_hash<true>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
                            tree_stride_nodes, level, d_list, sub_cap, d_ctr);
     } else {
         if (kt) hipExtLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
-                                      npad, level, d_uni, uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+                                      npad, level, d_uni, d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
         else hipLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
-                                uni_stride, d_bitmap, d_list, sub_cap, d_ctr, cols);
+                                d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
         hipLaunchKernelGGL(k_runs_hash<false>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
                            tree_stride_nodes, level, d_list, sub_cap, d_ctr);
     }

@@ -105,17 +105,17 @@ struct ColMap {
 };
 // Run-aware level `level` (0 = leaves) of the columns in `cols` (three launches: flags + list, hash the list, fill the
 // copies): identical digests, but a node that is a copy of its left neighbour (both subtrees uniform, same value) is
-// copied instead of hashed.  d_uni: per column `uni_stride` >= npad bytes of uniform flags for the levels >= 1;
+// copied instead of hashed.  d_uni / d_fv: cols.n x npad bytes / words (per node of the levels >= 1: uniform?, first value);
 // d_bitmap: runs_bitmap_words() u64; d_list: runs_list_entries() u32; d_ctr: RUN_CTRS u64, d_ctr[0] += nodes hashed
-// (zeroed by the caller before level 0; the rest are the level's list counters).  Requires (npad >> level) >= RUN_TILE and npad <= 2^26
-// (the caller stops at RUN_MIN_NODES).
+// (zeroed by the caller before level 0; the rest are the level's list counters).  Levels must be launched in order from 0.
+// Requires (npad >> level) >= RUN_TILE and npad <= 2^26 (the caller stops at RUN_MIN_NODES).
 constexpr unsigned RUN_TILE = 4096;
 constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
 constexpr unsigned RUN_CTRS = 33 * 16;  // u64 words: the build's total + 32 sub-list counters, each in a 128-byte line
 size_t runs_list_entries(size_t npad, size_t ncols);
 size_t runs_bitmap_words(size_t npad, size_t ncols);
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, size_t uni_stride,
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv,
                         unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
                         hipStream_t s, const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
