@@ -72,6 +72,24 @@ MERKLE_BUILDS = {  # --merkle: what config.merkle_build says
 }
 
 
+def host_cpus():
+    """CPUs this process may use: the cgroup quota (cpu.max) if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def default_batch(world):
+    """Lanes per GPU: every lane keeps one host core busy with its proof's sequential SHA3 sponge; two cores per rank are
+    left for the helper threads (serialisation, Lasso commitments) and this interpreter.  Beyond 14 lanes the GPU is the limit."""
+    return max(1, min(14, host_cpus() // max(world, 1) - 2))
+
+
 def launch_ranks(n, argv):
     """Start n ranks as a child torch.distributed.run and relay rank 0's JSON line.  Nothing in this process has
     imported torch or loaded HIP at this point (tests/test_bench_launch.py asserts it)."""
@@ -236,11 +254,12 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=16, help="independent traces proven concurrently per GPU per step.  One proof "
-                    "alone is bound by its sequential host transcript (~27 ms on one core) against ~2.7 ms of GPU work with the "
-                    "default Merkle build, so a proving service runs one host thread + one HIP stream per trace: 8 lanes "
-                    "~290 M steps/s (host-bound), 12 ~430 M, 16 ~500 M; more lanes than the 16 cores of one GPU's share of the "
-                    "host gain nothing")
+    ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: this "
+                    "rank's share of the host CPUs minus 2, at most 14).  One proof alone is bound by its sequential host "
+                    "transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default Merkle build, so a proving "
+                    "service runs one host thread + one HIP stream per trace: 8 lanes ~290 M steps/s (host-bound), 12 ~430 M, "
+                    "14 ~485 M; a GPU box of this pool grants 16 CPUs per GPU, and with 16 lanes the helper threads push the "
+                    "process over that quota (throttled: 395-500 M)")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
@@ -369,7 +388,7 @@ def main():
         return 0
 
     shard = args.mode == "shard"
-    B = 1 if shard else max(1, args.batch)
+    B = 1 if shard else (args.batch if args.batch > 0 else default_batch(world))
 
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
         def __init__(self, k):
@@ -681,7 +700,7 @@ def main():
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
                        "merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle],
                        "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
-                       "traces_per_step_per_gpu": B, "ms_per_proof_per_gpu": dt / nproofs * 1e3,
+                       "traces_per_step_per_gpu": B, "host_cpus_available": host_cpus(), "ms_per_proof_per_gpu": dt / nproofs * 1e3,
                        "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
                                        "sequential host transcript every rank replays" % world) if shard else
                                       ("independent-trace throughput: %d GPU(s) x %d concurrent proofs, one rank per GPU, no "

@@ -23,6 +23,7 @@ python3 bench.py > gpurun_out/p2_bench.json 2> gpurun_out/p2_bench.err
 python3 bench.py --batch 1 --no-cpu-baseline > gpurun_out/p2_bench_b1.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_b8.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --batch 12 --no-cpu-baseline > gpurun_out/p2_bench_b12.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --batch 16 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_b16.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle tables --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_tables_b8.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle dense --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_dense_b8.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle all --no-cpu-baseline --no-extras > gpurun_out/p2_bench_all.json 2>> gpurun_out/p2_bench.err
