@@ -58,3 +58,15 @@ def test_world_size_mismatch_is_refused():
 def test_single_rank_dry_run():
     out = subprocess.run([sys.executable, BENCH, "--dry-run"], env=_env(), capture_output=True, text=True, timeout=120)
     assert out.returncode == 0 and json.loads(out.stdout.strip())["n_gpus"] == 1
+
+
+def test_default_lane_count_follows_the_cpu_share(monkeypatch):
+    """--batch 0 (the default): one lane per host CPU of this rank's share, two left for the helper threads, at most 14."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    assert 1 <= b.host_cpus() <= len(os.sched_getaffinity(0))
+    for cpus, world, want in ((16, 1, 14), (128, 8, 14), (256, 8, 14), (8, 1, 6), (16, 8, 1), (2, 1, 1)):
+        monkeypatch.setattr(b, "host_cpus", lambda c=cpus: c)
+        assert b.default_batch(world) == want, (cpus, world)
