@@ -85,9 +85,16 @@ def host_cpus():
     return n
 
 
+def has_avx512f():
+    try:
+        return " avx512f" in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
 def default_batch(world):
     """Lanes per GPU: every lane keeps one host core busy with its proof's sequential SHA3 sponge; two cores per rank are
-    left for the helper threads (serialisation, Lasso commitments) and this interpreter.  Beyond 14 lanes the GPU is the limit."""
+    left for the helper threads (serialisation, Lasso commitments) and this interpreter (used without the sponge service)."""
     return max(1, min(14, host_cpus() // max(world, 1) - 2))
 
 
@@ -255,12 +262,17 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: this "
-                    "rank's share of the host CPUs minus 2, at most 14).  One proof alone is bound by its sequential host "
-                    "transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default Merkle build, so a proving "
-                    "service runs one host thread + one HIP stream per trace: 8 lanes ~290 M steps/s (host-bound), 12 ~430 M, "
-                    "14 ~485 M; a GPU box of this pool grants 16 CPUs per GPU, and with 16 lanes the helper threads push the "
-                    "process over that quota (throttled: 395-500 M)")
+    ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: 8 per "
+                    "sponge server; without the service this rank's share of the host CPUs minus 2, at most 14).  One proof alone "
+                    "is bound by its sequential host transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default "
+                    "Merkle build, so a proving service keeps many proofs in flight, one host thread + one HIP stream each: with "
+                    "4 sponge servers x 8 lanes the GPU is the limit (~575 M steps/s); with one core per transcript 14 lanes fit a "
+                    "16-CPU share of the host (~490 M)")
+    ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
+                    "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
+                    "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
+                    "bounded by the host cores: 14 lanes, 491 M steps/s); -1 (default) = a quarter of this rank's CPUs, at most 4, "
+                    "or 0 without AVX-512F")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
@@ -389,7 +401,21 @@ def main():
         return 0
 
     shard = args.mode == "shard"
-    B = 1 if shard else (args.batch if args.batch > 0 else default_batch(world))
+    servers = args.sponge_servers
+    if servers < 0:
+        servers = 0 if shard or not has_avx512f() else max(1, min(4, host_cpus() // max(world, 1) // 4))
+    if servers > 0:
+        zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
+        servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
+    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers if servers else default_batch(world)))
+    blocking = B + servers + 2 > host_cpus() // max(world, 1)  # more threads than cores: wait for the GPU asleep, not spinning
+    if os.environ.get("ZIGZ_BENCH_BLOCKING_SYNC"):
+        blocking = os.environ["ZIGZ_BENCH_BLOCKING_SYNC"] == "1"
+    if blocking:
+        rc = zigz_amd._ffi.lib.zigz_device_set_blocking_sync(local_rank, 1)
+        if rc != 0:
+            sys.stderr.write("bench.py: zigz_device_set_blocking_sync -> %d (threads will spin while waiting)\n" % rc)
+            blocking = False
 
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
         def __init__(self, k):
@@ -701,7 +727,11 @@ def main():
                        "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
                        "merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle],
                        "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
-                       "traces_per_step_per_gpu": B, "host_cpus_available": host_cpus(), "ms_per_proof_per_gpu": dt / nproofs * 1e3,
+                       "traces_per_step_per_gpu": B, "host_cpus_available": host_cpus(),
+                       "sponge_servers": servers, "blocking_sync": bool(blocking), "ms_per_proof_per_gpu": dt / nproofs * 1e3,
+                       "host_transcripts": ("%d sponge-server threads per GPU, each advancing up to 8 proofs' transcripts in lock "
+                                            "step (8-way AVX-512 Keccak-f); the proofs' own threads sleep meanwhile" % servers)
+                                           if servers else "every proof absorbs its transcript on its own host thread",
                        "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
                                        "sequential host transcript every rank replays" % world) if shard else
                                       ("independent-trace throughput: %d GPU(s) x %d concurrent proofs, one rank per GPU, no "

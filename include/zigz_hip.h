@@ -77,6 +77,11 @@ const char *zigz_status_name(zigz_status s); /* the Zig error name, e.g. "Length
 zigz_status zigz_device_count(int *count);
 /* Binds a context to HIP device `device` (must be gfx950) and creates its stream + workspace. */
 zigz_status zigz_ctx_create(int device, zigz_ctx **out);
+/* How host threads of this process wait for the device (stream / event synchronisation inside the calls below): on != 0
+ * they sleep until the device signals instead of spinning.  For a host that keeps more proofs in flight than it has cores
+ * (one thread per proof, most of them waiting for the GPU or for the sponge service); costs a wake-up per wait, so leave it
+ * off for a lone proof.  Call before the contexts of `device` are created. */
+zigz_status zigz_device_set_blocking_sync(int device, int on);
 void zigz_ctx_destroy(zigz_ctx *ctx);
 const char *zigz_last_error(const zigz_ctx *ctx);
 /* Run on a caller-owned hipStream_t (e.g. torch's current stream); NULL restores the own stream. */
@@ -284,6 +289,16 @@ void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]);
  * (0 = the picked one, 1 = scalar, 2 = bmi2, 3 = avx512f, 4 = avx512vl) -- diagnostics / self-test */
 const char *zigz_host_keccak_impl(void);
 void zigz_host_keccak_permute(uint64_t state[25], int which);
+/* Sponge service for a host that proves several traces at once (one thread per proof).  A proof's transcript is a chain of
+ * ~147 k dependent permutations at a 2^20 trace (prover.zig:302-312) and one permutation costs the same ~880 cycles whether
+ * its lanes sit in xmm or zmm registers, so `n` server threads each advance up to 8 transcripts' tagged-counter absorptions
+ * in lock step -- one 8-way AVX-512 permutation per block -- while the proofs' own threads sleep.  Same bytes absorbed, same
+ * challenges.  n = 0 (default): every transcript absorbs on its own thread.  Ignored without AVX-512F.  Call while no
+ * transcript is absorbing.  zigz_host_keccak_permute_x8: the 8-way permutation on states[lane][slot] (25 x 8 u64, 64-byte
+ * aligned) -- diagnostics / self-test, requires AVX-512F. */
+void zigz_host_sponge_servers(int n);
+int zigz_host_sponge_batching(void);
+void zigz_host_keccak_permute_x8(uint64_t *states);
 
 /* ---------------------------------------------------------------- measurement hooks (bench.py)
  * Average device time (microseconds, HIP events on the context's stream) of the last call's

@@ -206,6 +206,42 @@ def test_concurrent_proofs_on_one_gpu(ctx):
     assert got == expect
 
 
+def test_concurrent_proofs_through_the_sponge_service(ctx):
+    """zigz_host_sponge_servers: the transcripts of proofs in flight advance in lock step on server threads (8-way AVX-512
+    permutation).  Ten concurrent proofs with >= 3 500 lookup steps each (long enough to be handed to the service), two
+    rounds: proof bytes identical to the oracle's."""
+    import threading
+    import zigz_amd
+    from zigz_amd import host
+    from zigz_amd._ffi import lib
+    if " avx512f" not in open("/proc/cpuinfo").read():
+        pytest.skip("the sponge service needs AVX-512F")
+    jobs = [programs.fibonacci(750 + 130 * k) for k in range(6)] + [(programs.mixed_loop(400 + 50 * k), None) for k in range(4)]
+    expect = [O.prove(P, p, 0x1000, None, 1 << 20, i)[0] for p, i in jobs]
+    errs = []
+
+    def work(k):
+        try:
+            c = zigz_amd.Context(0)
+            for _ in range(2):
+                t = host.Trace(jobs[k][0], 0x1000, None, 1 << 20, jobs[k][1])
+                assert t.num_lookups * 19 >= 65536
+                assert t.prove(c, want_bytes="borrow").tobytes() == expect[k]
+            c.close()
+        except Exception as e:  # noqa: BLE001
+            errs.append((k, repr(e)))
+
+    lib.zigz_host_sponge_servers(2)
+    try:
+        assert lib.zigz_host_sponge_batching() == 1
+        th = [threading.Thread(target=work, args=(k,)) for k in range(len(jobs))]
+        [t.start() for t in th]
+        [t.join() for t in th]
+    finally:
+        lib.zigz_host_sponge_servers(0)
+    assert not errs, errs
+
+
 def test_prove_random_programs_vs_oracle(ctx):
     """25 random straight-line RV64IM programs (random lengths => ragged num_steps, loads/stores, initial registers):
     proof bytes from the HIP path == proof bytes from the oracle."""

@@ -132,3 +132,86 @@ def test_host_keccak_dispatch_matches_portable_code():
     for n in (0, 8, 64, 135):
         m = rng.integers(0, 256, n, dtype=np.uint8).tobytes()
         assert sha3_256(m) == hashlib.sha3_256(m).digest()
+
+
+def _has_avx512f():
+    try:
+        return "avx512f" in open("/proc/cpuinfo").read()
+    except OSError:
+        return False
+
+
+@pytest.mark.skipif(not _has_avx512f(), reason="the sponge service needs AVX-512F")
+def test_keccak_x8_equals_eight_single_permutations():
+    from zigz_amd._ffi import lib, u64p
+    rng = np.random.default_rng(8)
+    for _ in range(50):
+        raw = np.zeros(25 * 8 + 8, dtype=np.uint64)
+        off = (-raw.ctypes.data // 8) % 8          # 64-byte aligned window
+        st = raw[off:off + 200].reshape(25, 8)
+        st[:] = rng.integers(0, 2**64, (25, 8), dtype=np.uint64)
+        want = st.copy()
+        for s in range(8):
+            col = np.ascontiguousarray(want[:, s])
+            lib.zigz_host_keccak_permute(col.ctypes.data_as(u64p), 1)
+            want[:, s] = col
+        lib.zigz_host_keccak_permute_x8(st.ctypes.data_as(u64p))
+        assert np.array_equal(st, want)
+
+
+@pytest.mark.skipif(not _has_avx512f(), reason="the sponge service needs AVX-512F")
+def test_sponge_service_absorbs_the_same_bytes():
+    """zigz_host_sponge_servers: long tagged-counter runs of several transcripts advance in lock step on a server thread
+    (8-way permutation).  Every challenge must equal the sequential code's, whatever the sponge position at hand-over, the
+    tag length, a counter that wraps at p, and how the jobs overlap in time."""
+    import threading
+    from zigz_amd._ffi import lib
+    rng = np.random.default_rng(99)
+    jobs = []
+    for k in range(24):
+        prefix = bytes(rng.integers(0, 256, int(rng.integers(0, 300)), dtype=np.uint8))
+        tag = [b"LASSO_TABLE", b"", b"T" * 30, b"x" * 250, b"LASSO_TABLE"][k % 5]
+        start = [0, P - 1000, 12345, P - 1][k % 4]
+        rec = len(tag) + 8
+        count = (65536 // rec) + int(rng.integers(1, 3000))     # >= the 64 KiB threshold of the service
+        if k == 7:
+            count = (65536 + 136 * 50 - len(prefix) % 136 + rec - 1) // rec  # ends close to a block boundary
+        jobs.append((prefix, tag, start, count))
+    # a run that ends EXACTLY on a block boundary: 136 records of 17 + 8 = 25 bytes per 25 blocks, from position 0
+    jobs.append((b"", b"Q" * 17, 5, 136 * 30))
+
+    def run(job):
+        prefix, tag, start, count = job
+        t = Transcript()
+        t.append_bytes(prefix)
+        t.append_tagged_counter(tag, start, count)
+        t.append_field(7)
+        return [t.challenge() for _ in range(3)]
+
+    assert lib.zigz_host_sponge_batching() == 0
+    want = [run(j) for j in jobs]
+    # spot-check the sequential answers themselves against the oracle's transcript
+    for j, w in list(zip(jobs, want))[:3]:
+        o = O.Transcript()
+        o.append_bytes(j[0])
+        for i in range(j[3]):
+            o.append_bytes(j[1]); o.append_field((j[2] + i) % P)
+        o.append_field(7)
+        assert [o.challenge(P) for _ in range(3)] == w
+    for servers in (1, 3):
+        lib.zigz_host_sponge_servers(servers)
+        try:
+            assert lib.zigz_host_sponge_batching() == 1
+            got = [None] * len(jobs)
+
+            def work(i):
+                got[i] = run(jobs[i])
+            th = [threading.Thread(target=work, args=(i,)) for i in range(len(jobs))]
+            [t.start() for t in th]
+            [t.join() for t in th]
+            assert got == want, servers
+            assert run(jobs[0]) == want[0]          # a lone job through the service
+        finally:
+            lib.zigz_host_sponge_servers(0)
+        assert lib.zigz_host_sponge_batching() == 0
+    assert run(jobs[1]) == want[1]

@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""GPU-bound rate of the commit path: L lanes (thread + context + HIP stream each) run generateCommitments' device work
+-- Merkle build of the 43 resident columns of the bench trace, roots, 43 evals + openings -- back to back WITHOUT the host
+transcript that bounds a real proof.  What the GPU could take if the host sponge were free.
+
+    python tools/gpu_bound_rate.py [--lanes 14] [--iters 20] [--trace add_xor|round_robin]
+"""
+import argparse
+import os
+import sys
+import threading
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import programs  # noqa: E402
+import zigz_amd  # noqa: E402
+from zigz_amd import host  # noqa: E402
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--lanes", type=int, default=14)
+ap.add_argument("--iters", type=int, default=20)
+ap.add_argument("--trace", default="add_xor")
+args = ap.parse_args()
+nv = 20
+N = 1 << nv
+REGS = 0x7fffffff << 2
+SMALL = (1 << 1) | (0x3f << 33) | (1 << 42)
+rng = np.random.default_rng(1)
+
+
+class Lane:
+    def __init__(self, k):
+        self.ctx = zigz_amd.Context(0)
+        prog = programs.add_xor_loop((N - 3) // 4 - k) if args.trace == "add_xor" else programs.register_round_robin((N - 2) // 31 - k)
+        self.tr = host.Trace(prog, 0x1000, None, 2 * N)
+        self.d = self.ctx.dev_alloc(43 * N * 4)
+        self.tr.witness_to_device(self.ctx, self.d, N)
+        self.points = rng.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
+        self.ctx.set_option("small_domain_mask", SMALL)
+        self.ctx.set_option("run_aware_mask", REGS)
+
+    def once(self):
+        job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)
+        job.roots()
+        job.open_all(self.points)
+        job.end()
+
+
+lanes = [Lane(k) for k in range(args.lanes)]
+for l in lanes:
+    l.once()
+
+
+def loop(l):
+    for _ in range(args.iters):
+        l.once()
+
+
+t0 = time.perf_counter()
+th = [threading.Thread(target=loop, args=(l,)) for l in lanes]
+[t.start() for t in th]
+[t.join() for t in th]
+dt = time.perf_counter() - t0
+n = args.lanes * args.iters
+print("%s: %d lanes: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
+      (args.trace, args.lanes, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))

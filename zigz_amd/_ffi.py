@@ -111,6 +111,10 @@ SIGNATURES = {
     "zigz_sha3_256": (None, [C.c_char_p, C.c_size_t, u8p]),
     "zigz_sha256": (None, [C.c_char_p, C.c_size_t, u8p]),
     "zigz_host_keccak_impl": (C.c_char_p, []),
+    "zigz_device_set_blocking_sync": (C.c_int32, [C.c_int, C.c_int]),
+    "zigz_host_sponge_servers": (None, [C.c_int]),
+    "zigz_host_sponge_batching": (C.c_int, []),
+    "zigz_host_keccak_permute_x8": (None, [u64p]),
     "zigz_host_keccak_permute": (None, [u64p, C.c_int]),
     "zigz_ctx_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
     "zigz_ctx_enable_timing": (C.c_int32, [vp, C.c_int]),

@@ -66,6 +66,7 @@ def build_hip(force=False):
         ("host_keccak_avx512.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
         ("host_keccak_bmi.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
         ("host_keccak_avx512vl.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
+        ("host_sponge_batch.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", "-pthread", f"-I{CSRC}"]),
         ("shm_comm.cpp", [_host_cxx(), "-O2", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
     ]
     for src, cmd in units:

@@ -176,6 +176,13 @@ extern "C" zigz_status zigz_device_count(int *count) {
     return n > 0 ? ZIGZ_OK : ZIGZ_ERR_NO_DEVICE;
 }
 
+extern "C" zigz_status zigz_device_set_blocking_sync(int device, int on) {
+    int n = 0;
+    if (zigz_device_count(&n) != ZIGZ_OK || device < 0 || device >= n) return ZIGZ_ERR_NO_DEVICE;
+    if (hipSetDevice(device) != hipSuccess) return ZIGZ_ERR_HIP;
+    return hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto) == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP;
+}
+
 extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     if (!out) return ZIGZ_ERR_INVALID_ARGUMENT;
     *out = nullptr;
@@ -1731,5 +1738,8 @@ extern "C" void zigz_transcript_append_tagged_counter(zigz_transcript *t, const 
 extern "C" uint64_t zigz_transcript_challenge(zigz_transcript *t) { return t ? t->t.challenge() : 0; }
 extern "C" void zigz_sha3_256(const uint8_t *data, size_t len, uint8_t out[32]) { sha3_256(data, len, out); }
 extern "C" void zigz_sha256(const uint8_t *data, size_t len, uint8_t out[32]) { sha256(data, len, out); }
+extern "C" void zigz_host_sponge_servers(int n) { host_sponge_servers(n); }
+extern "C" int zigz_host_sponge_batching(void) { return host_sponge_batching() ? 1 : 0; }
+extern "C" void zigz_host_keccak_permute_x8(uint64_t *states) { host_keccak_permute_x8(reinterpret_cast<uint64_t (*)[8]>(states)); }
 extern "C" const char *zigz_host_keccak_impl(void) { return host_keccak_impl(); }
 extern "C" void zigz_host_keccak_permute(uint64_t state[25], int which) { host_keccak_permute(state, which); }

@@ -146,6 +146,10 @@ void Transcript::append_tagged_counter(const uint8_t *tag, size_t tag_len, uint6
     // materialise the records (tag || LE64((start+k) mod p)) in chunks and absorb them in bulk
     constexpr size_t CHUNK = 512;
     const size_t rec = tag_len + 8;
+    // a long run goes to the sponge service when one is running (8 transcripts per core in lock step; same bytes absorbed)
+    if (rec <= 256 && count * rec >= (64u << 10) && host_sponge_batching() &&
+        host_sponge_absorb_tagged(h_.raw_state(), h_.raw_pos(), tag, tag_len, start, count))
+        return;
     if (rec > 256) {
         for (uint64_t k = 0; k < count; k++) { h_.update(tag, tag_len); h_.update_le64((start + k) % (uint64_t)P); }
         return;
