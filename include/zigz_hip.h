@@ -155,7 +155,8 @@ zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, u
                                  uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);
 /* diagnostic (tests): device address of the job's trees once built -- per column `bytes_per_column` = 2 * 2^nv nodes x 32 B
  * in the kernels' internal node form (level l at node offset 2N - 2(N >> l)); valid until zigz_commit_end.  Lets a test
- * compare two builds of the same columns node for node (dense vs table / run-aware levels). */
+ * compare two builds of the same columns node for node (dense vs table / run-aware levels; set "run_aware_materialize"
+ * for the latter, otherwise the copies of the run-aware levels are not in the tree). */
 zigz_status zigz_commit_job_tree(zigz_commit_job *job, const void **d_tree, size_t *bytes_per_column);
 void zigz_commit_end(zigz_commit_job *job);
 
@@ -365,6 +366,10 @@ zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
  *   nodes a node whose subtree and its left neighbour's are uniform with the same value takes the neighbour's digest
  *   instead of being hashed.  Decided from the VALUES on the device, never from the hint: identical trees for ANY input;
  *   with c change points in a column a level costs <= min(nodes, 2 c + nodes / 4096) hashes.
+ *   In a commit job the copies of all but the top run-aware level are VIRTUAL: their 32 bytes are never written; the next
+ *   level's hashes and zigz_commit_open_all read a copy through a per-level bitmap of hashed nodes (2 GB less HBM traffic per
+ *   2^20 x 43 build).  "run_aware_materialize" = 1 writes them all (tests that compare whole trees); single trees
+ *   (zigz_merkle_commit) always hold every digest.
  * "merkle_dedup" = 1 / 0 is shorthand for run_aware_mask = all ones / 0;
  * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
  *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the

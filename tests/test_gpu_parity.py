@@ -665,6 +665,7 @@ def test_run_aware_levels_identical_trees(ctx, nv):
     for masks in ((0, 0), (run_mask, 0), (run_mask, 1 << 14), (~0 & ((1 << nc) - 1), 0)):
         ctx.set_option("run_aware_mask", masks[0])
         ctx.set_option("small_domain_mask", masks[1])
+        ctx.set_option("run_aware_materialize", 1)   # write the copies too: whole trees are compared below
         try:
             job = zigz_amd.CommitJob(ctx, cols=cols)
             roots = job.roots()
@@ -674,6 +675,7 @@ def test_run_aware_levels_identical_trees(ctx, nv):
         finally:
             ctx.set_option("run_aware_mask", 0)
             ctx.set_option("small_domain_mask", 0)
+            ctx.set_option("run_aware_materialize", 0)
     r0, t0, s0 = trees[0]
     assert s0["run_aware_columns"] == 0 and s0["keccak_permutations"] == nc * (2 * N - 1)
     for k, (r, t, st) in enumerate(trees[1:], 1):
@@ -691,6 +693,68 @@ def test_run_aware_levels_identical_trees(ctx, nv):
     for c in (1, 3, 4, 10, 12):
         lv, h = O.merkle_levels(cols[c])
         assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r0[c].tobytes()
+
+
+@pytest.mark.parametrize("nv", [15, 17])
+def test_run_aware_virtual_copies_open_like_the_dense_tree(ctx, nv):
+    """In a commit job the copies of the run-aware levels are not written at all: the next level's hashes and the openings
+    read a copy through its leader (bitmap of hashed nodes + last hashed node before the chunk).  Roots and the openings at
+    many indices -- next to change points, chunk and tile boundaries, the ends, random -- must equal the dense build's."""
+    import zigz_amd
+    N = 1 << nv
+    nc = 12
+    cols = rnd(7150 + nv, nc * N).reshape(nc, N).copy()
+    cols[1, :] = 5
+    cols[2, :] = 0
+    cols[3, :] = np.repeat(rnd(1, N // 1000 + 1), 1000)[:N]
+    cols[4, :] = 9; cols[4, 20000] = 10
+    cols[5, : N // 2] = 123
+    cols[6, :] = np.repeat(rnd(2, N // 256), 256)
+    cols[7, :] = np.repeat(rnd(3, N // 4096), 4096)
+    cols[8, :] = 1
+    for pos in (63, 64, 65, 4095, 4096, 4097, N - 1, N // 2, N // 2 + 1):
+        cols[8, pos:] += 1
+    cols[9, :] = np.repeat(rnd(4, N // 3 + 1), 3)[:N]
+    cols[10, :] = np.repeat(np.arange(N // 512) % 128, 512)
+    rng = np.random.default_rng(nv)
+    special = [0, 1, 62, 63, 64, 65, 127, 128, 999, 1000, 1001, 4094, 4095, 4096, 4097, 8191, 8192, 19999, 20000, 20001,
+               N // 2 - 1, N // 2, N // 2 + 1, N - 2, N - 1]
+    index_sets = [np.full(nc, i) for i in special] + [rng.integers(0, N, nc) for _ in range(25)]
+
+    def run(run_mask, sd_mask):
+        ctx.set_option("run_aware_mask", run_mask)
+        ctx.set_option("small_domain_mask", sd_mask)
+        try:
+            outs = []
+            for idx in index_sets:  # a job opens once: one build per index set
+                job = zigz_amd.CommitJob(ctx, cols=cols)
+                try:
+                    roots = job.roots().copy()
+                    st = ctx.stats()
+                    pts = rnd(int(idx[0]) + 5, nc * nv).reshape(nc, nv)
+                    pts[:, 0] = idx
+                    o = job.open_all(pts)
+                    outs.append({k: v.copy() for k, v in o.items()})
+                finally:
+                    job.end()
+        finally:
+            ctx.set_option("run_aware_mask", 0)
+            ctx.set_option("small_domain_mask", 0)
+        return roots, outs, st
+
+    r0, o0, s0 = run(0, 0)
+    for masks in ((0xBFF, 0), (0xFFF, 0), (0xBFF, 1 << 10)):
+        r1, o1, s1 = run(*masks)
+        assert np.array_equal(r0, r1), masks
+        assert s1["run_aware_columns"] >= 10 and s1["run_aware_hashed"] < s1["run_aware_dense_nodes"]
+        for a, b in zip(o0, o1):
+            for k in a:
+                assert np.array_equal(a[k], b[k]), (masks, k, a["indices"][:3])
+    lv, h = O.merkle_levels(cols[8])
+    assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r0[8].tobytes()
+    sib, dirs, leaf = O.merkle_open(cols[8], 4096)
+    k = special.index(4096)
+    assert o0[k]["siblings"][8].tobytes() == sib and int(o0[k]["leaves"][8]) == leaf
 
 
 def test_run_aware_hash_counts(ctx):

@@ -20,7 +20,7 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_SLOTS };
 
 constexpr int KEV_MAX = 56;
 struct zigz_ctx {
@@ -39,6 +39,7 @@ struct zigz_ctx {
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
+    bool run_aware_materialize;  // option (tests): write the copies of every run-aware level (no virtual copies)
     uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
                               // are copied, not hashed); "merkle_dedup" = 1 is all columns
     unsigned long long *d_run_count;  // nodes hashed by the run-aware launches of the last build
@@ -288,6 +289,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "fold_eval") == 0) { ctx->fold_eval = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "merkle_dedup") == 0) { ctx->run_aware_mask = value != 0 ? ~0ull : 0; return ZIGZ_OK; }
     if (strcmp(name, "run_aware_mask") == 0) { ctx->run_aware_mask = (uint64_t)value; return ZIGZ_OK; }
+    if (strcmp(name, "run_aware_materialize") == 0) { ctx->run_aware_materialize = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1097,8 +1099,11 @@ extern "C" zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint
 
 // ------------------------------------------------------------------ Merkle
 // builds all levels of `ncols` trees (leaf hashes + level merges), asynchronous on the stream
+// run_meta != nullptr: the caller keeps the trees only as long as the context's WS_RUNMETA workspace stays untouched (a
+// commit job), so the copies of the run-aware levels are left virtual and *run_meta describes how to resolve them; nullptr:
+// every digest is written (single trees that outlive the call, tests that compare whole trees)
 static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
-                               uint8_t *d_tree, size_t ncols, bool record = false) {
+                               uint8_t *d_tree, size_t ncols, bool record = false, RunMeta *run_meta = nullptr) {
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
     ctx->stats.small_domain_columns = 0;
@@ -1150,20 +1155,36 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         ctx->stats.small_domain_columns = H.n;
     }
     unsigned run_top = 0;  // R columns: levels 0..run_top come from the run-aware kernel
+    if (run_meta) {
+        *run_meta = RunMeta{};
+        for (int c = 0; c < 64; c++) run_meta->y_of_col[c] = -1;
+    }
     if (R.n) {
         run_top = height - log2_floor(RUN_MIN_NODES);  // the last level with RUN_MIN_NODES nodes per column
-        // workspace: per hinted column and node of the levels >= 1 a "uniform?" byte and a "first value" word | the
-        // listed-node bitmap of the current level | its list
-        const size_t uni_bytes = (size_t)R.n * npad, fv_bytes = uni_bytes * 4, bm_bytes = runs_bitmap_words(npad, R.n) * 8;
-        void *w;
-        CHK(ws_get(ctx, WS_RUNS, fv_bytes + bm_bytes + runs_list_entries(npad, R.n) * 4 + uni_bytes, &w));
+        // scratch: per hinted column and node of the levels >= 1 a "first value" word and a "uniform?" byte | the list of the
+        // current level.  Kept for the openings (virtual copies) or scratch as well (everything written): per level and 64
+        // nodes the bitmap of hashed nodes and the last hashed node before the chunk
+        const size_t uni_bytes = (size_t)R.n * npad, fv_bytes = uni_bytes * 4, list_bytes = runs_list_entries(npad, R.n) * 4;
+        const size_t meta_n = runs_meta_words(npad, R.n);
+        const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;
+        void *w, *mw;
+        CHK(ws_get(ctx, WS_RUNS, fv_bytes + list_bytes + uni_bytes + (virt ? 0 : meta_n * 10 + 64), &w));
         uint32_t *fv = (uint32_t *)w;
-        unsigned long long *bitmap = (unsigned long long *)((uint8_t *)w + fv_bytes);
-        uint32_t *list = (uint32_t *)((uint8_t *)w + fv_bytes + bm_bytes);
-        uint8_t *uni = (uint8_t *)(list + runs_list_entries(npad, R.n));
+        uint32_t *list = (uint32_t *)((uint8_t *)w + fv_bytes);
+        uint8_t *uni = (uint8_t *)w + fv_bytes + list_bytes;
+        if (virt) CHK(ws_get(ctx, WS_RUNMETA, meta_n * 10 + 64, &mw));
+        else mw = (uint8_t *)w + ((fv_bytes + list_bytes + uni_bytes + 63) & ~(size_t)63);
+        RunMeta meta{};
+        meta.bitmap = (unsigned long long *)mw;
+        meta.prev = (unsigned short *)((uint8_t *)mw + meta_n * 8);
+        meta.ncols = R.n;
+        meta.virt_levels = virt ? run_top : 0;  // the top run-aware level is always filled in: the dense kernels read it
+        for (int c = 0; c < 64; c++) meta.y_of_col[c] = -1;
+        for (unsigned y = 0; y < R.n; y++) meta.y_of_col[R.c[y]] = (signed char)y;
+        if (run_meta) *run_meta = meta;
         HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
         for (unsigned l = 0; l <= run_top; l++) {
-            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, fv, bitmap, list, ctx->d_run_count, R,
+            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, fv, meta, list, ctx->d_run_count, R,
                                ctx->stream, stamp(4, 0));
             ctx->stats.run_aware_dense_nodes += (uint64_t)R.n * (npad >> l);
         }
@@ -1277,7 +1298,7 @@ extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values,
 
 static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad, unsigned height, const uint32_t *d_vals,
                               size_t val_stride, const uint64_t *h_idx, size_t ncols, uint8_t *siblings, uint8_t *dirs,
-                              uint64_t *leaves) {
+                              uint64_t *leaves, const RunMeta *run_meta = nullptr) {
     ZIGZ_NOTHROW_BEGIN
     // device scratch layout: idx[ncols] u64 | sib[ncols*h*32] | leaf[ncols] u32 | dirs[ncols*h]
     const size_t sib_b = ncols * height * 32, idx_b = ncols * 8, leaf_b = ncols * 4, dir_b = ncols * height;
@@ -1290,7 +1311,7 @@ static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad,
     uint8_t *d_dirs = (uint8_t *)(d_leaf + ncols);
     HIPCHK(ctx, hipMemcpyAsync(d_idx, h_idx, idx_b, hipMemcpyHostToDevice, ctx->stream));
     launch_paths(d_tree, tree_nodes(npad), npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols,
-                 ctx->stream);
+                 ctx->stream, run_meta);
     HIPCHK(ctx, hipGetLastError());
     std::vector<uint32_t> hl(ncols);
     if (sib_b) HIPCHK(ctx, hipMemcpyAsync(siblings, d_sib, sib_b, hipMemcpyDeviceToHost, ctx->stream));
@@ -1341,6 +1362,7 @@ struct zigz_commit_job {
     uint8_t *d_tree;
     int state;  // 0 begun, 1 roots read, 2 opened
     hipEvent_t built;
+    RunMeta run_meta;  // how to resolve the virtual copies of the run-aware levels (WS_RUNMETA of the context)
 };
 
 static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride, size_t nv,
@@ -1364,7 +1386,7 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         job->d_tree = (uint8_t *)tree;
         HIPCHK(ctx, hipEventCreateWithFlags(&job->built, hipEventDisableTiming));
         CHK(timed_begin(ctx, 2));
-        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols, ctx->timing));
+        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols, ctx->timing, &job->run_meta));
         if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
         // roots -> contiguous device buffer -> pinned staging (async), then the "built" event
         void *d_roots;
@@ -1470,7 +1492,7 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         indices[c] = idx[c];
     }
     CHK(open_paths(ctx, job->d_tree, job->N, (unsigned)nv, job->d_cols, job->col_stride, idx.data(), ncols, siblings,
-                   dirs, leaves));
+                   dirs, leaves, &job->run_meta));
     for (size_t c = 0; c < ncols; c++) values[c] = hv[c];
     CHK(bind_pool_collect(ctx));
     job->state = 2;

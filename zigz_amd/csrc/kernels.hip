@@ -753,13 +753,26 @@ __device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, c
     unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
     q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
 }
-constexpr unsigned RUN_NODE_BITS = 26;  // list entry = column << 26 | node
+constexpr unsigned RUN_NODE_BITS = 26;  // list entry = hinted-column index << 26 | node
+// first entry of level l in RunMeta::bitmap / ::prev (one entry per 64 nodes, levels stored one after the other)
+__device__ __host__ __forceinline__ size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
+    return (size_t)ncols * ((2 * npad - 2 * (npad >> l)) / 64);
+}
+// the node whose digest node k of level l of hinted column y has: itself if it was hashed, else the nearest hashed node
+// before it in its tile
+__device__ __forceinline__ size_t run_leader(const RunMeta &m, size_t npad, unsigned y, unsigned l, size_t k) {
+    const size_t e = run_meta_base(npad, m.ncols, l) + ((size_t)y * (npad >> l) + k) / 64;
+    const unsigned q = (unsigned)(k & 63);
+    const unsigned long long mm = m.bitmap[e] & (q == 63 ? ~0ull : ((2ull << q) - 1));
+    if (mm) return (k & ~(size_t)63) + (63 - __builtin_clzll(mm));
+    return (k & ~(size_t)(RUN_TILE - 1)) + m.prev[e];
+}
 constexpr unsigned RUN_SUBS = 32;       // sub-lists per level (power of two)
 
 template <bool LEAF>
 __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
                                                     size_t npad, unsigned L, uint8_t *__restrict__ uni, uint32_t *__restrict__ fv,
-                                                    unsigned long long *__restrict__ bitmap, uint32_t *__restrict__ list,
+                                                    RunMeta meta, uint32_t *__restrict__ list,
                                                     size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap cmap) {
     constexpr int CH = RUN_TILE / 64;  // chunks of 64 nodes per tile
     constexpr int NPT = RUN_TILE / TPB;  // nodes per thread
@@ -819,20 +832,25 @@ __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__
         // a copy of its left neighbour: both uniform, same value (the first node of a tile is always listed)
         const bool copy = li != 0 && s_u[li] && s_u[li - 1] && s_x[li] == s_x[li - 1];
         const unsigned long long need = __ballot(!copy);
-        if (lane == 0) {
-            s_need[j * (TPB / 64) + wave] = need;
-            bitmap[(blockIdx.y * n_nodes + tile_base) / 64 + j * (TPB / 64) + wave] = need;
-        }
+        if (lane == 0) s_need[j * (TPB / 64) + wave] = need;
     }
     __syncthreads();
     if (wave == 0) {
-        const unsigned cnt = (unsigned)__builtin_popcountll(s_need[lane]);
+        const unsigned long long m = s_need[lane];
+        const unsigned cnt = (unsigned)__builtin_popcountll(m);
         unsigned incl = cnt;
+        int last = m ? (int)(lane * 64 + 63 - __builtin_clzll(m)) : -1;  // last listed node up to the end of this chunk
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
             const unsigned a = __shfl_up(incl, off, 64);
-            if (lane >= (unsigned)off) incl += a;
+            const int b = __shfl_up(last, off, 64);
+            if (lane >= (unsigned)off) { incl += a; last = last > b ? last : b; }
         }
+        int prev = __shfl_up(last, 1, 64);
+        if (lane == 0) prev = 0;
+        const size_t e = run_meta_base(npad, meta.ncols, L) + (blockIdx.y * n_nodes + tile_base) / 64 + lane;
+        meta.bitmap[e] = m;
+        meta.prev[e] = (unsigned short)prev;
         s_off[lane] = incl - cnt;
         if (lane == 63) {
             s_off[CH] = incl;
@@ -850,7 +868,7 @@ __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__
         const unsigned long long m = s_need[c];
         if ((m >> lane) & 1)
             list[base + s_off[c] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] =
-                ((uint32_t)col << RUN_NODE_BITS) | (uint32_t)(tile_base + c * 64 + lane);
+                ((uint32_t)blockIdx.y << RUN_NODE_BITS) | (uint32_t)(tile_base + c * 64 + lane);
     }
 }
 
@@ -858,7 +876,7 @@ template <bool LEAF>
 __global__ __launch_bounds__(TPB) void k_runs_hash(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
                                                    size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes, unsigned L,
                                                    const uint32_t *__restrict__ list, size_t sub_cap,
-                                                   unsigned long long *__restrict__ ctr) {
+                                                   unsigned long long *__restrict__ ctr, RunMeta meta, ColMap cmap) {
     __shared__ unsigned long long s_start[RUN_SUBS + 1];  // exclusive prefix of the sub-list lengths
     if (threadIdx.x < 64) {
         static_assert(RUN_SUBS <= 64, "one lane per sub-list");
@@ -886,17 +904,26 @@ __global__ __launch_bounds__(TPB) void k_runs_hash(const uint32_t *__restrict__ 
         for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
             if (s_start[sub + step] <= e) sub += step;
         const uint32_t ent = list[(size_t)sub * sub_cap + (e - s_start[sub])];
-        const size_t col = ent >> RUN_NODE_BITS, k = ent & ((1u << RUN_NODE_BITS) - 1);
+        const unsigned y = ent >> RUN_NODE_BITS;
+        const size_t col = cmap.c[y], k = ent & ((1u << RUN_NODE_BITS) - 1);
         uint8_t *t = tree + col * tree_stride_nodes * 32;
         Digest d;
-        if (LEAF) d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
-        else d = sha3_node(load_digest(t, in_off + 2 * k), load_digest(t, in_off + 2 * k + 1));
+        if (LEAF) {
+            d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
+        } else {
+            size_t c0 = 2 * k, c1 = 2 * k + 1;
+            if (L - 1 < meta.virt_levels) {  // the children's level holds hashed nodes only: read their leaders
+                c0 = run_leader(meta, npad, y, L - 1, c0);
+                c1 = run_leader(meta, npad, y, L - 1, c1);
+            }
+            d = sha3_node(load_digest(t, in_off + c0), load_digest(t, in_off + c1));
+        }
         store_digest_plain(t, out_off + k, d);
     }
 }
 
 __global__ __launch_bounds__(TPB) void k_runs_fill(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad, unsigned L,
-                                                   const unsigned long long *__restrict__ bitmap, ColMap cmap) {
+                                                   RunMeta meta, ColMap cmap) {
     constexpr int CH = RUN_TILE / 64;
     __shared__ unsigned long long s_need[CH];
     __shared__ int s_prev[CH];
@@ -906,7 +933,7 @@ __global__ __launch_bounds__(TPB) void k_runs_fill(uint8_t *__restrict__ tree, s
     const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
     uint8_t *out = tree + (col * tree_stride_nodes + 2 * npad - 2 * n_nodes + tile_base) * 32;  // this tile's digests
     if (wave == 0) {
-        const unsigned long long m = bitmap[(blockIdx.y * n_nodes + tile_base) / 64 + lane];
+        const unsigned long long m = meta.bitmap[run_meta_base(npad, meta.ncols, L) + (blockIdx.y * n_nodes + tile_base) / 64 + lane];
         s_need[lane] = m;
         int last = m ? (int)(lane * 64 + 63 - __builtin_clzll(m)) : -1;  // last listed node at or before the end of the chunk
 #pragma unroll
@@ -941,39 +968,43 @@ static size_t runs_sub_cap(size_t npad, size_t ncols) {
     return (tiles + RUN_SUBS - 1) / RUN_SUBS * RUN_TILE;
 }
 size_t runs_list_entries(size_t npad, size_t ncols) { return runs_sub_cap(npad, ncols) * RUN_SUBS; }
-size_t runs_bitmap_words(size_t npad, size_t ncols) { return ncols * npad / 64; }
+size_t runs_meta_words(size_t npad, size_t ncols) { return ncols * (2 * npad / 64); }
 
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv,
-                        unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
-                        hipStream_t s, const KTime *kt) {
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
+                        uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols, hipStream_t s, const KTime *kt) {
     if (cols.n == 0) return;
     const size_t n_nodes = npad >> level;  // caller: n_nodes >= RUN_TILE (a power of two, so a multiple of it)
     const size_t sub_cap = runs_sub_cap(npad, cols.n);
+    const bool fill = level >= meta.virt_levels;
     dim3 grid((unsigned)(n_nodes / RUN_TILE), (unsigned)cols.n);
     size_t hash_wgs = (n_nodes * cols.n + TPB - 1) / TPB;
     if (hash_wgs > 16384) hash_wgs = 16384;  // one hash per thread for lists up to 4 M entries; longer lists are strided over
     // the sub-list counters restart at every level (word 0, the build's total, stays)
     (void)hipMemsetAsync(d_ctr + 16, 0, RUN_SUBS * 128, s);
-    // timing: the three launches of a level are bracketed as one (start of the first, stop of the last)
+    // timing: the launches of a level are bracketed as one (start of the first, stop of the last)
+    hipEvent_t ev_start = kt ? kt->start : nullptr, ev_hash_stop = kt && !fill ? kt->stop : nullptr;
+#define ZK_RUN_LAUNCH(e0, e1, kern, g, ...)                                                            \
+    do {                                                                                               \
+        if ((e0) || (e1)) hipExtLaunchKernelGGL(kern, g, dim3(TPB), 0, s, (e0), (e1), 0, __VA_ARGS__); \
+        else hipLaunchKernelGGL(kern, g, dim3(TPB), 0, s, __VA_ARGS__);                                \
+    } while (0)
+    const dim3 hgrid((unsigned)hash_wgs);
     if (level == 0) {
-        if (kt) hipExtLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
-                                      npad, level, d_uni, d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
-        else hipLaunchKernelGGL(k_runs_flags<true>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
-                                d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
-        hipLaunchKernelGGL(k_runs_hash<true>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                           tree_stride_nodes, level, d_list, sub_cap, d_ctr);
+        ZK_RUN_LAUNCH(ev_start, (hipEvent_t) nullptr, k_runs_flags<true>, grid, d_vals, val_stride, n_values, npad, level, d_uni, d_fv,
+                      meta, d_list, sub_cap, d_ctr, cols);
+        ZK_RUN_LAUNCH((hipEvent_t) nullptr, ev_hash_stop, k_runs_hash<true>, hgrid, d_vals, val_stride, n_values, npad, d_tree,
+                      tree_stride_nodes, level, d_list, sub_cap, d_ctr, meta, cols);
     } else {
-        if (kt) hipExtLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, kt->start, nullptr, 0, d_vals, val_stride, n_values,
-                                      npad, level, d_uni, d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
-        else hipLaunchKernelGGL(k_runs_flags<false>, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, level, d_uni,
-                                d_fv, d_bitmap, d_list, sub_cap, d_ctr, cols);
-        hipLaunchKernelGGL(k_runs_hash<false>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                           tree_stride_nodes, level, d_list, sub_cap, d_ctr);
+        ZK_RUN_LAUNCH(ev_start, (hipEvent_t) nullptr, k_runs_flags<false>, grid, d_vals, val_stride, n_values, npad, level, d_uni, d_fv,
+                      meta, d_list, sub_cap, d_ctr, cols);
+        ZK_RUN_LAUNCH((hipEvent_t) nullptr, ev_hash_stop, k_runs_hash<false>, hgrid, d_vals, val_stride, n_values, npad, d_tree,
+                      tree_stride_nodes, level, d_list, sub_cap, d_ctr, meta, cols);
     }
-    if (kt) hipExtLaunchKernelGGL(k_runs_fill, grid, dim3(TPB), 0, s, nullptr, kt->stop, 0, d_tree, tree_stride_nodes, npad, level,
-                                  d_bitmap, cols);
-    else hipLaunchKernelGGL(k_runs_fill, grid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, level, d_bitmap, cols);
+    if (fill)
+        ZK_RUN_LAUNCH((hipEvent_t) nullptr, kt ? kt->stop : (hipEvent_t) nullptr, k_runs_fill, grid, d_tree, tree_stride_nodes, npad,
+                      level, meta, cols);
+#undef ZK_RUN_LAUNCH
 }
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
@@ -1112,7 +1143,7 @@ void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, u
 __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
                                               unsigned height, const uint32_t *__restrict__ vals, size_t val_stride,
                                               const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
-                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf) {
+                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, RunMeta meta) {
     const size_t col = blockIdx.x;
     const size_t index = idx[col];
     const unsigned l = threadIdx.x;
@@ -1121,7 +1152,10 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
     const uint8_t *t = tree + col * tree_stride_nodes * 32;
     const size_t off = 2 * npad - 2 * (npad >> l);
-    const Digest d = canonical_digest(load_digest(t, off + (ci ^ 1)));  // tree form -> SHA3 bytes at the boundary
+    size_t node = ci ^ 1;
+    const int y = col < 64 ? meta.y_of_col[col] : -1;
+    if (y >= 0 && l < meta.virt_levels) node = run_leader(meta, npad, (unsigned)y, l, node);  // a copy: its leader's digest
+    const Digest d = canonical_digest(load_digest(t, off + node));  // tree form -> SHA3 bytes at the boundary
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
@@ -1130,9 +1164,12 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
 
 void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
                   const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs,
-                  uint32_t *d_leaf, size_t ncols, hipStream_t s) {
+                  uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta) {
+    RunMeta m{};
+    if (meta) m = *meta;
+    else for (int c = 0; c < 64; c++) m.y_of_col[c] = -1;
     hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, height, d_vals,
-                       val_stride, d_idx, d_sib, d_dirs, d_leaf);
+                       val_stride, d_idx, d_sib, d_dirs, d_leaf, m);
 }
 
 __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t node,

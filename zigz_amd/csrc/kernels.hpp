@@ -103,21 +103,31 @@ struct ColMap {
     uint8_t n;
     uint8_t c[64];
 };
-// Run-aware level `level` (0 = leaves) of the columns in `cols` (three launches: flags + list, hash the list, fill the
-// copies): identical digests, but a node that is a copy of its left neighbour (both subtrees uniform, same value) is
-// copied instead of hashed.  d_uni / d_fv: cols.n x npad bytes / words (per node of the levels >= 1: uniform?, first value);
-// d_bitmap: runs_bitmap_words() u64; d_list: runs_list_entries() u32; d_ctr: RUN_CTRS u64, d_ctr[0] += nodes hashed
-// (zeroed by the caller before level 0; the rest are the level's list counters).  Levels must be launched in order from 0.
-// Requires (npad >> level) >= RUN_TILE and npad <= 2^26 (the caller stops at RUN_MIN_NODES).
+// Run-aware levels.  A node that is a copy of its left neighbour (both subtrees uniform, same value) is not hashed, and on
+// the levels < RunMeta::virt_levels its digest is not even written: readers (the next level's hashes, the openings) resolve
+// a node to its "leader" -- the nearest hashed node at or before it in its 4096-node tile -- through the per-level bitmap of
+// hashed nodes and a per-chunk "last hashed node before this chunk".  Levels >= virt_levels are filled in (every digest in
+// HBM), which is what the dense kernels above the run-aware levels and single trees that outlive the call need.
+struct RunMeta {
+    unsigned long long *bitmap;  // per level l at word base(l): [hinted column y][node / 64], bit = hashed
+    unsigned short *prev;        // same indexing: local index (in the tile) of the last hashed node before the chunk
+    unsigned ncols;              // hinted columns
+    unsigned virt_levels;        // levels below this hold digests of hashed nodes only
+    signed char y_of_col[64];    // column -> hinted index, -1 = not hinted
+};
 constexpr unsigned RUN_TILE = 4096;
 constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
-constexpr unsigned RUN_CTRS = 33 * 16;  // u64 words: the build's total + 32 sub-list counters, each in a 128-byte line
+constexpr unsigned RUN_CTRS = 33 * 16;   // u64 words: the build's total + 32 sub-list counters, each in a 128-byte line
 size_t runs_list_entries(size_t npad, size_t ncols);
-size_t runs_bitmap_words(size_t npad, size_t ncols);
+size_t runs_meta_words(size_t npad, size_t ncols);  // entries of RunMeta::bitmap and ::prev for all levels
+// Level `level` (0 = leaves) of the columns in `cols`: flags + device-wide list, hash the list, and -- if level >=
+// meta.virt_levels -- fill in the copies.  d_uni / d_fv: cols.n x npad bytes / words of scratch; d_list:
+// runs_list_entries() u32; d_ctr: RUN_CTRS u64, d_ctr[0] += nodes hashed (zeroed by the caller before level 0).  Levels
+// must be launched in order from 0.  Requires (npad >> level) >= RUN_TILE and npad <= 2^26.
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv,
-                        unsigned long long *d_bitmap, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols,
-                        hipStream_t s, const KTime *kt = nullptr);
+                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
+                        uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols, hipStream_t s,
+                        const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,
@@ -147,7 +157,7 @@ void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, u
 // leaf value -> d_leaf[c].
 void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
                   const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib,
-                  uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s);
+                  uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta = nullptr);
 // copies node `node` of every column's tree into d_out[c][32]
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s);
