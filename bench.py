@@ -266,12 +266,12 @@ def main():
                     "sponge server; without the service this rank's share of the host CPUs minus 2, at most 14).  One proof alone "
                     "is bound by its sequential host transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default "
                     "Merkle build, so a proving service keeps many proofs in flight, one host thread + one HIP stream each: with "
-                    "4 sponge servers x 8 lanes the GPU is the limit (~575 M steps/s); with one core per transcript 14 lanes fit a "
+                    "5 sponge servers x 8 lanes the GPU is the limit (~650 M steps/s); with one core per transcript 14 lanes fit a "
                     "16-CPU share of the host (~490 M)")
     ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
                     "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
                     "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
-                    "bounded by the host cores: 14 lanes, 491 M steps/s); -1 (default) = a quarter of this rank's CPUs, at most 4, "
+                    "bounded by the host cores: 14 lanes, 491 M steps/s); -1 (default) = a third of this rank's CPUs, at most 5, "
                     "or 0 without AVX-512F")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
@@ -403,7 +403,7 @@ def main():
     shard = args.mode == "shard"
     servers = args.sponge_servers
     if servers < 0:
-        servers = 0 if shard or not has_avx512f() else max(1, min(4, host_cpus() // max(world, 1) // 4))
+        servers = 0 if shard or not has_avx512f() else max(1, min(5, host_cpus() // max(world, 1) // 3))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0

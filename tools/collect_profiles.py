@@ -89,9 +89,12 @@ def main():
         shutil.copy(newest("gpurun_out/p2_%s/*/*kernel_stats.csv" % tag), "profiles/%s_%s_kernel_stats.csv" % (ROUND, tag))
     for src_, dst in (("p2_kernels.json", "kernels.json"), ("p2_kernels_plain.json", "kernels_unprofiled.json"),
                       ("p2_bench.json", "final_bench.json"), ("p2_bench_b1.json", "final_bench_b1.json"),
-                      ("p2_bench_b8.json", "final_bench_b8.json"), ("p2_bench_b12.json", "final_bench_b12.json"), ("p2_bench_b16.json", "final_bench_b16.json"),
+                      ("p2_bench_s0.json", "final_bench_own_thread_transcripts.json"),
+                      ("p2_bench_s0_b8.json", "final_bench_own_thread_transcripts_b8.json"),
+                      ("p2_bench_s4.json", "final_bench_4x8.json"), ("p2_bench_s6.json", "final_bench_6x8.json"),
                       ("p2_bench_tables_b8.json", "final_bench_merkle_tables_b8.json"),
                       ("p2_bench_dense_b8.json", "final_bench_merkle_dense_b8.json"), ("p2_bench_all.json", "final_bench_merkle_all.json"),
+                      ("p2_gpu_bound.txt", "gpu_bound_rate.txt"),
                       ("p2_bench_gpus2_rehearsal.json", "bench_gpus2_rehearsal.json"), ("p2_lasso.json", "lasso.json"),
                       ("p2_sumcheck.json", "sumcheck.json"), ("p2_extra.json", "extra.json"), ("p2_configs.jsonl", "configs.jsonl")):
         if os.path.exists(os.path.join("gpurun_out", src_)):
@@ -112,8 +115,9 @@ def main():
                 f.write("%s,%s,%s,%.1f,%.1f\n" % (r["Kernel_Name"].split("(")[0].replace("void ", ""), r.get("Grid_Size_X", ""),
                                                   r.get("Grid_Size_Y", ""), (int(r["Start_Timestamp"]) - t0) / 1e3,
                                                   (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
-    for name in ("final_bench", "final_bench_b1", "final_bench_b8", "final_bench_b12", "final_bench_b16", "final_bench_merkle_tables_b8",
-                 "final_bench_merkle_dense_b8", "final_bench_merkle_all"):
+    for name in ("final_bench", "final_bench_b1", "final_bench_own_thread_transcripts", "final_bench_own_thread_transcripts_b8",
+                 "final_bench_4x8", "final_bench_6x8", "final_bench_merkle_tables_b8", "final_bench_merkle_dense_b8",
+                 "final_bench_merkle_all"):
         pth = "profiles/%s_%s.json" % (ROUND, name)
         if not os.path.exists(pth):
             continue
