@@ -28,6 +28,7 @@ time.  `--mode shard` (one proof per step, its 43 columns sharded over the ranks
 timestamps) and prints its own JSON line; that is the command profiles/r02_kernels_* were taken from.
 """
 import argparse
+import hashlib
 import json
 import os
 import socket
@@ -437,6 +438,12 @@ def main():
                 self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
 
+        def prove_and_digest(self):  # self-check steps (untimed): SHA-256 of the proof, taken on the proving thread while
+            # the borrowed buffer is still this proof's
+            r = self.prove()
+            self.digest = hashlib.sha256(self.proof.tobytes()).hexdigest()
+            return r
+
         def prove_worst(self):  # the register-round-robin trace of the worst-case leg (resident in d_cols by then)
             self.trace_w.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
@@ -524,17 +531,27 @@ def main():
         run_step(Lane.upload_and_prove)
         dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
         pcie = {"dt": dtp}
+        # self-check, untimed: every lane's proof under this build ...
+        run_step(Lane.prove_and_digest)
+        digests = [l.digest for l in lanes]
+        run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
+        self_check = {"lane0_alone_equals_lane0_in_batch": lanes[0].digest == digests[0]}  # single-state code, not the 8-way)
         variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
         for mode in ("regs", "all", "tables", "dense"):
             if mode == args.merkle:
                 continue
             set_merkle_mode(mode)
-            run_step()
+            run_step(Lane.prove_and_digest)
+            # ... must be byte-identical under every other build (dense hashes every node of every tree)
+            self_check["all_lanes_equal_under_" + mode] = [l.digest for l in lanes] == digests
             ks = max(3, min(args.steps, 10))
             dtv, accv, _ = timed(ks)
             variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * B)}
         set_merkle_mode(args.merkle)
         pcie["variants"] = variants
+        pcie["self_check"] = self_check
+        if not all(self_check.values()):
+            raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
         if args.merkle in ("regs", "all"):
@@ -757,6 +774,10 @@ def main():
             out["config"]["pcie_inclusive_ms_per_step"] = pcie["dt"] / args.steps * 1e3
             out["config"]["pcie_inclusive_note"] = ("same batch, but every proof first uploads its trace over PCIe and runs the "
                                                     "witness kernels inside the loop (never reported as value)")
+            if pcie.get("self_check"):
+                out["config"]["self_check"] = dict(pcie["self_check"], note="SHA-256 of every lane's 2^%d proof: identical under every "
+                                                   "Merkle build, and lane 0 alone (single-state transcript code) vs in the batch "
+                                                   "(sponge service)" % nv)
             if pcie.get("variants"):
                 out["config"]["merkle_variants"] = {
                     m: {"value": total_steps * vv["steps"] / vv["dt"], "keccak_permutations_per_proof": vv["perms"]}
