@@ -95,6 +95,20 @@ def test_prove_from_pinned_compact_trace_async(ctx, maker, arg):
             tr.witness_to_device(ctx, d, max(N, 4), wait=False)
             proof = tr.prove(ctx, d, max(N, 4), want_bytes=True)
             assert tr.num_steps == ons and proof == oproof
+        # the pipelined form of bench.py's PCIe-inclusive leg: a SECOND context (its own stream) uploads the next proof's
+        # trace from the same pinned records while the first proves
+        import zigz_amd
+        up = zigz_amd.Context(0)
+        d2 = up.dev_alloc(43 * max(N, 4) * 4)
+        try:
+            for _ in range(3):
+                tr.witness_to_device(up, d2, max(N, 4), wait=False)
+                assert tr.prove(ctx, d, max(N, 4), want_bytes=True) == oproof
+                up.synchronize()
+                d, d2 = d2, d
+        finally:
+            up.dev_free(d2)
+            up.close()
     finally:
         ctx.dev_free(d)
         del tr

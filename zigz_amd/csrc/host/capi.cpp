@@ -127,7 +127,8 @@ extern "C" int zigzh_trace_witness_dev(const zigzh_trace *t, zigz_ctx *ctx, uint
 
 extern "C" int zigzh_trace_witness_dev_async(const zigzh_trace *t, zigz_ctx *ctx, uint32_t *d_cols, size_t stride) {
     return guard([&] {
-        if (t->registered != ctx) throw Error(ZIGZ_ERR_BAD_STATE, "zigzh_trace_witness_dev_async: pin the trace on this context first");
+        // page-locking is a property of the process, not of the context that asked for it: any context may upload from it
+        if (!t->registered) throw Error(ZIGZ_ERR_BAD_STATE, "zigzh_trace_witness_dev_async: pin the trace first (zigzh_trace_pin)");
         check(ctx, zigz_dev_witness_from_steps_async(ctx, t->trace.steps.data(), t->trace.stepCount(), t->num_vars,
                                                      t->trace.initial_regs, d_cols, stride));
     });
