@@ -5,18 +5,21 @@
                     [--no-cpu-baseline] [--kernels]
 
 A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces
-(default: this rank's share of the host CPUs minus 2, at most 14; every trace gets its own complete proof) whose 43 witness columns each are already
+(default: 8 per sponge-server thread, 5 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness columns each are already
 resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of Prover.prove
 (public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v
 challenges, OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and
 the ZIGZ v1 serialisation of the proof.  Nothing is skipped or cached between steps.
 
 Why a batch: one proof is bounded by its own sequential SHA3 transcript on ONE host core (19 bytes absorbed per
-lookup step, ~27 ms at 2^20) while its GPU work takes ~2.6 ms, so a proving service keeps the GPU busy by
-running several proofs per GPU concurrently (one host thread + one HIP stream each).  The same JSON line also
+lookup step, ~27 ms at 2^20) while its GPU work takes ~1.6 ms, so a proving service keeps the GPU busy by
+running many proofs per GPU concurrently (one host thread + one HIP stream each), and advances their transcripts
+8 per host thread in lock step (zigz_host_sponge_servers: 8-way AVX-512 Keccak-f, same bytes absorbed) so that
+the host cores do not become the limit.  The same JSON line also
 carries `single_proof_ms` (one proof at a time), `pcie_inclusive_value` (trace upload + witness kernels inside
 the timed loop), `merkle_variants` (the same batch under the other Merkle builds of --merkle) and
-`register_worst_case_value` (the trace that is worst for the default build), measured right after the timed region.
+`register_worst_case_value` (the trace that is worst for the default build) and `self_check` (SHA-256 of every lane's
+proof: identical under every Merkle build and transcript path), measured right after the timed region.
 
 N > 1: `python bench.py --gpus N` starts the N ranks itself (child `python -m torch.distributed.run`, before this
 process touches torch or HIP) and relays rank 0's JSON line; when a launcher has already set WORLD_SIZE the
