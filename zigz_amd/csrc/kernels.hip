@@ -736,19 +736,22 @@ __global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, 
 
 // ------------------------------------------------------------------ run-aware Merkle levels (node-granular)
 // A node whose subtree holds one value everywhere ("uniform") has the same digest as its left neighbour when that one is
-// uniform with the same value.  Per level, three launches over the hinted columns:
+// uniform with the same value.  Per level, two or three launches over the hinted columns:
 //   k_runs_flags  one workgroup per tile of RUN_TILE consecutive nodes: uniform?  (children uniform + the two halves' first
 //                 values equal; leaves are uniform), copy-of-left?  The nodes that are NOT copies go onto ONE device-wide
 //                 list (a tile reserves its block with one atomic); the first node of a tile is always listed, so the
-//                 copies of a tile never depend on another tile.  The per-chunk "listed" masks go to a bitmap.
+//                 copies of a tile never depend on another tile.  Per 64-node chunk the "listed" mask and the last listed
+//                 node before the chunk go to RunMeta (kept for the life of a commit job).
 //   k_runs_hash   a fixed grid strides over the list: one hash per thread with every lane busy, whatever mix of constant
 //                 and busy columns produced the list (tile-local hashing left the chip idle behind the few busy tiles:
-//                 2.2 ms for the leaves of 31 columns, 0.22 ms for a level of 4096 nodes)
-//   k_runs_fill   per tile: every node takes the digest of the nearest listed node at or before it (find-last-set in
-//                 the chunk's mask, else the last listed node before the chunk); each store instruction writes 1 KiB of
-//                 consecutive tree (16 B per lane, two lanes per node), chunks without copies are skipped.
-// Every digest of the level ends up in HBM, so the tree is the dense one, bit for bit, for ANY input: the values decide,
-// not a hint.  Cost: (change points + tiles) hashes per level instead of one per node, + 32 B written per node.
+//                 2.2 ms for the leaves of 31 columns, 0.22 ms for a level of 4096 nodes).  Children on a level whose
+//                 copies are virtual are read through their leader (run_leader).
+//   k_runs_fill   only on the levels >= RunMeta::virt_levels: per tile, every node takes the digest of the nearest listed
+//                 node at or before it; each store instruction writes 1 KiB of consecutive tree (16 B per lane, two lanes
+//                 per node), chunks without copies are skipped.
+// Whether filled in or read through its leader, every node has the dense tree's digest, bit for bit, for ANY input: the
+// values decide, not a hint.  Cost: (change points + tiles) hashes per level instead of one per node; a filled level also
+// writes 32 B per node.
 __device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, const Digest &d) {
     unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
     q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
