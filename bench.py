@@ -711,6 +711,13 @@ def main():
                 "small_domain_lookup_us": a["small_domain_us"] / solo["n"],
                 "run_aware_levels_us": a["run_aware_us"] / solo["n"],
                 "run_aware_hashed": a["run_aware_hashed"] / solo["n"],
+                # the other hashing kernels of a lone proof, priced the same way (permutations x VALU instructions per hash /
+                # kernel time / peak): small dense level launches, and the run-aware levels with their flag passes included
+                "level_small_frac": (a["keccak_level_small_perms"] * ic["level"] / (a["keccak_level_small_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
+                if a["keccak_level_small_us"] else None,
+                "run_aware_levels_gperm_per_s": (a["run_aware_hashed"] / 1e9 / (a["run_aware_us"] / 1e6)) if a["run_aware_us"] else None,
+                "run_aware_levels_frac": (a["run_aware_hashed"] * ic["level"] / (a["run_aware_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
+                if a["run_aware_us"] else None,
                 "merkle_build_gperm_per_s": a["keccak_permutations"] / 1e9 / (a["merkle_build_us"] / 1e6),
                 "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1),
                 "eval_fold_hbm_frac": (a["bind_vec_bytes"] / 1e9) / (a["bind_vec_us"] / 1e6) / HBM_PEAK_GBS if a["bind_vec_us"] else None,
