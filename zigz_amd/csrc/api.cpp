@@ -1141,6 +1141,10 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
                              stamp(0, (uint64_t)D.n * npad), &D);
     }
+    if (run_meta) {
+        *run_meta = RunMeta{};
+        for (int c = 0; c < 64; c++) run_meta->y_of_col[c] = -1;
+    }
     if (H.n) {
         if (!ctx->d_sd_tables) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
@@ -1150,15 +1154,16 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
         void *todo;
         CHK(ws_get(ctx, WS_DEDUP, sd_todo_words(npad, H.n) * 4, &todo));
+        // in a commit job the leaf digests of these columns are left out (virtual): only an opening reads one, and it
+        // hashes that value itself
+        const bool virt_leaves = run_meta != nullptr && !ctx->run_aware_materialize;
         launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
-                                (uint32_t *)todo, ctx->stream, stamp(3, 0));
+                                (uint32_t *)todo, ctx->stream, stamp(3, 0), !virt_leaves);
+        if (virt_leaves)
+            for (unsigned k = 0; k < H.n; k++) run_meta->virtual_leaves |= 1ull << H.c[k];
         ctx->stats.small_domain_columns = H.n;
     }
     unsigned run_top = 0;  // R columns: levels 0..run_top come from the run-aware kernel
-    if (run_meta) {
-        *run_meta = RunMeta{};
-        for (int c = 0; c < 64; c++) run_meta->y_of_col[c] = -1;
-    }
     if (R.n) {
         run_top = height - log2_floor(RUN_MIN_NODES);  // the last level with RUN_MIN_NODES nodes per column
         // scratch: per hinted column and node of the levels >= 1 a "first value" word and a "uniform?" byte | the list of the
@@ -1181,7 +1186,10 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         meta.virt_levels = virt ? run_top : 0;  // the top run-aware level is always filled in: the dense kernels read it
         for (int c = 0; c < 64; c++) meta.y_of_col[c] = -1;
         for (unsigned y = 0; y < R.n; y++) meta.y_of_col[R.c[y]] = (signed char)y;
-        if (run_meta) *run_meta = meta;
+        if (run_meta) {
+            meta.virtual_leaves = run_meta->virtual_leaves;
+            *run_meta = meta;
+        }
         HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
         for (unsigned l = 0; l <= run_top; l++) {
             launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, fv, meta, list, ctx->d_run_count, R,
@@ -1310,7 +1318,8 @@ static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad,
     uint32_t *d_leaf = (uint32_t *)(d_sib + sib_b);
     uint8_t *d_dirs = (uint8_t *)(d_leaf + ncols);
     HIPCHK(ctx, hipMemcpyAsync(d_idx, h_idx, idx_b, hipMemcpyHostToDevice, ctx->stream));
-    launch_paths(d_tree, tree_nodes(npad), npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols,
+    // (n_values = npad: leaf digests are virtual only in commit jobs, whose columns have exactly npad values)
+    launch_paths(d_tree, tree_nodes(npad), npad, npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols,
                  ctx->stream, run_meta);
     HIPCHK(ctx, hipGetLastError());
     std::vector<uint32_t> hl(ncols);

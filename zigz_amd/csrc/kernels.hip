@@ -860,7 +860,7 @@ __global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__
             // this tile's block of the level's list.  The list is split into RUN_SUBS sub-lists with a counter each, every
             // counter in a 128-byte line of its own: reservations into ONE word serialise at ~15 ns each (8 k tiles: 0.2 ms)
             const unsigned sub = (blockIdx.y * gridDim.x + blockIdx.x) % RUN_SUBS;
-            s_base = (size_t)sub * sub_cap + atomicAdd(&ctr[(1 + sub) * 16], (unsigned long long)incl);
+            s_base = (size_t)sub * sub_cap + atomicAdd(&ctr[(1 + L * RUN_SUBS + sub) * 16], (unsigned long long)incl);
         }
     }
     __syncthreads();
@@ -883,7 +883,7 @@ __global__ __launch_bounds__(TPB) void k_runs_hash(const uint32_t *__restrict__ 
     __shared__ unsigned long long s_start[RUN_SUBS + 1];  // exclusive prefix of the sub-list lengths
     if (threadIdx.x < 64) {
         static_assert(RUN_SUBS <= 64, "one lane per sub-list");
-        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + threadIdx.x) * 16] : 0;
+        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + L * RUN_SUBS + threadIdx.x) * 16] : 0;
         unsigned long long incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -983,8 +983,6 @@ void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_valu
     dim3 grid((unsigned)(n_nodes / RUN_TILE), (unsigned)cols.n);
     size_t hash_wgs = (n_nodes * cols.n + TPB - 1) / TPB;
     if (hash_wgs > 16384) hash_wgs = 16384;  // one hash per thread for lists up to 4 M entries; longer lists are strided over
-    // the sub-list counters restart at every level (word 0, the build's total, stays)
-    (void)hipMemsetAsync(d_ctr + 16, 0, RUN_SUBS * 128, s);
     // timing: the launches of a level are bracketed as one (start of the first, stop of the last)
     hipEvent_t ev_start = kt ? kt->start : nullptr, ev_hash_stop = kt && !fill ? kt->stop : nullptr;
 #define ZK_RUN_LAUNCH(e0, e1, kern, g, ...)                                                            \
@@ -1059,7 +1057,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__rest
                                                           size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                           ColMap cmap, const uint8_t *__restrict__ tables,
                                                           unsigned long long *__restrict__ todo_count,
-                                                          uint32_t *__restrict__ todo) {
+                                                          uint32_t *__restrict__ todo, int write_leaves) {
     const size_t col = cmap.c[blockIdx.y];
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;  // level-1 node
     const bool live = i < npad / 2;
@@ -1081,17 +1079,22 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__rest
             const uint4 *t0 = reinterpret_cast<const uint4 *>(tables);
             const uint4 *t1 = reinterpret_cast<const uint4 *>(tables + (size_t)SD_DOMAIN * 32);
             const size_t e = (size_t)x.x * SD_DOMAIN + x.y;
-            mine[4 * lane + 0] = t0[2 * x.x];
-            mine[4 * lane + 1] = t0[2 * x.x + 1];
-            mine[4 * lane + 2] = t0[2 * x.y];
-            mine[4 * lane + 3] = t0[2 * x.y + 1];
+            if (write_leaves) {  // (a commit job leaves them out: nothing but an opening reads a leaf digest of these
+                // columns, and k_paths hashes that one value itself)
+                mine[4 * lane + 0] = t0[2 * x.x];
+                mine[4 * lane + 1] = t0[2 * x.x + 1];
+                mine[4 * lane + 2] = t0[2 * x.y];
+                mine[4 * lane + 3] = t0[2 * x.y + 1];
+            }
             mine[256 + 2 * lane + 0] = t1[2 * e];
             mine[256 + 2 * lane + 1] = t1[2 * e + 1];
             __builtin_amdgcn_wave_barrier();  // LDS is in order within a wave; keep the compiler from moving the reads up
             const size_t w0 = i - lane;       // first node of this wave
             uint4 *leaves = reinterpret_cast<uint4 *>(t + 2 * w0 * 32), *nodes = reinterpret_cast<uint4 *>(t + (npad + w0) * 32);
+            if (write_leaves) {
 #pragma unroll
-            for (int k = 0; k < 4; k++) nt_store16(leaves + 64 * k + lane, mine[64 * k + lane]);
+                for (int k = 0; k < 4; k++) nt_store16(leaves + 64 * k + lane, mine[64 * k + lane]);
+            }
 #pragma unroll
             for (int k = 0; k < 2; k++) nt_store16(nodes + 64 * k + lane, mine[256 + 64 * k + lane]);
         }
@@ -1106,7 +1109,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
                                                                size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                                size_t tree_stride_nodes, ColMap cmap,
                                                                const unsigned long long *__restrict__ todo_count,
-                                                               const uint32_t *__restrict__ todo) {
+                                                               const uint32_t *__restrict__ todo, int write_leaves) {
     const unsigned long long count = *todo_count;
     const unsigned lane = threadIdx.x & 63;
     for (unsigned long long w = (unsigned long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); w < count;
@@ -1118,22 +1121,25 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
         const uint32_t *v = vals + col * val_stride;
         const uint64_t v0 = 2 * i < n_values ? v[2 * i] : 0, v1 = 2 * i + 1 < n_values ? v[2 * i + 1] : 0;
         const Digest l0 = sha3_leaf(v0), l1 = sha3_leaf(v1);
-        store_digest(t, 2 * i, l0);
-        store_digest(t, 2 * i + 1, l1);
+        if (write_leaves) {
+            store_digest(t, 2 * i, l0);
+            store_digest(t, 2 * i + 1, l1);
+        }
         store_digest(t, npad + i, sha3_node(l0, l1));
     }
 }
 
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
-                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt) {
+                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt,
+                             bool write_leaves) {
     if (cols.n == 0 || npad < 2) return;
     dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
     ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
-              d_tables, d_todo_count, d_todo);
+              d_tables, d_todo_count, d_todo, write_leaves ? 1 : 0);
     // list-driven; 512 workgroups walk the to-do list (empty unless a hint was wrong: then a few microseconds)
     hipLaunchKernelGGL(k_keccak_small_fallback, dim3(512), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                       tree_stride_nodes, cols, d_todo_count, d_todo);
+                       tree_stride_nodes, cols, d_todo_count, d_todo, write_leaves ? 1 : 0);
 }
 
 void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
@@ -1144,7 +1150,7 @@ void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, u
 
 // ------------------------------------------------------------------ K7: authentication paths
 __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                              unsigned height, const uint32_t *__restrict__ vals, size_t val_stride,
+                                              size_t n_values, unsigned height, const uint32_t *__restrict__ vals, size_t val_stride,
                                               const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
                                               uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, RunMeta meta) {
     const size_t col = blockIdx.x;
@@ -1158,20 +1164,24 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     size_t node = ci ^ 1;
     const int y = col < 64 ? meta.y_of_col[col] : -1;
     if (y >= 0 && l < meta.virt_levels) node = run_leader(meta, npad, (unsigned)y, l, node);  // a copy: its leader's digest
-    const Digest d = canonical_digest(load_digest(t, off + node));  // tree form -> SHA3 bytes at the boundary
+    Digest d;
+    if (l == 0 && col < 64 && ((meta.virtual_leaves >> col) & 1))  // leaf digests of this column were never written
+        d = sha3_leaf(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
+    else d = load_digest(t, off + node);
+    d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
     dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
 }
 
-void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
+void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, size_t n_values, unsigned height,
                   const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs,
                   uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta) {
     RunMeta m{};
     if (meta) m = *meta;
     else for (int c = 0; c < 64; c++) m.y_of_col[c] = -1;
-    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, height, d_vals,
+    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, n_values, height, d_vals,
                        val_stride, d_idx, d_sib, d_dirs, d_leaf, m);
 }
 

@@ -113,16 +113,20 @@ struct RunMeta {
     unsigned short *prev;        // same indexing: local index (in the tile) of the last hashed node before the chunk
     unsigned ncols;              // hinted columns
     unsigned virt_levels;        // levels below this hold digests of hashed nodes only
+    unsigned long long virtual_leaves;  // bit c: the leaf digests of column c were not written (small-domain columns of a
+                                        // commit job): an opening hashes the sibling value itself
     signed char y_of_col[64];    // column -> hinted index, -1 = not hinted
 };
 constexpr unsigned RUN_TILE = 4096;
 constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
-constexpr unsigned RUN_CTRS = 33 * 16;   // u64 words: the build's total + 32 sub-list counters, each in a 128-byte line
+constexpr unsigned RUN_MAX_LEVELS = 16;  // run-aware levels of a 2^26-leaf tree: 0 .. 26 - 14
+constexpr unsigned RUN_CTRS = (1 + RUN_MAX_LEVELS * 32) * 16;  // u64 words: the build's total + per level 32 sub-list counters,
+                                                               // each in a 128-byte line of its own
 size_t runs_list_entries(size_t npad, size_t ncols);
 size_t runs_meta_words(size_t npad, size_t ncols);  // entries of RunMeta::bitmap and ::prev for all levels
 // Level `level` (0 = leaves) of the columns in `cols`: flags + device-wide list, hash the list, and -- if level >=
 // meta.virt_levels -- fill in the copies.  d_uni / d_fv: cols.n x npad bytes / words of scratch; d_list:
-// runs_list_entries() u32; d_ctr: RUN_CTRS u64, d_ctr[0] += nodes hashed (zeroed by the caller before level 0).  Levels
+// runs_list_entries() u32; d_ctr: RUN_CTRS u64, zeroed by the caller before level 0 (d_ctr[0] += nodes hashed).  Levels
 // must be launched in order from 0.  Requires (npad >> level) >= RUN_TILE and npad <= 2^26.
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                         size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
@@ -147,7 +151,8 @@ void launch_sd_tables(uint8_t *d_tables, hipStream_t s);
 inline size_t sd_todo_words(size_t npad, size_t ncols) { return 2 * ncols * ((npad / 2 + 63) / 64) + 2; }
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
-                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr);
+                             unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr,
+                             bool write_leaves = true);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
@@ -155,7 +160,7 @@ void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, u
                        size_t ncols, hipStream_t s);
 // K7: authentication paths.  For column c: index d_idx[c]; siblings -> d_sib[c][l][32], dirs -> d_dirs[c][l],
 // leaf value -> d_leaf[c].
-void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned height,
+void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, size_t n_values, unsigned height,
                   const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib,
                   uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta = nullptr);
 // copies node `node` of every column's tree into d_out[c][32]
