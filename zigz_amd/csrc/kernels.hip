@@ -1018,7 +1018,10 @@ void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_va
               tree_stride_nodes, cm);
 }
 
-bool keccak_level_is_wide(size_t n_out, size_t ncols) { return n_out * ncols >= (size_t)TPB * HPT * 4096; }
+#ifndef ZK_WIDE_MIN_WGS
+#define ZK_WIDE_MIN_WGS 4096  // (512, i.e. four hashes per thread down to 0.5 M nodes: 1.585 against 1.555 ms of GPU per proof at 14
+#endif                        // lanes, tools/ab_runs.sh -- the small levels want the waves)
+bool keccak_level_is_wide(size_t n_out, size_t ncols) { return n_out * ncols >= (size_t)TPB * HPT * ZK_WIDE_MIN_WGS; }
 
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
                          size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
