@@ -59,6 +59,8 @@ struct VMState::Mem {
     std::unordered_map<uint64_t, std::unique_ptr<uint8_t[]>> pages;
     uint64_t last_tag = ~0ull;
     uint8_t *last = nullptr;
+    uint64_t fetch_tag = ~0ull;  // page of the last instruction fetch (see fetch())
+    const uint8_t *fetch_page = nullptr;
     uint8_t *page(uint64_t addr, bool create) {
         const uint64_t tag = addr / PAGE;
         if (tag == last_tag) return last;
@@ -67,6 +69,7 @@ struct VMState::Mem {
             if (!create) return nullptr;
             auto p = std::unique_ptr<uint8_t[]>(new uint8_t[PAGE]());
             it = pages.emplace(tag, std::move(p)).first;
+            fetch_tag = ~0ull;  // a fetch from this page may have cached "unmapped"
         }
         last_tag = tag;
         last = it->second.get();
@@ -78,12 +81,38 @@ struct VMState::Mem {
     }
     void sb(uint64_t a, uint8_t v) { page(a, true)[a % PAGE] = v; }
     uint64_t load(uint64_t a, int n) {
+        if ((a % PAGE) + (uint64_t)n <= PAGE) {  // inside one page (the common case): one copy, little-endian host
+            const uint8_t *p = page(a, false);
+            uint64_t v = 0;
+            if (p) memcpy(&v, p + a % PAGE, (size_t)n);
+            return v;
+        }
         uint64_t v = 0;
         for (int b = 0; b < n; b++) v |= (uint64_t)lb(a + (uint64_t)b) << (8 * b);
         return v;
     }
     void store(uint64_t a, uint64_t v, int n) {
+        if ((a % PAGE) + (uint64_t)n <= PAGE) {
+            memcpy(page(a, true) + a % PAGE, &v, (size_t)n);
+            return;
+        }
         for (int b = 0; b < n; b++) sb(a + (uint64_t)b, (uint8_t)(v >> (8 * b)));
+    }
+    // instruction fetch: code and data alternate in a loop, so the page of the last fetch is remembered separately from
+    // the page of the last data access
+    uint32_t fetch(uint64_t pc) {
+        if ((pc % PAGE) + 4 <= PAGE) {
+            const uint64_t tag = pc / PAGE;
+            if (tag != fetch_tag) {
+                auto it = pages.find(tag);
+                fetch_page = it == pages.end() ? nullptr : it->second.get();
+                fetch_tag = tag;
+            }
+            uint32_t w = 0;
+            if (fetch_page) memcpy(&w, fetch_page + pc % PAGE, 4);
+            return w;
+        }
+        return (uint32_t)load(pc, 4);
     }
 };
 
@@ -282,7 +311,7 @@ std::vector<uint64_t> ExecutionTrace::expandRows() const {
 void VMState::step() {  // state.zig:128-167
     if (halted) throw Error(ERR_VM_HALTED, "error.VMHalted");
     Instruction in;
-    if (!Instruction::decode((uint32_t)mem_->load(pc, 4), in)) {
+    if (!Instruction::decode(mem_->fetch(pc), in)) {
         halted = true;
         invalid_instruction = true;  // error.InvalidInstruction: no step recorded
         return;
