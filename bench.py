@@ -67,11 +67,13 @@ def free_port():
 
 
 MERKLE_BUILDS = {  # --merkle: what config.merkle_build says
-    "regs": "leaf + level-1 digests of the 8 structurally small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, "
-            "is_read: values < 128 by construction) from constant tables; large levels of the 31 register columns x1..x31 (at "
-            "most one of them changes per step, whatever the program) run-aware: a node that repeats its left neighbour is "
-            "copied, decided from the values on the device; the other 4 columns dense; identical trees",
-    "all": "as regs, with every column that is not small-domain run-aware (pc, imm, mem.address, mem.value too)",
+    "struct": "leaf + level-1 digests of the 8 structurally small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, "
+              "is_read: values < 128 by construction) from constant tables; large levels of the 31 register columns x1..x31 "
+              "(at most one of them changes per step, whatever the program) and of mem.address / mem.value (0 on every step "
+              "that is not a LOAD / STORE) run-aware: a node that repeats its left neighbour is neither hashed nor written, "
+              "decided from the values on the device; pc and imm dense; identical trees",
+    "regs": "as struct, but only the 31 register columns run-aware (mem.address / mem.value dense)",
+    "all": "as struct, with every column that is not small-domain run-aware (pc and imm too)",
     "tables": "dense; leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, identical trees",
     "dense": "dense: every node of every column hashed",
 }
@@ -283,12 +285,14 @@ def main():
                     "GPUs (two all-gathers of 43 x 32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the "
                     "sequential host transcript that every rank replays (DESIGN.md s7)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
-    ap.add_argument("--merkle", choices=["regs", "all", "tables", "dense"], default="regs",
-                    help="Merkle build of the 43 columns (identical trees and proofs in every mode).  regs (the product's "
-                    "default): leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, and the 31 "
-                    "register columns x1..x31 -- at most one of them changes per step, whatever the program -- with run-aware "
-                    "large levels (a node that repeats its left neighbour is copied, not hashed).  all: every other column "
-                    "run-aware too.  tables: the tables only (round 2's first default).  dense: hash every node")
+    ap.add_argument("--merkle", choices=["struct", "regs", "all", "tables", "dense"], default="struct",
+                    help="Merkle build of the 43 columns (identical trees and proofs in every mode).  struct (the product's "
+                    "default): leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, and the "
+                    "columns that are piecewise constant by construction -- the 31 registers x1..x31 (at most one of them changes "
+                    "per step) and mem.address / mem.value (0 on every step without a memory access) -- with run-aware large "
+                    "levels (a node that repeats its left neighbour is copied, not hashed).  regs: the registers only.  all: "
+                    "every column that is not small-domain.  tables: the tables only (round 2's first default).  dense: hash "
+                    "every node")
     ap.add_argument("--dedup", action="store_true", help="same as --merkle all")
     ap.add_argument("--dense-merkle", action="store_true", help="same as --merkle dense")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -381,7 +385,7 @@ def main():
         if mode == "dense":
             os.environ["ZIGZ_DENSE_MERKLE"] = "1"
         else:
-            os.environ["ZIGZ_RUN_AWARE"] = {"regs": "regs", "all": "all", "tables": "off"}[mode]
+            os.environ["ZIGZ_RUN_AWARE"] = {"struct": "struct", "regs": "regs", "all": "all", "tables": "off"}[mode]
     set_merkle_mode(args.merkle)
     import zigz_amd
     from zigz_amd import host
@@ -550,7 +554,7 @@ def main():
         run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
         self_check = {"lane0_alone_equals_lane0_in_batch": lanes[0].digest == digests[0]}  # single-state code, not the 8-way)
         variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
-        for mode in ("regs", "all", "tables", "dense"):
+        for mode in ("struct", "regs", "all", "tables", "dense"):
             if mode == args.merkle:
                 continue
             set_merkle_mode(mode)
@@ -567,7 +571,7 @@ def main():
             raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
-        if args.merkle in ("regs", "all"):
+        if args.merkle in ("struct", "regs", "all"):
             # The run-aware register levels make the GPU time depend on the trace.  Its worst case by construction: a loop
             # that writes 30 different registers in turn, so the <= N change points of the 31 register columns are spread
             # evenly over all of them (tests/programs.py register_round_robin).  Same batch, same everything else; the lanes'
@@ -811,8 +815,8 @@ def main():
                     "the same batch on the trace that is worst for the run-aware register levels: a loop writing 30 different "
                     "registers in turn (each register column changes every 31 steps; tests/programs.py register_round_robin)")
                 out["config"]["merkle_variants_note"] = ("the same batch under the other Merkle builds of --merkle (identical "
-                                                         "proofs; regs = default, all = every column run-aware, tables = "
-                                                         "small-domain tables only, dense = every node hashed)")
+                                                         "proofs; struct = default, regs = registers only, all = every column run-aware, "
+                                                         "tables = small-domain tables only, dense = every node hashed)")
         out["kernels"] = {"timed_region": {
             "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,
             "keccak_leaves_ms_per_proof": acc["keccak_leaves_us"] / nproofs / 1e3,

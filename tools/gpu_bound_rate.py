@@ -23,7 +23,8 @@ from zigz_amd import host  # noqa: E402
 ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=14)
 ap.add_argument("--iters", type=int, default=20)
-ap.add_argument("--trace", default="add_xor")
+ap.add_argument("--trace", default="add_xor", help="add_xor | round_robin | mixed (RV64IM mix with loads / stores, BASELINE config 4's loop)")
+ap.add_argument("--hint", default="regs", help="run-aware hint: regs | regs+mem | all")
 args = ap.parse_args()
 nv = 20
 N = 1 << nv
@@ -35,13 +36,15 @@ rng = np.random.default_rng(1)
 class Lane:
     def __init__(self, k):
         self.ctx = zigz_amd.Context(0)
-        prog = programs.add_xor_loop((N - 3) // 4 - k) if args.trace == "add_xor" else programs.register_round_robin((N - 2) // 31 - k)
+        prog = (programs.add_xor_loop((N - 3) // 4 - k) if args.trace == "add_xor" else
+                programs.mixed_loop((N - 8) // 12 - k) if args.trace == "mixed" else
+                programs.register_round_robin((N - 2) // 31 - k))
         self.tr = host.Trace(prog, 0x1000, None, 2 * N)
         self.d = self.ctx.dev_alloc(43 * N * 4)
         self.tr.witness_to_device(self.ctx, self.d, N)
         self.points = rng.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
         self.ctx.set_option("small_domain_mask", SMALL)
-        self.ctx.set_option("run_aware_mask", REGS)
+        self.ctx.set_option("run_aware_mask", {"regs": REGS, "regs+mem": REGS | (3 << 40), "all": ((1 << 43) - 1) & ~SMALL}[args.hint])
 
     def once(self):
         job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)
@@ -66,5 +69,5 @@ th = [threading.Thread(target=loop, args=(l,)) for l in lanes]
 [t.join() for t in th]
 dt = time.perf_counter() - t0
 n = args.lanes * args.iters
-print("%s: %d lanes: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
-      (args.trace, args.lanes, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))
+print("%s (hint %s): %d lanes: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
+      (args.trace, args.hint, args.lanes, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))

@@ -89,8 +89,8 @@ bool Prover::defaultSmallDomain() {
 int Prover::defaultRunAware() {
     if (!defaultSmallDomain()) return 0;
     const char *e = getenv("ZIGZ_RUN_AWARE");
-    if (!e || !e[0]) return 1;
-    return strcmp(e, "off") == 0 ? 0 : strcmp(e, "all") == 0 ? 2 : 1;
+    if (!e || !e[0]) return 3;
+    return strcmp(e, "off") == 0 ? 0 : strcmp(e, "regs") == 0 ? 1 : strcmp(e, "all") == 0 ? 2 : 3;
 }
 
 void Prover::bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs) {
@@ -254,10 +254,14 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     // The register columns x1..x31 are piecewise constant by construction: a step writes at most one register
     // (VMState.writeReg, src/vm/state.zig), so together they change at most once per step.  Their large Merkle levels are
     // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
-    // the values on the device; identical trees for any input).  run_aware == 2 hints every column that is not small-domain.
+    // the values on the device; identical trees for any input).  So are mem.address and mem.value between memory accesses:
+    // a step that is not a LOAD / STORE records 0 in both (witness.zig:236-253), so each of them changes at most twice per
+    // memory access.  run_aware: 1 = the registers, 3 (default) = registers + the two memory columns, 2 = every column that
+    // is not small-domain.
     if (run_aware) {
         const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
-        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : 0x7fffffffull << 2;
+        const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
+        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware == 3 ? regs | mem : regs;
         check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
     }
     struct MaskReset {
