@@ -5,14 +5,14 @@
                     [--no-cpu-baseline] [--kernels]
 
 A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces
-(default: 8 per sponge-server thread, 5 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness columns each are already
+(default: 8 per sponge-server thread, 6 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness columns each are already
 resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of Prover.prove
 (public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v
 challenges, OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and
 the ZIGZ v1 serialisation of the proof.  Nothing is skipped or cached between steps.
 
 Why a batch: one proof is bounded by its own sequential SHA3 transcript on ONE host core (19 bytes absorbed per
-lookup step, ~27 ms at 2^20) while its GPU work takes ~1.6 ms, so a proving service keeps the GPU busy by
+lookup step, ~27 ms at 2^20) while its GPU work takes ~0.9 ms, so a proving service keeps the GPU busy by
 running many proofs per GPU concurrently (one host thread + one HIP stream each), and advances their transcripts
 8 per host thread in lock step (zigz_host_sponge_servers: 8-way AVX-512 Keccak-f, same bytes absorbed) so that
 the host cores do not become the limit.  The same JSON line also
@@ -67,6 +67,10 @@ def free_port():
 
 
 MERKLE_BUILDS = {  # --merkle: what config.merkle_build says
+    "cons": "as struct, and the ten columns that are functions of the instruction at pc (pc, x0, opcode, rd, rs1, rs2, funct3, "
+            "funct7, imm, is_read) as a content-addressed group: per level a device hash table finds the first node with the same "
+            "content in all ten, only those representatives are hashed (a loop of P steps has at most P distinct nodes per "
+            "level); probed on the leaves first and dropped for a trace that does not repeat; identical trees",
     "struct": "leaf + level-1 digests of the 8 structurally small-domain columns (x0, opcode, rd, rs1, rs2, funct3, funct7, "
               "is_read: values < 128 by construction) from constant tables; large levels of the 31 register columns x1..x31 "
               "(at most one of them changes per step, whatever the program) and of mem.address / mem.value (0 on every step "
@@ -272,22 +276,23 @@ def main():
                     "sponge server; without the service this rank's share of the host CPUs minus 2, at most 14).  One proof alone "
                     "is bound by its sequential host transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default "
                     "Merkle build, so a proving service keeps many proofs in flight, one host thread + one HIP stream each: with "
-                    "5 sponge servers x 8 lanes the GPU is the limit (~650 M steps/s); with one core per transcript 14 lanes fit a "
-                    "16-CPU share of the host (~490 M)")
+                    "6 sponge servers x 8 lanes ~1.0 G steps/s (each more server adds ~150 M until the GPU's 0.86 ms per proof is "
+                    "reached at 8 x 8, 235 GB of HBM); with one core per transcript 14 lanes fit a 16-CPU share of the host (~480 M)")
     ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
                     "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
                     "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
-                    "bounded by the host cores: 14 lanes, 491 M steps/s); -1 (default) = a third of this rank's CPUs, at most 5, "
-                    "or 0 without AVX-512F")
+                    "bounded by the host cores: 14 lanes, ~480 M steps/s); -1 (default) = a third of this rank's CPUs + 1, at most 6 "
+                    "(48 proofs in flight: 163 GiB of HBM), or 0 without AVX-512F")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
                     "GPUs (two all-gathers of 43 x 32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the "
                     "sequential host transcript that every rank replays (DESIGN.md s7)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
-    ap.add_argument("--merkle", choices=["struct", "regs", "all", "tables", "dense"], default="struct",
-                    help="Merkle build of the 43 columns (identical trees and proofs in every mode).  struct (the product's "
-                    "default): leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, and the "
+    ap.add_argument("--merkle", choices=["cons", "struct", "regs", "all", "tables", "dense"], default="cons",
+                    help="Merkle build of the 43 columns (identical trees and proofs in every mode).  cons (the product's default): "
+                    "struct + the ten instruction-determined columns as a content-addressed group (repeat wherever the program "
+                    "loops).  struct: leaf + level-1 digests of the 8 structurally small-domain columns from constant tables, and the "
                     "columns that are piecewise constant by construction -- the 31 registers x1..x31 (at most one of them changes "
                     "per step) and mem.address / mem.value (0 on every step without a memory access) -- with run-aware large "
                     "levels (a node that repeats its left neighbour is copied, not hashed).  regs: the registers only.  all: "
@@ -385,7 +390,7 @@ def main():
         if mode == "dense":
             os.environ["ZIGZ_DENSE_MERKLE"] = "1"
         else:
-            os.environ["ZIGZ_RUN_AWARE"] = {"struct": "struct", "regs": "regs", "all": "all", "tables": "off"}[mode]
+            os.environ["ZIGZ_RUN_AWARE"] = {"cons": "cons", "struct": "struct", "regs": "regs", "all": "all", "tables": "off"}[mode]
     set_merkle_mode(args.merkle)
     import zigz_amd
     from zigz_amd import host
@@ -411,7 +416,7 @@ def main():
     shard = args.mode == "shard"
     servers = args.sponge_servers
     if servers < 0:
-        servers = 0 if shard or not has_avx512f() else max(1, min(5, host_cpus() // max(world, 1) // 3))
+        servers = 0 if shard or not has_avx512f() else max(1, min(6, host_cpus() // max(world, 1) // 3 + 1))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
@@ -554,7 +559,7 @@ def main():
         run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
         self_check = {"lane0_alone_equals_lane0_in_batch": lanes[0].digest == digests[0]}  # single-state code, not the 8-way)
         variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
-        for mode in ("struct", "regs", "all", "tables", "dense"):
+        for mode in ("cons", "struct", "regs", "all", "tables", "dense"):
             if mode == args.merkle:
                 continue
             set_merkle_mode(mode)
@@ -571,7 +576,7 @@ def main():
             raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
-        if args.merkle in ("struct", "regs", "all"):
+        if args.merkle in ("cons", "struct", "regs", "all"):
             # The run-aware register levels make the GPU time depend on the trace.  Its worst case by construction: a loop
             # that writes 30 different registers in turn, so the <= N change points of the 31 register columns are spread
             # evenly over all of them (tests/programs.py register_round_robin).  Same batch, same everything else; the lanes'
@@ -698,13 +703,14 @@ def main():
                 pass
         if solo:
             a = solo["acc"]
-            ach = a["keccak_leaves_perms"] * ic["leaves"] / (a["keccak_leaves_us"] / 1e6) / 1e12
+            # (with the default build no column is hashed densely from the leaves any more: no k_keccak_leaves launch in a proof)
+            ach = a["keccak_leaves_perms"] * ic["leaves"] / (a["keccak_leaves_us"] / 1e6) / 1e12 if a["keccak_leaves_us"] else None
             roof.update({
-                "in_proof_achieved": ach, "in_proof_frac": ach / VALU_PEAK_TOPS,
+                "in_proof_achieved": ach, "in_proof_frac": ach / VALU_PEAK_TOPS if ach else None,
                 "in_proof_note": "the %d k_keccak_leaves launches of the single-proof leg (one proof on the GPU at a time: every "
                                  "build starts after ~20 ms of idle GPU while the host absorbs the transcript)" % solo["n"],
                 "in_proof_avg_launch_us": a["keccak_leaves_us"] / solo["n"],
-                "in_proof_gperm_per_s": a["keccak_leaves_perms"] / 1e9 / (a["keccak_leaves_us"] / 1e6),
+                "in_proof_gperm_per_s": (a["keccak_leaves_perms"] / 1e9 / (a["keccak_leaves_us"] / 1e6)) if a["keccak_leaves_us"] else None,
                 "level_wide_gperm_per_s": (a["keccak_level_wide_perms"] / 1e9 / (a["keccak_level_wide_us"] / 1e6))
                 if a["keccak_level_wide_us"] else None,
                 "level_wide_frac": (a["keccak_level_wide_perms"] * ic["level"] / (a["keccak_level_wide_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
@@ -815,7 +821,7 @@ def main():
                     "the same batch on the trace that is worst for the run-aware register levels: a loop writing 30 different "
                     "registers in turn (each register column changes every 31 steps; tests/programs.py register_round_robin)")
                 out["config"]["merkle_variants_note"] = ("the same batch under the other Merkle builds of --merkle (identical "
-                                                         "proofs; struct = default, regs = registers only, all = every column run-aware, "
+                                                         "proofs; cons = default, struct = without the content-addressed group, regs = registers only, all = every column run-aware, "
                                                          "tables = small-domain tables only, dense = every node hashed)")
         out["kernels"] = {"timed_region": {
             "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,

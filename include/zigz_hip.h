@@ -326,6 +326,12 @@ typedef struct zigz_kernel_stats {
     uint64_t run_aware_dense_nodes;
     uint64_t run_aware_hashed;
     double run_aware_us;
+    /* content-addressed levels (option "cons_group_mask") of the last batched commit: columns of the group, the nodes of the
+     * levels they covered (what a dense build hashes there) and the digests actually computed (representatives x columns) */
+    uint64_t cons_columns;
+    uint64_t cons_dense_nodes;
+    uint64_t cons_hashed;
+    uint64_t cons_probe_distinct; /* distinct leaves (tuples) of the group found by the probe; > 1/4 of the leaves: cons_columns = 0 */
     /* Keccak launches of the last batched commit by class, each launch timed with its own begin / end timestamps
      * (kernel time as rocprofv3 --kernel-trace reports it; the gaps between launches are in merkle_build_us only):
      * k_keccak_leaves; k_keccak_level<4> (the large levels); k_keccak_level<1> (the small levels); hashes = permutations */
@@ -370,6 +376,16 @@ zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
  *   level's hashes and zigz_commit_open_all read a copy through a per-level bitmap of hashed nodes (2 GB less HBM traffic per
  *   2^20 x 43 build).  "run_aware_materialize" = 1 writes them all (tests that compare whole trees); single trees
  *   (zigz_merkle_commit) always hold every digest.
+ * "cons_group_mask" = bit c set: the columns of this set repeat in the same places -- in the witness of prover.zig:376-390
+ *   the ten columns that are functions of the instruction at pc (pc, x0, opcode, rd, rs1, rs2, funct3, funct7, imm, is_read):
+ *   wherever the program loops, the same nodes recur in all of them, at most P distinct ones per level for a loop of P steps.
+ *   On the levels with >= 16384 nodes a device hash table finds for every node the first node of its level with the same
+ *   content in ALL columns of the group (leaves: the tuple of values, fingerprinted and verified; above: the pair of the
+ *   children's representatives -- the identity of the hash input itself), and only representatives are hashed, once per
+ *   column.  Takes precedence over the two hints above; identical trees for ANY input; in a commit job the other nodes are
+ *   virtual like run-aware copies.  The leaf level is probed first (one table pass + a read-back of the number of distinct
+ *   leaves, ~0.1 ms during which zigz_commit_begin* waits for the device): a group that does not repeat -- more than a quarter
+ *   of its leaves distinct -- is built like any other columns (the other hints then apply to them).
  * "merkle_dedup" = 1 / 0 is shorthand for run_aware_mask = all ones / 0;
  * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
  *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the

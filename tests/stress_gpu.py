@@ -66,8 +66,8 @@ def main():
         oproof, ons = O.prove(P, prog, 0x1000, iregs, 1 << 20)
         t_or = time.time() - t0
         variants = 0
-        for mode in ("dense", "off", "regs", "struct", "all"):  # Merkle build: dense / small-domain tables / + run-aware registers
-            # / + the memory columns (the default) / + every column
+        for mode in ("dense", "off", "regs", "struct", "all", "cons"):  # Merkle build: dense / small-domain tables / + run-aware registers
+            # / + the memory columns / + every column / struct + the content-addressed instruction group (the default)
             os.environ.pop("ZIGZ_DENSE_MERKLE", None)
             os.environ.pop("ZIGZ_RUN_AWARE", None)
             if mode == "dense":

@@ -760,6 +760,119 @@ def test_run_aware_virtual_copies_open_like_the_dense_tree(ctx, nv):
     assert o0[k]["siblings"][8].tobytes() == sib and int(o0[k]["leaves"][8]) == leaf
 
 
+@pytest.mark.parametrize("nv", [15, 17])
+def test_content_addressed_group_identical_trees(ctx, nv):
+    """Option "cons_group_mask": the levels with >= 16384 nodes of a column group are content-addressed (one representative
+    per distinct node, found through a device hash table; only representatives hashed).  With the copies written out the
+    whole device trees equal the dense build's, for groups that repeat (loops of power-of-two and odd periods), that do not
+    repeat at all, whose columns repeat in DIFFERENT places (the tuple decides, not one column), and next to the other hints."""
+    import zigz_amd
+    N = 1 << nv
+    nc = 12
+    cols = rnd(9150 + nv, nc * N).reshape(nc, N).copy()
+    step = np.arange(N)
+    cols[0, :] = 0x1000 + 4 * (step % 4)                       # a 4-step loop: "pc"
+    cols[1, :] = (step % 4) * 7 + 3                            # a function of it
+    cols[2, :] = 0                                             # constant (x0)
+    cols[3, :] = 0x2000 + 4 * (step % 31)                      # a 31-step loop (odd period: never aligned)
+    cols[4, :] = (step % 31) % 128
+    cols[5, :] = np.where(step < N // 2, step % 5, step % 7)   # two loops one after the other
+    cols[6, :] = rnd(77, N)                                    # no repetition at all
+    cols[7, :] = np.repeat(rnd(3, N // 64), 64)                # piecewise constant (run-aware hint)
+    cols[8, :] = step % 128                                    # small-domain
+    cols[9, :] = step % 3                                      # period 3: repeats where column 0 does not
+    groups = [sum(1 << c for c in (0, 1, 2)), sum(1 << c for c in (3, 4)), sum(1 << c for c in (0, 1, 2, 5, 9)),
+              sum(1 << c for c in (0, 6)), sum(1 << c for c in (0, 1, 2, 3, 4, 5, 8, 9))]
+    trees = []
+    for g in [0] + groups:
+        ctx.set_option("cons_group_mask", g)
+        ctx.set_option("run_aware_mask", 1 << 7)
+        ctx.set_option("small_domain_mask", 1 << 8)
+        ctx.set_option("run_aware_materialize", 1)
+        try:
+            job = zigz_amd.CommitJob(ctx, cols=cols)
+            roots = job.roots().copy()
+            st = ctx.stats()
+            trees.append((roots, _tree_words(ctx, job, nc), st))
+            job.end()
+        finally:
+            for o in ("cons_group_mask", "run_aware_mask", "small_domain_mask", "run_aware_materialize"):
+                ctx.set_option(o, 0)
+    r0, t0, s0 = trees[0]
+    assert s0["cons_columns"] == 0
+    levels = nv - 14 + 1
+    for g, (r, t, st) in zip(groups, trees[1:]):
+        assert np.array_equal(r, r0), g
+        bad = np.nonzero(t != t0)[0]
+        assert bad.size == 0, (g, "first differing node", int(bad[0]) // 8)
+        ng = bin(g).count("1")
+        if st["cons_probe_distinct"] > N // 4:   # the probe found (almost) no repetition: built like any other columns
+            assert st["cons_columns"] == 0 and st["cons_dense_nodes"] == 0
+        else:
+            assert st["cons_columns"] == ng and st["cons_dense_nodes"] == ng * sum(N >> l for l in range(levels))
+        assert st["keccak_permutations"] == nc * (2 * N - 1) - st["small_domain_columns"] * (N + N // 2) - \
+            (st["run_aware_dense_nodes"] - st["run_aware_hashed"]) - (st["cons_dense_nodes"] - st["cons_hashed"])
+    # a 4-step loop has 4 distinct leaves, 2 distinct pairs, then 1 node per level; a 31-step loop at most 31 per level
+    assert trees[1][2]["cons_hashed"] == 3 * (4 + 2 + max(0, levels - 2))
+    assert trees[2][2]["cons_hashed"] <= 2 * 31 * levels
+    assert trees[1][2]["cons_probe_distinct"] == 4 and trees[2][2]["cons_probe_distinct"] == 31
+    # a random column in the group: nothing repeats, the probe says so and the group is dropped
+    assert trees[4][2]["cons_probe_distinct"] >= N - 16 and trees[4][2]["cons_columns"] == 0
+
+
+@pytest.mark.parametrize("nv", [15, 18])
+def test_content_addressed_group_virtual_openings(ctx, nv):
+    """In a commit job only representatives hold a digest below the top content-addressed level; the next level's hashes and
+    the openings go through the representative array.  Roots and openings at many indices equal the dense build's."""
+    import zigz_amd
+    N = 1 << nv
+    nc = 10
+    step = np.arange(N)
+    cols = rnd(9350 + nv, nc * N).reshape(nc, N).copy()
+    cols[0, :] = 0x1000 + 4 * (step % 12)
+    cols[1, :] = (step % 12) % 5
+    cols[2, :] = 0
+    cols[3, :] = np.where(step % 12 == 3, 1, 0)
+    cols[4, :] = np.repeat(rnd(5, N // 128), 128)
+    cols[5, :] = (step % 12) * 1000003 % P
+    cols[0, N - 1000:] = 0x1000 + 4 * 11                      # "padding": pc repeats its last value ...
+    for c in (1, 3, 5):
+        cols[c, N - 1000:] = 0                                 # ... while the instruction fields drop to 0
+    group = sum(1 << c for c in (0, 1, 2, 3, 5))
+    rng = np.random.default_rng(nv)
+    special = [0, 1, 11, 12, 13, 63, 64, 4095, 4096, N - 1001, N - 1000, N - 999, N // 2, N - 1]
+    index_sets = [np.full(nc, i) for i in special] + [rng.integers(0, N, nc) for _ in range(12)]
+
+    def run(g):
+        outs = []
+        ctx.set_option("cons_group_mask", g)
+        ctx.set_option("run_aware_mask", 1 << 4)
+        try:
+            for idx in index_sets:
+                job = zigz_amd.CommitJob(ctx, cols=cols)
+                try:
+                    roots = job.roots().copy()
+                    st = ctx.stats()
+                    pts = rnd(int(idx[0]) + 9, nc * nv).reshape(nc, nv)
+                    pts[:, 0] = idx
+                    outs.append({k: v.copy() for k, v in job.open_all(pts).items()})
+                finally:
+                    job.end()
+        finally:
+            ctx.set_option("cons_group_mask", 0)
+            ctx.set_option("run_aware_mask", 0)
+        return roots, outs, st
+
+    r0, o0, s0 = run(0)
+    r1, o1, s1 = run(group)
+    assert np.array_equal(r0, r1) and s1["cons_columns"] == 5 and s1["cons_hashed"] < s1["cons_dense_nodes"] // 100
+    for a, b in zip(o0, o1):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), (k, a["indices"][:3])
+    lv, h = O.merkle_levels(cols[0])
+    assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == r1[0].tobytes()
+
+
 def test_run_aware_hash_counts(ctx):
     """What the run-aware levels cost: a constant column needs one hash per tile of 4096 nodes; a change point at most
     two more per level."""

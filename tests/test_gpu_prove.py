@@ -291,7 +291,8 @@ def test_prove_with_run_aware_merkle_is_byte_identical(ctx):
         os.environ.pop("ZIGZ_DENSE_MERKLE", None)
     assert a == b == dense
     assert st_dense["run_aware_columns"] == 0 and st_dense["keccak_permutations"] == 43 * ((2 << 17) - 1)
-    assert st_default["run_aware_columns"] == 33 and st["run_aware_columns"] == 43  # default: 31 registers + 2 memory columns
+    # default: 31 registers + 2 memory columns run-aware, the 10 instruction-determined columns content-addressed
+    assert st_default["run_aware_columns"] == 33 and st_default["cons_columns"] == 10 and st["run_aware_columns"] == 43
     assert st["run_aware_hashed"] < st["run_aware_dense_nodes"] // 2
     assert st["keccak_permutations"] == 43 * ((2 << 17) - 1) - (st["run_aware_dense_nodes"] - st["run_aware_hashed"])
     assert host.verify(b, prog) == "Accept"

@@ -24,7 +24,8 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=14)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--trace", default="add_xor", help="add_xor | round_robin | mixed (RV64IM mix with loads / stores, BASELINE config 4's loop)")
-ap.add_argument("--hint", default="regs+mem", help="run-aware hint: regs | regs+mem (what Prover sets) | all")
+ap.add_argument("--hint", default="regs+mem", help="run-aware hint: regs | regs+mem | all | cons (regs+mem and the ten "
+                "instruction-determined columns as a content-addressed group)")
 args = ap.parse_args()
 nv = 20
 N = 1 << nv
@@ -33,10 +34,16 @@ SMALL = (1 << 1) | (0x3f << 33) | (1 << 42)
 rng = np.random.default_rng(1)
 
 
+STRAIGHT = None
+if args.trace == "straight":  # no loop at all: ~2^20 different instructions, executed once each (the worst case for a
+    STRAIGHT = programs.random_program(np.random.default_rng(3), n_insts=int(0.83 * N))  # content-addressed group)
+
+
 class Lane:
     def __init__(self, k):
         self.ctx = zigz_amd.Context(0)
-        prog = (programs.add_xor_loop((N - 3) // 4 - k) if args.trace == "add_xor" else
+        prog = (STRAIGHT if args.trace == "straight" else
+                programs.add_xor_loop((N - 3) // 4 - k) if args.trace == "add_xor" else
                 programs.mixed_loop((N - 8) // 12 - k) if args.trace == "mixed" else
                 programs.register_round_robin((N - 2) // 31 - k))
         self.tr = host.Trace(prog, 0x1000, None, 2 * N)
@@ -44,7 +51,10 @@ class Lane:
         self.tr.witness_to_device(self.ctx, self.d, N)
         self.points = rng.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
         self.ctx.set_option("small_domain_mask", SMALL)
-        self.ctx.set_option("run_aware_mask", {"regs": REGS, "regs+mem": REGS | (3 << 40), "all": ((1 << 43) - 1) & ~SMALL}[args.hint])
+        self.ctx.set_option("run_aware_mask", {"regs": REGS, "regs+mem": REGS | (3 << 40), "all": ((1 << 43) - 1) & ~SMALL,
+                                               "cons": REGS | (3 << 40)}[args.hint])
+        if args.hint == "cons":
+            self.ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
 
     def once(self):
         job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)

@@ -26,6 +26,8 @@ class KernelStats(C.Structure):
                 ("bind_vec_us", C.c_double), ("bind_vec_launches", C.c_uint64), ("bind_vec_bytes", C.c_uint64),
                 ("run_aware_columns", C.c_uint64), ("run_aware_dense_nodes", C.c_uint64),
                 ("run_aware_hashed", C.c_uint64), ("run_aware_us", C.c_double),
+                ("cons_columns", C.c_uint64), ("cons_dense_nodes", C.c_uint64), ("cons_hashed", C.c_uint64),
+                ("cons_probe_distinct", C.c_uint64),
                 ("keccak_leaves_us", C.c_double), ("keccak_leaves_perms", C.c_uint64),
                 ("keccak_level_wide_us", C.c_double), ("keccak_level_wide_perms", C.c_uint64),
                 ("keccak_level_small_us", C.c_double), ("keccak_level_small_perms", C.c_uint64),

@@ -20,7 +20,7 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_CONS, WS_CONSMETA, WS_SLOTS };
 
 constexpr int KEV_MAX = 56;
 struct zigz_ctx {
@@ -39,6 +39,8 @@ struct zigz_ctx {
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
+    uint64_t cons_group_mask;    // option: columns (bit c) that repeat in the same places -> content-addressed levels
+    unsigned long long *d_cons_count;
     bool run_aware_materialize;  // option (tests): write the copies of every run-aware level (no virtual copies)
     uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
                               // are copied, not hashed); "merkle_dedup" = 1 is all columns
@@ -200,7 +202,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     auto fail = [&](hipError_t e) { return e != hipSuccess; };
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
-        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTRS * 8)) ||
+        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTRS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_count, RUN_CTRS * 8)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
@@ -229,6 +231,7 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
     if (ctx->d_sums) (void)hipFree(ctx->d_sums);
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_run_count) (void)hipFree(ctx->d_run_count);
+    if (ctx->d_cons_count) (void)hipFree(ctx->d_cons_count);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_roots) (void)hipHostFree(ctx->h_roots);
     for (int i = 0; i < 6; i++)
@@ -290,6 +293,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "merkle_dedup") == 0) { ctx->run_aware_mask = value != 0 ? ~0ull : 0; return ZIGZ_OK; }
     if (strcmp(name, "run_aware_mask") == 0) { ctx->run_aware_mask = (uint64_t)value; return ZIGZ_OK; }
     if (strcmp(name, "run_aware_materialize") == 0) { ctx->run_aware_materialize = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "cons_group_mask") == 0) { ctx->cons_group_mask = (uint64_t)value; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1109,6 +1113,8 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     ctx->stats.small_domain_columns = 0;
     ctx->stats.run_aware_columns = 0;
     ctx->stats.run_aware_dense_nodes = 0;
+    ctx->stats.cons_columns = 0;
+    ctx->stats.cons_dense_nodes = 0;
     if (record) ctx->kev_n = 0;
     // timing mode: every Keccak launch carries its own begin / end timestamps, by class
     KTime kt_store;
@@ -1127,15 +1133,51 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     //      only where it is not a copy of its left neighbour -- decided from the values, so the hint cannot make a tree wrong;
     //   D  the rest: hashed densely.
     // From the level where every column is complete the launches cover all columns together.
-    ColMap H{}, R{}, D{};
+    //   G  hinted as a group that repeats in the same places (the columns that are functions of the instruction at pc): the
+    //      levels with >= RUN_MIN_NODES nodes are content-addressed (launch_keccak_cons) -- takes precedence over H and R.
+    ColMap H{}, R{}, D{}, G{};
     const bool sd_ok = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
     const bool run_ok = ctx->run_aware_mask && npad >= 2 * RUN_MIN_NODES && npad <= ((size_t)1 << 26) && ncols <= 64;
-    if (sd_ok || run_ok)
+    bool cons_ok = ctx->cons_group_mask && npad >= 2 * RUN_MIN_NODES && npad <= ((size_t)1 << 26) && ncols <= 64;
+    // The group pays only where it repeats (a loop): probe the leaf level first -- one table pass -- and read back how many
+    // distinct leaves (tuples of the group's values) there are.  More than a quarter of the leaves: the columns are built
+    // like any others (a trace that never loops would pay 70 % more for table passes that find nothing).  The read-back is
+    // the one place where starting a batched commit waits for the device (~0.1 ms).
+    void *cons_w = nullptr, *cons_mw = nullptr;
+    ctx->stats.cons_probe_distinct = 0;
+    if (cons_ok) {
+        ColMap P_{};
+        for (size_t c = 0; c < ncols; c++)
+            if ((ctx->cons_group_mask >> c) & 1) P_.c[P_.n++] = (uint8_t)c;
+        if (P_.n == 0) cons_ok = false;
+        else {
+            CHK(ws_get(ctx, WS_CONS, 2 * npad * 12 + cons_list_entries(npad) * 4 + 256, &cons_w));
+            CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &cons_mw));
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
+            launch_cons_probe(d_vals, val_stride, n_values, npad, (uint32_t *)cons_mw, (unsigned long long *)cons_w,
+                              (uint32_t *)((uint8_t *)cons_w + 2 * npad * 8), (uint32_t *)((uint8_t *)cons_w + 2 * npad * 12),
+                              ctx->d_cons_count, P_, ctx->stream, nullptr);
+            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_cons_count, 33 * 128, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+            uint64_t distinct = 0;
+            for (int sb = 0; sb < 32; sb++) distinct += ctx->h_pin[(1 + sb) * 16];
+            ctx->stats.cons_probe_distinct = distinct;
+            if (distinct > npad / 4) cons_ok = false;
+        }
+    }
+    auto kind = [&](size_t c) -> int {  // 0 D, 1 H, 2 R, 3 G
+        if (cons_ok && ((ctx->cons_group_mask >> c) & 1)) return 3;
+        if (sd_ok && ((ctx->small_domain_mask >> c) & 1)) return 1;
+        if (run_ok && ((ctx->run_aware_mask >> c) & 1)) return 2;
+        return 0;
+    };
+    if (sd_ok || run_ok || cons_ok)
         for (size_t c = 0; c < ncols; c++) {
-            ColMap &m = sd_ok && ((ctx->small_domain_mask >> c) & 1) ? H : run_ok && ((ctx->run_aware_mask >> c) & 1) ? R : D;
+            const int kd = kind(c);
+            ColMap &m = kd == 3 ? G : kd == 1 ? H : kd == 2 ? R : D;
             m.c[m.n++] = (uint8_t)c;
         }
-    if (H.n == 0 && R.n == 0) {
+    if (H.n == 0 && R.n == 0 && G.n == 0) {
         launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
     } else if (D.n) {
         launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
@@ -1198,21 +1240,38 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         }
         ctx->stats.run_aware_columns = R.n;
     }
+    unsigned cons_top = 0;  // G columns: levels 0..cons_top are content-addressed
+    if (G.n) {
+        cons_top = height - log2_floor(RUN_MIN_NODES);
+        const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;
+        void *w = cons_w, *mw = cons_mw;  // table + list (scratch) and the representative arrays (kept while the trees are read
+        unsigned long long *keys = (unsigned long long *)w;  // through them); level 0 was done by the probe above
+        uint32_t *idx = (uint32_t *)((uint8_t *)w + 2 * npad * 8);
+        uint32_t *list = (uint32_t *)((uint8_t *)w + 2 * npad * 12);
+        launch_keccak_cons(d_vals, val_stride, n_values, npad, d_tree, stride, cons_top, virt ? cons_top : 0, (uint32_t *)mw, keys, idx,
+                           list, ctx->d_cons_count, G, ctx->stream, nullptr);
+        if (run_meta && virt) {
+            run_meta->cons_rep = (const uint32_t *)mw;
+            run_meta->cons_levels = cons_top;  // the top content-addressed level is filled in: the dense kernels read it
+            for (unsigned k = 0; k < G.n; k++) run_meta->cons_mask |= 1ull << G.c[k];
+        }
+        for (unsigned l = 0; l <= cons_top; l++) ctx->stats.cons_dense_nodes += (uint64_t)G.n * (npad >> l);
+        ctx->stats.cons_columns = G.n;
+    }
     for (unsigned l = 0; l < height; l++) {  // level l + 1 from level l, for the columns that do not have it yet
         const size_t n_out = npad >> (l + 1);
-        const bool with_h = l >= 1, with_r = l >= run_top;
-        if (n_out <= 256) {  // all columns are complete here: run_top < height - 9, and H stops at level 1
+        const bool with_h = l >= 1, with_r = l >= run_top, with_g = l >= cons_top;
+        if (n_out <= 256) {  // all columns are complete here: run_top, cons_top < height - 9, and H stops at level 1
             launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
             break;
         }
         ColMap m{};
         const ColMap *pm = nullptr;
         size_t nc = ncols;
-        if ((H.n && !with_h) || (R.n && !with_r)) {  // a subset: the sorted union of the kinds that take part
+        if ((H.n && !with_h) || (R.n && !with_r) || (G.n && !with_g)) {  // a subset: the sorted union of the kinds that take part
             for (size_t c = 0; c < ncols; c++) {
-                const bool in_h = sd_ok && ((ctx->small_domain_mask >> c) & 1);
-                const bool in_r = !in_h && run_ok && ((ctx->run_aware_mask >> c) & 1);
-                if ((in_h && with_h) || (in_r && with_r) || (!in_h && !in_r)) m.c[m.n++] = (uint8_t)c;
+                const int kd = kind(c);
+                if ((kd == 1 && with_h) || (kd == 2 && with_r) || (kd == 3 && with_g) || kd == 0) m.c[m.n++] = (uint8_t)c;
             }
             if (m.n == 0) continue;
             pm = &m;
@@ -1406,11 +1465,13 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
         // the two diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later
         unsigned long long *h_cnt = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
-        h_cnt[0] = h_cnt[1] = 0;
+        h_cnt[0] = h_cnt[1] = h_cnt[2] = 0;
         if (ctx->stats.run_aware_columns)
             HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_run_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         if (ctx->stats.small_domain_columns)
             HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->stats.cons_columns)
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[2], ctx->d_cons_count, 8, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
         return ZIGZ_OK;
     };
@@ -1468,6 +1529,9 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     // the run-aware levels hashed h_cnt[0] of their run_aware_dense_nodes nodes
     ctx->stats.run_aware_hashed = ctx->stats.run_aware_columns ? h_cnt[0] : 0;
     ctx->stats.keccak_permutations -= ctx->stats.run_aware_dense_nodes - ctx->stats.run_aware_hashed;
+    // likewise the content-addressed levels: h_cnt[2] digests computed for their cons_dense_nodes nodes
+    ctx->stats.cons_hashed = ctx->stats.cons_columns ? h_cnt[2] : 0;
+    ctx->stats.keccak_permutations -= ctx->stats.cons_dense_nodes - ctx->stats.cons_hashed;
     ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
     if (ctx->timing) {
         float ms = 0;

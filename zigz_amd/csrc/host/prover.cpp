@@ -89,8 +89,8 @@ bool Prover::defaultSmallDomain() {
 int Prover::defaultRunAware() {
     if (!defaultSmallDomain()) return 0;
     const char *e = getenv("ZIGZ_RUN_AWARE");
-    if (!e || !e[0]) return 3;
-    return strcmp(e, "off") == 0 ? 0 : strcmp(e, "regs") == 0 ? 1 : strcmp(e, "all") == 0 ? 2 : 3;
+    if (!e || !e[0]) return 4;
+    return strcmp(e, "off") == 0 ? 0 : strcmp(e, "regs") == 0 ? 1 : strcmp(e, "all") == 0 ? 2 : strcmp(e, "struct") == 0 ? 3 : 4;
 }
 
 void Prover::bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs) {
@@ -256,12 +256,18 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
     // the values on the device; identical trees for any input).  So are mem.address and mem.value between memory accesses:
     // a step that is not a LOAD / STORE records 0 in both (witness.zig:236-253), so each of them changes at most twice per
-    // memory access.  run_aware: 1 = the registers, 3 (default) = registers + the two memory columns, 2 = every column that
-    // is not small-domain.
+    // memory access.  run_aware: 1 = the registers, 3 = registers + the two memory columns, 2 = every column that is not
+    // small-domain, 4 (default) = 3 + the ten columns that are functions of the instruction at pc -- pc, x0, opcode, rd, rs1,
+    // rs2, funct3, funct7, imm, is_read -- as a content-addressed group (zigz_hip.h, option "cons_group_mask": wherever the
+    // program loops the same nodes recur in all ten; probed first, dropped for a trace that does not repeat).
     if (run_aware) {
         const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
         const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
-        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware == 3 ? regs | mem : regs;
+        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware >= 3 ? regs | mem : regs;
+        if (run_aware == 4) {
+            const uint64_t group = 1ull | (1ull << 1) | (0x7full << 33) | (1ull << 42);
+            check(ctx_, zigz_ctx_set_option(ctx_, "cons_group_mask", (int64_t)((group >> c0) & ((1ull << (c1 - c0)) - 1))));
+        }
         check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
     }
     struct MaskReset {
@@ -270,6 +276,7 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         ~MaskReset() {
             if (sd) (void)zigz_ctx_set_option(ctx, "small_domain_mask", 0);
             if (ra) (void)zigz_ctx_set_option(ctx, "run_aware_mask", 0);
+            if (ra) (void)zigz_ctx_set_option(ctx, "cons_group_mask", 0);
         }
     } mask_reset{ctx_, small_domain_tables, run_aware != 0};
     if (witness)

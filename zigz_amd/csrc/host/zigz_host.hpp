@@ -302,9 +302,10 @@ class Prover {  // src/prover/prover.zig
     bool small_domain_tables = defaultSmallDomain();
     static bool defaultSmallDomain();
     // run-aware Merkle levels (identical trees): 0 off; 1 the register columns x1..x31 (at most one of them changes per
-    // step, whatever the program); 3 (default) the registers and mem.address / mem.value (0 on every step that is not a
-    // LOAD / STORE); 2 every column that is not small-domain.  Environment: ZIGZ_RUN_AWARE=off|regs|struct|all (default
-    // struct); ZIGZ_DENSE_MERKLE=1 turns this off too
+    // step, whatever the program); 3 the registers and mem.address / mem.value (0 on every step that is not a
+    // LOAD / STORE); 2 every column that is not small-domain; 4 (default) = 3 + the ten instruction-determined columns as a
+    // content-addressed group.  Environment: ZIGZ_RUN_AWARE=off|regs|struct|all|cons (default cons); ZIGZ_DENSE_MERKLE=1
+    // turns this off too
     int run_aware = defaultRunAware();
     static int defaultRunAware();
 

@@ -1008,6 +1008,212 @@ void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_valu
 #undef ZK_RUN_LAUNCH
 }
 
+// ------------------------------------------------------------------ content-addressed levels of a column group
+// (kernels.hpp, launch_keccak_cons)
+constexpr unsigned long long CONS_EMPTY = ~0ull;
+__device__ __forceinline__ unsigned long long cons_mix(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+// the key of node k: leaves -- a fingerprint of the group's values at leaf k; above -- the children's representatives
+template <bool LEAF>
+__device__ __forceinline__ unsigned long long cons_key(const uint32_t *vals, size_t val_stride, size_t n_values, const uint32_t *rep_prev,
+                                                       size_t k, const ColMap &g) {
+    if (LEAF) {
+        unsigned long long h = 0x243f6a8885a308d3ull;
+        for (unsigned j = 0; j < g.n; j++)
+            h = cons_mix(h ^ (k < n_values ? vals[(size_t)g.c[j] * val_stride + k] : 0u));  // padding leaves hold 0
+        return h == CONS_EMPTY ? h - 1 : h;
+    }
+    return ((unsigned long long)rep_prev[2 * k] << 32) | rep_prev[2 * k + 1];
+}
+
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_cons_insert(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                     size_t n_nodes, const uint32_t *__restrict__ rep_prev,
+                                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ idx,
+                                                     size_t mask, ColMap g, size_t first) {
+    const size_t k = first + (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= n_nodes) return;
+    const unsigned long long key = cons_key<LEAF>(vals, val_stride, n_values, rep_prev, k, g);
+    size_t slot = cons_mix(key) & mask;
+    for (;;) {  // the table has twice as many slots as the level has nodes: a free or matching slot is always reached
+        // look before the atomic: in a loop-dominated trace a million nodes share a handful of keys, and a million
+        // compare-and-swaps on one word serialise at ~15 ns each
+        unsigned long long cur = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
+        if (cur == CONS_EMPTY) cur = atomicCAS(&keys[slot], CONS_EMPTY, key);
+        if (cur == CONS_EMPTY) {  // this thread inserted the key: it is the representative
+            idx[slot] = (uint32_t)k;
+            return;
+        }
+        if (cur == key) return;
+        slot = (slot + 1) & mask;
+    }
+}
+
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_cons_resolve(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
+                                                      size_t n_nodes, unsigned L, const uint32_t *__restrict__ rep_prev,
+                                                      const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ idx,
+                                                      size_t mask, uint32_t *__restrict__ rep_out, uint32_t *__restrict__ list,
+                                                      size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap g) {
+    __shared__ unsigned s_cnt[TPB / 64];
+    __shared__ unsigned long long s_base;
+    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    bool is_rep = false;
+    if (k < n_nodes) {
+        const unsigned long long key = cons_key<LEAF>(vals, val_stride, n_values, rep_prev, k, g);
+        size_t slot = cons_mix(key) & mask;
+        while (keys[slot] != key) slot = (slot + 1) & mask;  // inserted by k_cons_insert
+        uint32_t r = idx[slot];
+        if (LEAF && r != k) {  // equal fingerprints are not yet equal tuples: verify, else this leaf stands for itself
+            for (unsigned j = 0; j < g.n; j++) {
+                const uint32_t *v = vals + (size_t)g.c[j] * val_stride;
+                if ((k < n_values ? v[k] : 0u) != (r < n_values ? v[r] : 0u)) { r = (uint32_t)k; break; }
+            }
+        }
+        rep_out[k] = r;
+        is_rep = r == k;
+    }
+    // representatives go onto the level's list (one reservation per workgroup, spread over the sub-list counters)
+    const unsigned long long m = __ballot(is_rep);
+    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < TPB / 64; w++) { const unsigned c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
+        const unsigned sub = blockIdx.x % RUN_SUBS;
+        s_base = (unsigned long long)sub * sub_cap + atomicAdd(&ctr[(1 + L * RUN_SUBS + sub) * 16], (unsigned long long)tot);
+    }
+    __syncthreads();
+    if (is_rep) list[s_base + s_cnt[wave] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)k;
+}
+
+// one digest per (representative, column of the group)
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_cons_hash(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values, size_t npad,
+                                                   uint8_t *__restrict__ tree, size_t tree_stride_nodes, unsigned L,
+                                                   const uint32_t *__restrict__ rep_all, const uint32_t *__restrict__ list,
+                                                   size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap g) {
+    __shared__ unsigned long long s_start[RUN_SUBS + 1];
+    if (threadIdx.x < 64) {
+        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + L * RUN_SUBS + threadIdx.x) * 16] : 0;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long a = __shfl_up(incl, off, 64);
+            if (threadIdx.x >= (unsigned)off) incl += a;
+        }
+        if (threadIdx.x < RUN_SUBS) s_start[threadIdx.x] = incl - c;
+        if (threadIdx.x == RUN_SUBS - 1) {
+            s_start[RUN_SUBS] = incl;
+            if (blockIdx.x == 0) atomicAdd(&ctr[0], incl * g.n);  // digests computed by the whole build
+        }
+    }
+    __syncthreads();
+    const size_t cnt = s_start[RUN_SUBS] * g.n;
+    const size_t out_off = 2 * npad - 2 * (npad >> L);
+    const size_t in_off = LEAF ? 0 : 2 * npad - 2 * (npad >> (L - 1));
+#pragma unroll 1
+    for (size_t t = (size_t)blockIdx.x * TPB + threadIdx.x; t < cnt; t += (size_t)gridDim.x * TPB) {
+        const size_t e = t / g.n;
+        const size_t col = g.c[t % g.n];
+        unsigned sub = 0;
+#pragma unroll
+        for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
+            if (s_start[sub + step] <= e) sub += step;
+        const size_t k = list[(size_t)sub * sub_cap + (e - s_start[sub])];
+        uint8_t *tr = tree + col * tree_stride_nodes * 32;
+        Digest d;
+        if (LEAF) d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
+        else d = sha3_node(load_digest(tr, in_off + rep_all[in_off + 2 * k]), load_digest(tr, in_off + rep_all[in_off + 2 * k + 1]));
+        store_digest_plain(tr, out_off + k, d);
+    }
+}
+
+// every node of the level takes its representative's digest (levels the dense kernels or a whole-tree comparison read)
+__global__ __launch_bounds__(TPB) void k_cons_fill(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad, unsigned L,
+                                                   const uint32_t *__restrict__ rep_all, ColMap g) {
+    const size_t n_nodes = npad >> L, off = 2 * npad - 2 * n_nodes;
+    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= n_nodes) return;
+    const uint32_t r = rep_all[off + k];
+    if (r == k) return;
+    uint8_t *tr = tree + (size_t)g.c[blockIdx.y] * tree_stride_nodes * 32;
+    store_digest(tr, off + k, load_digest(tr, off + r));
+}
+
+size_t cons_list_entries(size_t npad) { return ((npad / TPB + RUN_SUBS - 1) / RUN_SUBS) * TPB * RUN_SUBS; }
+
+// table passes of level L: representatives of its nodes into d_rep, the list of representatives and its sub-list counters
+static void cons_find(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, unsigned L, uint32_t *d_rep,
+                      unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g,
+                      hipStream_t s, hipEvent_t ev_start) {
+    const size_t n_nodes = npad >> L, slots = 2 * n_nodes, off = 2 * npad - 2 * n_nodes;
+    const size_t sub_cap = ((n_nodes + TPB - 1) / TPB + RUN_SUBS - 1) / RUN_SUBS * TPB;
+    const uint32_t *rep_prev = L ? d_rep + (2 * npad - 2 * (npad >> (L - 1))) : nullptr;
+    (void)hipMemsetAsync(d_keys, 0xff, slots * 8, s);
+    (void)hipMemsetAsync(d_idx, 0xff, slots * 4, s);
+    // seeded: the first nodes alone, then the rest -- in a loop-dominated trace the rest then only READS the table (a million
+    // simultaneous first insertions of a handful of keys serialise on those words: 4.3 ms instead of 0.86 per build)
+    const size_t seed = 4096 < n_nodes ? 4096 : n_nodes;
+    const dim3 g_seed((unsigned)((seed + TPB - 1) / TPB)), g_rest((unsigned)((n_nodes - seed + TPB - 1) / TPB)),
+        g_all((unsigned)((n_nodes + TPB - 1) / TPB));
+    if (L == 0) {
+        if (ev_start) hipExtLaunchKernelGGL(k_cons_insert<true>, g_seed, dim3(TPB), 0, s, ev_start, nullptr, 0, d_vals, val_stride,
+                                            n_values, seed, rep_prev, d_keys, d_idx, slots - 1, g, (size_t)0);
+        else hipLaunchKernelGGL(k_cons_insert<true>, g_seed, dim3(TPB), 0, s, d_vals, val_stride, n_values, seed, rep_prev, d_keys,
+                                d_idx, slots - 1, g, (size_t)0);
+        if (n_nodes > seed)
+            hipLaunchKernelGGL(k_cons_insert<true>, g_rest, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, rep_prev, d_keys,
+                               d_idx, slots - 1, g, seed);
+        hipLaunchKernelGGL(k_cons_resolve<true>, g_all, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, L, rep_prev, d_keys,
+                           d_idx, slots - 1, d_rep + off, d_list, sub_cap, d_ctr, g);
+    } else {
+        hipLaunchKernelGGL(k_cons_insert<false>, g_seed, dim3(TPB), 0, s, d_vals, val_stride, n_values, seed, rep_prev, d_keys, d_idx,
+                           slots - 1, g, (size_t)0);
+        if (n_nodes > seed)
+            hipLaunchKernelGGL(k_cons_insert<false>, g_rest, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, rep_prev, d_keys,
+                               d_idx, slots - 1, g, seed);
+        hipLaunchKernelGGL(k_cons_resolve<false>, g_all, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, L, rep_prev, d_keys,
+                           d_idx, slots - 1, d_rep + off, d_list, sub_cap, d_ctr, g);
+    }
+}
+
+void launch_cons_probe(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint32_t *d_rep,
+                       unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g,
+                       hipStream_t s, const KTime *kt) {
+    cons_find(d_vals, val_stride, n_values, npad, 0, d_rep, d_keys, d_idx, d_list, d_ctr, g, s, kt ? kt->start : nullptr);
+}
+
+void launch_keccak_cons(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                        size_t tree_stride_nodes, unsigned top, unsigned fill_from, uint32_t *d_rep, unsigned long long *d_keys,
+                        uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g, hipStream_t s, const KTime *kt) {
+    if (g.n == 0) return;
+    for (unsigned L = 0; L <= top; L++) {
+        const size_t n_nodes = npad >> L;
+        const size_t sub_cap = ((n_nodes + TPB - 1) / TPB + RUN_SUBS - 1) / RUN_SUBS * TPB;
+        if (L) cons_find(d_vals, val_stride, n_values, npad, L, d_rep, d_keys, d_idx, d_list, d_ctr, g, s, nullptr);  // (level 0: the probe)
+        size_t hash_wgs = (n_nodes * g.n + TPB - 1) / TPB;
+        if (hash_wgs > 16384) hash_wgs = 16384;
+        const bool last = L == top;
+        if (L == 0)
+            hipLaunchKernelGGL(k_cons_hash<true>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
+                               tree_stride_nodes, L, d_rep, d_list, sub_cap, d_ctr, g);
+        else
+            hipLaunchKernelGGL(k_cons_hash<false>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad,
+                               d_tree, tree_stride_nodes, L, d_rep, d_list, sub_cap, d_ctr, g);
+        if (L >= fill_from || last) {
+            const dim3 fgrid((unsigned)((n_nodes + TPB - 1) / TPB), g.n);
+            if (kt && last) hipExtLaunchKernelGGL(k_cons_fill, fgrid, dim3(TPB), 0, s, nullptr, kt->stop, 0, d_tree, tree_stride_nodes,
+                                                  npad, L, d_rep, g);
+            else hipLaunchKernelGGL(k_cons_fill, fgrid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, L, d_rep, g);
+        }
+    }
+}
+
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                           size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
     ColMap cm{};
@@ -1167,6 +1373,7 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     size_t node = ci ^ 1;
     const int y = col < 64 ? meta.y_of_col[col] : -1;
     if (y >= 0 && l < meta.virt_levels) node = run_leader(meta, npad, (unsigned)y, l, node);  // a copy: its leader's digest
+    if (col < 64 && ((meta.cons_mask >> col) & 1) && l < meta.cons_levels) node = meta.cons_rep[off + node];  // its representative's
     Digest d;
     if (l == 0 && col < 64 && ((meta.virtual_leaves >> col) & 1))  // leaf digests of this column were never written
         d = sha3_leaf(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);

@@ -116,6 +116,11 @@ struct RunMeta {
     unsigned long long virtual_leaves;  // bit c: the leaf digests of column c were not written (small-domain columns of a
                                         // commit job): an opening hashes the sibling value itself
     signed char y_of_col[64];    // column -> hinted index, -1 = not hinted
+    // content-addressed group (launch_keccak_cons): on the levels < cons_levels a node of a column in cons_mask has the
+    // digest stored at node cons_rep[2 npad - 2 (npad >> l) + k] of the same level and column (its representative)
+    const uint32_t *cons_rep;
+    unsigned cons_levels;
+    unsigned long long cons_mask;
 };
 constexpr unsigned RUN_TILE = 4096;
 constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
@@ -131,6 +136,24 @@ size_t runs_meta_words(size_t npad, size_t ncols);  // entries of RunMeta::bitma
 void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                         size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
                         uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols, hipStream_t s,
+                        const KTime *kt = nullptr);
+// Content-addressed levels 0..top of a GROUP of columns that repeat in the same places (the columns that are functions of the
+// instruction at pc): per level one device hash table finds, for every node, the first node of the level with the same
+// content in ALL columns of the group -- leaves: the tuple of the group's values (64-bit fingerprint, verified against the
+// representative's tuple); above: the pair of the children's representatives, which IS the identity of the hash input --
+// and only representatives are hashed (once per column).  d_rep: 2 npad u32 (kept while the trees are read through it);
+// d_keys / d_idx: 2 npad u64 / u32 of table; d_list: cons_list_entries() u32; d_ctr: RUN_CTRS u64, zeroed by the caller
+// (d_ctr[0] += digests computed).  Levels >= fill_from are filled in (every node's digest written).
+size_t cons_list_entries(size_t npad);
+// The table passes of the leaf level alone: afterwards the sub-list counters d_ctr[(1 + s) * 16], s < 32, add up to the number
+// of distinct leaves (tuples) of the group -- the caller decides from it whether the group repeats enough to go on
+// (launch_keccak_cons, which starts from this state) or is built like any other columns.
+void launch_cons_probe(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint32_t *d_rep,
+                       unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &group,
+                       hipStream_t s, const KTime *kt = nullptr);
+void launch_keccak_cons(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
+                        size_t tree_stride_nodes, unsigned top, unsigned fill_from, uint32_t *d_rep, unsigned long long *d_keys,
+                        uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &group, hipStream_t s,
                         const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
