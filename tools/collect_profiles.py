@@ -91,7 +91,7 @@ def main():
                       ("p2_bench.json", "final_bench.json"), ("p2_bench_b1.json", "final_bench_b1.json"),
                       ("p2_bench_s0.json", "final_bench_own_thread_transcripts.json"),
                       ("p2_bench_s0_b8.json", "final_bench_own_thread_transcripts_b8.json"),
-                      ("p2_bench_s4.json", "final_bench_4x8.json"), ("p2_bench_s6.json", "final_bench_6x8.json"),
+                      ("p2_bench_s4.json", "final_bench_5x8.json"), ("p2_bench_s6.json", "final_bench_7x8.json"),
                       ("p2_bench_tables_b8.json", "final_bench_merkle_tables_b8.json"),
                       ("p2_bench_dense_b8.json", "final_bench_merkle_dense_b8.json"), ("p2_bench_all.json", "final_bench_merkle_all.json"),
                       ("p2_gpu_bound.txt", "gpu_bound_rate.txt"),
@@ -106,7 +106,7 @@ def main():
     one = glob.glob("gpurun_out/p2_one/**/*kernel_trace.csv", recursive=True)
     if one:  # the launches of the last of three lone proofs, in order: name, grid, start (us from the first), duration (us)
         rows = sorted(csv.DictReader(open(max(one, key=os.path.getmtime))), key=lambda r: int(r["Start_Timestamp"]))
-        rows = [r for r in rows if "keccak" in r["Kernel_Name"] or "k_runs" in r["Kernel_Name"]]
+        rows = [r for r in rows if "keccak" in r["Kernel_Name"] or "k_runs" in r["Kernel_Name"] or "k_cons" in r["Kernel_Name"]]
         last = rows[-(len(rows) // 3):]
         t0 = int(last[0]["Start_Timestamp"])
         with open("profiles/%s_one_proof_launches.csv" % ROUND, "w") as f:
@@ -116,7 +116,7 @@ def main():
                                                   r.get("Grid_Size_Y", ""), (int(r["Start_Timestamp"]) - t0) / 1e3,
                                                   (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3))
     for name in ("final_bench", "final_bench_b1", "final_bench_own_thread_transcripts", "final_bench_own_thread_transcripts_b8",
-                 "final_bench_4x8", "final_bench_6x8", "final_bench_merkle_tables_b8", "final_bench_merkle_dense_b8",
+                 "final_bench_5x8", "final_bench_7x8", "final_bench_merkle_tables_b8", "final_bench_merkle_dense_b8",
                  "final_bench_merkle_all"):
         pth = "profiles/%s_%s.json" % (ROUND, name)
         if not os.path.exists(pth):

@@ -24,7 +24,7 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--lanes", type=int, default=14)
 ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--trace", default="add_xor", help="add_xor | round_robin | mixed (RV64IM mix with loads / stores, BASELINE config 4's loop)")
-ap.add_argument("--hint", default="regs+mem", help="run-aware hint: regs | regs+mem | all | cons (regs+mem and the ten "
+ap.add_argument("--hint", default="cons", help="run-aware hint: regs | regs+mem | all | cons (regs+mem and the ten "
                 "instruction-determined columns as a content-addressed group)")
 args = ap.parse_args()
 nv = 20

@@ -23,14 +23,13 @@ python3 bench.py > gpurun_out/p2_bench.json 2> gpurun_out/p2_bench.err
 python3 bench.py --batch 1 --sponge-servers 0 --no-cpu-baseline > gpurun_out/p2_bench_b1.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --sponge-servers 0 --no-cpu-baseline > gpurun_out/p2_bench_s0.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --sponge-servers 0 --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_s0_b8.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --sponge-servers 4 --batch 32 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_s4.json 2>> gpurun_out/p2_bench.err
-python3 bench.py --sponge-servers 6 --batch 48 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_s6.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --sponge-servers 5 --batch 40 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_s4.json 2>> gpurun_out/p2_bench.err
+python3 bench.py --sponge-servers 7 --batch 56 --no-cpu-baseline --no-extras > gpurun_out/p2_bench_s6.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle tables --sponge-servers 0 --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_tables_b8.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle dense --sponge-servers 0 --batch 8 --no-cpu-baseline > gpurun_out/p2_bench_dense_b8.json 2>> gpurun_out/p2_bench.err
 python3 bench.py --merkle all --no-cpu-baseline --no-extras > gpurun_out/p2_bench_all.json 2>> gpurun_out/p2_bench.err
 ZIGZ_BENCH_BACKEND=gloo python3 bench.py --gpus 2 --steps 5 --warmup 1 --sponge-servers 2 --batch 12 > gpurun_out/p2_bench_gpus2_rehearsal.json 2>> gpurun_out/p2_bench.err
-python3 tools/gpu_bound_rate.py --lanes 14 > gpurun_out/p2_gpu_bound.txt 2>> gpurun_out/p2_bench.err
-python3 tools/gpu_bound_rate.py --lanes 14 --trace round_robin >> gpurun_out/p2_gpu_bound.txt 2>> gpurun_out/p2_bench.err
+for t in add_xor mixed round_robin straight; do for h in regs regs+mem all cons; do python3 tools/gpu_bound_rate.py --lanes 14 --trace $t --hint $h; done; done > gpurun_out/p2_gpu_bound.txt 2>> gpurun_out/p2_bench.err
 python3 tools/measure_extra.py > gpurun_out/p2_extra.json 2>> gpurun_out/p2_bench.err
 # (5) BASELINE configs 2-5 at full size on one GPU
 rm -f gpurun_out/p2_configs.jsonl

@@ -1151,8 +1151,13 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             if ((ctx->cons_group_mask >> c) & 1) P_.c[P_.n++] = (uint8_t)c;
         if (P_.n == 0) cons_ok = false;
         else {
-            CHK(ws_get(ctx, WS_CONS, 2 * npad * 12 + cons_list_entries(npad) * 4 + 256, &cons_w));
-            CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &cons_mw));
+            // the representative arrays outlive the build only in a commit job with virtual nodes: they then live in a
+            // workspace of their own, which nothing but the next commit job touches (other calls may interleave with a job)
+            const bool keep = run_meta != nullptr && !ctx->run_aware_materialize;
+            const size_t scratch = 2 * npad * 12 + cons_list_entries(npad) * 4 + 256;
+            CHK(ws_get(ctx, WS_CONS, scratch + (keep ? 0 : 64 + 2 * npad * 4), &cons_w));
+            if (keep) CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &cons_mw));
+            else cons_mw = (uint8_t *)cons_w + ((scratch + 63) & ~(size_t)63);
             HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
             launch_cons_probe(d_vals, val_stride, n_values, npad, (uint32_t *)cons_mw, (unsigned long long *)cons_w,
                               (uint32_t *)((uint8_t *)cons_w + 2 * npad * 8), (uint32_t *)((uint8_t *)cons_w + 2 * npad * 12),
