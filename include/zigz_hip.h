@@ -346,6 +346,15 @@ typedef struct zigz_kernel_stats {
     uint64_t small_domain_columns;
     double small_domain_us;
     uint64_t small_domain_fallback_waves;
+    /* the structure-aware build of the last batched commit (timing mode), by class: structure_us = the passes that decide
+     * WHICH nodes are hashed (run-aware stages k_runs_stage, content-addressing table passes k_cons_*: no hashing);
+     * list_hash_us / list_hash_perms = the per-level launches that hash those lists (k_level_hash) and the permutations they
+     * computed; top_us / top_perms = the last 8 levels (k_merkle_top).  run_aware_us = structure_us + list_hash_us. */
+    double structure_us;
+    double list_hash_us;
+    uint64_t list_hash_perms;
+    double top_us;
+    uint64_t top_perms;
 } zigz_kernel_stats;
 /* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
  * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per

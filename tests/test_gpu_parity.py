@@ -613,9 +613,23 @@ def test_unaligned_device_pointers(ctx):
         ctx.dev_free(o)
 
 
-def _run_aware_hashed(cols, levels, tile=4096):
-    """numpy model of k_runs_flags: nodes hashed (not copied from the left neighbour) on levels 0..levels-1; the first node
-    of every tile of 4096 nodes is always hashed."""
+def _run_tile_nodes(N, l):
+    """kernels.hpp run_tile_nodes: the nodes one segment of a stage covers at level l (its first node is always hashed)."""
+    if l == 0:
+        return 4096
+    s = (l - 1) // 6
+    n_in = N >> (6 * s)
+    return min(4096, n_in) >> (l - 6 * s)
+
+
+def _list_levels(nv):
+    """the list-driven levels of a 2^nv tree: 0 .. nv - 8 (down to 256 nodes per column)"""
+    return nv - 8 + 1
+
+
+def _run_aware_hashed(cols, levels):
+    """numpy model of k_runs_stage: nodes hashed (not copied from the left neighbour) on levels 0..levels-1; the first node
+    of every tile (what one segment of a stage covers at that level) is always hashed."""
     total = 0
     for col in np.asarray(cols):
         uni = np.ones(col.size, dtype=bool)
@@ -626,7 +640,7 @@ def _run_aware_hashed(cols, levels, tile=4096):
             val = col[::(1 << l)]
             copy = np.zeros(val.size, dtype=bool)
             copy[1:] = uni[1:] & uni[:-1] & (val[1:] == val[:-1])
-            copy[::tile] = False
+            copy[::_run_tile_nodes(col.size, l)] = False
             total += int((~copy).sum())
     return total
 
@@ -638,7 +652,7 @@ def _tree_words(ctx, job, ncols):
 
 @pytest.mark.parametrize("nv", [15, 16, 18])
 def test_run_aware_levels_identical_trees(ctx, nv):
-    """Option "run_aware_mask": on the levels with >= 16384 nodes a node that is a copy of its left neighbour (both subtrees
+    """Option "run_aware_mask": on the levels 0 .. v - 8 a node that is a copy of its left neighbour (both subtrees
     uniform, same value) is copied instead of hashed.  EVERY node of EVERY tree must equal the dense build's (the device
     trees are compared word for word), whatever the columns look like and whatever the hint says; roots also vs the oracle."""
     import zigz_amd
@@ -684,7 +698,7 @@ def test_run_aware_levels_identical_trees(ctx, nv):
         bad = np.nonzero(t != t0)[0]
         assert bad.size == 0, (k, "first differing node", int(bad[0]) // 8, "of", t.size // 8)
     s1 = trees[1][2]
-    levels = nv - 14 + 1                                         # the levels with >= 16384 nodes
+    levels = _list_levels(nv)
     assert s1["run_aware_columns"] == 14
     assert s1["run_aware_dense_nodes"] == 14 * sum(N >> l for l in range(levels))
     assert s1["run_aware_hashed"] == _run_aware_hashed(cols[[c for c in range(nc) if (run_mask >> c) & 1]], levels)
@@ -762,7 +776,7 @@ def test_run_aware_virtual_copies_open_like_the_dense_tree(ctx, nv):
 
 @pytest.mark.parametrize("nv", [15, 17])
 def test_content_addressed_group_identical_trees(ctx, nv):
-    """Option "cons_group_mask": the levels with >= 16384 nodes of a column group are content-addressed (one representative
+    """Option "cons_group_mask": the levels 0 .. v - 8 of a column group are content-addressed (one representative
     per distinct node, found through a device hash table; only representatives hashed).  With the copies written out the
     whole device trees equal the dense build's, for groups that repeat (loops of power-of-two and odd periods), that do not
     repeat at all, whose columns repeat in DIFFERENT places (the tuple decides, not one column), and next to the other hints."""
@@ -800,7 +814,7 @@ def test_content_addressed_group_identical_trees(ctx, nv):
                 ctx.set_option(o, 0)
     r0, t0, s0 = trees[0]
     assert s0["cons_columns"] == 0
-    levels = nv - 14 + 1
+    levels = _list_levels(nv)
     for g, (r, t, st) in zip(groups, trees[1:]):
         assert np.array_equal(r, r0), g
         bad = np.nonzero(t != t0)[0]
@@ -874,13 +888,13 @@ def test_content_addressed_group_virtual_openings(ctx, nv):
 
 
 def test_run_aware_hash_counts(ctx):
-    """What the run-aware levels cost: a constant column needs one hash per tile of 4096 nodes; a change point at most
-    two more per level."""
+    """What the run-aware levels cost: a constant column needs one hash per tile (the range one segment covers at a level);
+    a change point at most two more per level."""
     import zigz_amd
     nv = 16
     N = 1 << nv
-    levels = nv - 14 + 1                                         # 3 run-aware levels: 65536, 32768, 16384 nodes
-    tiles = sum((N >> l) // 4096 for l in range(levels))
+    levels = _list_levels(nv)                                    # 9 list-driven levels: 65536 .. 256 nodes
+    tiles = sum((N >> l) // _run_tile_nodes(N, l) for l in range(levels))
     cols = np.zeros((4, N), dtype=np.uint64)
     cols[1, :] = 77
     cols[2, 12345:] = 3                                          # one change point
@@ -894,10 +908,11 @@ def test_run_aware_hash_counts(ctx):
     finally:
         ctx.set_option("run_aware_mask", 0)
     assert st["run_aware_columns"] == 4
-    # one hash per tile for the constant columns; column 2's change point costs 1 leaf + 2 nodes on each higher level;
-    # column 3's 15 change points sit on tile starts at the leaves and cost one node each where they do not above
-    assert st["run_aware_hashed"] == 4 * tiles + (1 + 2 * 2) + (8 + 12)
     assert st["run_aware_hashed"] == _run_aware_hashed(cols, levels)
+    # one hash per tile for the constant columns; column 2's change point costs 1 leaf + at most 2 nodes on each higher level;
+    # column 3's 15 change points sit on tile starts at the leaves and cost at most one node each above
+    assert 4 * tiles < st["run_aware_hashed"] <= 4 * tiles + (1 + 2 * (levels - 1)) + 15 * levels
+    assert _run_aware_hashed(cols[:2], levels) == 2 * tiles
     for c in range(4):
         lv, h = O.merkle_levels(cols[c])
         assert lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes() == roots[c].tobytes()

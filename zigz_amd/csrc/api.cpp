@@ -22,7 +22,7 @@ using namespace zk;
 // ------------------------------------------------------------------ context
 enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_CONS, WS_CONSMETA, WS_SLOTS };
 
-constexpr int KEV_MAX = 56;
+constexpr int KEV_MAX = 72;
 struct zigz_ctx {
     int device;
     hipStream_t own_stream;
@@ -61,6 +61,12 @@ struct zigz_ctx {
     unsigned long long *d_sd_fallbacks;
     zigz_kernel_stats stats;
     zigz_commit_job *active_job;
+    // content-addressing table of the last build (generation-tagged slots: cleared only when new or out of generations)
+    void *cons_table;
+    size_t cons_table_bytes;
+    unsigned cons_gen;
+    // what the last build asked for; turned into stats when its counters have arrived (zigz_commit_roots)
+    uint64_t build_cons_hinted, build_cons_levels_nodes, build_cons_sd, build_top_perms;
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
@@ -1115,8 +1121,13 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     ctx->stats.run_aware_dense_nodes = 0;
     ctx->stats.cons_columns = 0;
     ctx->stats.cons_dense_nodes = 0;
+    ctx->stats.cons_probe_distinct = 0;
+    ctx->build_cons_hinted = 0;
+    ctx->build_cons_levels_nodes = 0;
+    ctx->build_cons_sd = 0;
+    ctx->build_top_perms = 0;
     if (record) ctx->kev_n = 0;
-    // timing mode: every Keccak launch carries its own begin / end timestamps, by class
+    // timing mode: every launch (or bracketed group of launches) carries its own begin / end timestamps, by class
     KTime kt_store;
     auto stamp = [&](int cls, uint64_t perms) -> const KTime * {
         if (!record || ctx->kev_n >= KEV_MAX) return nullptr;
@@ -1126,50 +1137,23 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         ctx->kev_n++;
         return &kt_store;
     };
-    // Three kinds of columns:
+    // Four kinds of columns:
+    //   G  hinted as a group that repeats in the same places (the columns that are functions of the instruction at pc): the
+    //      levels 0 .. v - 8 are content-addressed -- takes precedence over H and R.  Whether the group repeats enough to be
+    //      worth it is decided ON THE DEVICE after the leaf level's table pass (more than a quarter of the leaves distinct:
+    //      dropped); a dropped group's columns are built like H (its small-domain members) and D (the rest) by launches that
+    //      read the same device flag, so nothing here waits for the device;
     //   H  hinted small-domain (values < 128 by construction): levels 0 and 1 from two constant tables, checked per wave
     //      and hashed where the bound does not hold;
-    //   R  hinted run-aware (piecewise constant): the levels with >= RUN_TILE nodes by k_keccak_runs, which hashes a node
-    //      only where it is not a copy of its left neighbour -- decided from the values, so the hint cannot make a tree wrong;
+    //   R  hinted run-aware (piecewise constant): the levels 0 .. v - 8 from lists of the nodes that are not a copy of their
+    //      left neighbour -- decided from the values, so the hint cannot make a tree wrong;
     //   D  the rest: hashed densely.
-    // From the level where every column is complete the launches cover all columns together.
-    //   G  hinted as a group that repeats in the same places (the columns that are functions of the instruction at pc): the
-    //      levels with >= RUN_MIN_NODES nodes are content-addressed (launch_keccak_cons) -- takes precedence over H and R.
-    ColMap H{}, R{}, D{}, G{};
+    // The top kernel (256 nodes per column -> root) takes all columns together.
+    ColMap H{}, R{}, D{}, G{}, GS{};
+    const bool big = npad >= RUN_MIN_LEAVES && npad <= RUN_MAX_LEAVES && ncols <= 64;
     const bool sd_ok = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
-    const bool run_ok = ctx->run_aware_mask && npad >= 2 * RUN_MIN_NODES && npad <= ((size_t)1 << 26) && ncols <= 64;
-    bool cons_ok = ctx->cons_group_mask && npad >= 2 * RUN_MIN_NODES && npad <= ((size_t)1 << 26) && ncols <= 64;
-    // The group pays only where it repeats (a loop): probe the leaf level first -- one table pass -- and read back how many
-    // distinct leaves (tuples of the group's values) there are.  More than a quarter of the leaves: the columns are built
-    // like any others (a trace that never loops would pay 70 % more for table passes that find nothing).  The read-back is
-    // the one place where starting a batched commit waits for the device (~0.1 ms).
-    void *cons_w = nullptr, *cons_mw = nullptr;
-    ctx->stats.cons_probe_distinct = 0;
-    if (cons_ok) {
-        ColMap P_{};
-        for (size_t c = 0; c < ncols; c++)
-            if ((ctx->cons_group_mask >> c) & 1) P_.c[P_.n++] = (uint8_t)c;
-        if (P_.n == 0) cons_ok = false;
-        else {
-            // the representative arrays outlive the build only in a commit job with virtual nodes: they then live in a
-            // workspace of their own, which nothing but the next commit job touches (other calls may interleave with a job)
-            const bool keep = run_meta != nullptr && !ctx->run_aware_materialize;
-            const size_t scratch = 2 * npad * 12 + cons_list_entries(npad) * 4 + 256;
-            CHK(ws_get(ctx, WS_CONS, scratch + (keep ? 0 : 64 + 2 * npad * 4), &cons_w));
-            if (keep) CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &cons_mw));
-            else cons_mw = (uint8_t *)cons_w + ((scratch + 63) & ~(size_t)63);
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
-            launch_cons_probe(d_vals, val_stride, n_values, npad, (uint32_t *)cons_mw, (unsigned long long *)cons_w,
-                              (uint32_t *)((uint8_t *)cons_w + 2 * npad * 8), (uint32_t *)((uint8_t *)cons_w + 2 * npad * 12),
-                              ctx->d_cons_count, P_, ctx->stream, nullptr);
-            HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, ctx->d_cons_count, 33 * 128, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
-            uint64_t distinct = 0;
-            for (int sb = 0; sb < 32; sb++) distinct += ctx->h_pin[(1 + sb) * 16];
-            ctx->stats.cons_probe_distinct = distinct;
-            if (distinct > npad / 4) cons_ok = false;
-        }
-    }
+    const bool run_ok = ctx->run_aware_mask && big;
+    const bool cons_ok = ctx->cons_group_mask && big;
     auto kind = [&](size_t c) -> int {  // 0 D, 1 H, 2 R, 3 G
         if (cons_ok && ((ctx->cons_group_mask >> c) & 1)) return 3;
         if (sd_ok && ((ctx->small_domain_mask >> c) & 1)) return 1;
@@ -1181,118 +1165,166 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             const int kd = kind(c);
             ColMap &m = kd == 3 ? G : kd == 1 ? H : kd == 2 ? R : D;
             m.c[m.n++] = (uint8_t)c;
+            if (kd == 3 && sd_ok && ((ctx->small_domain_mask >> c) & 1)) GS.c[GS.n++] = (uint8_t)c;
         }
+    const bool lists = R.n || G.n;
+    const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;  // copies / non-representatives / table leaves unwritten
     if (H.n == 0 && R.n == 0 && G.n == 0) {
         launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
     } else if (D.n) {
         launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
                              stamp(0, (uint64_t)D.n * npad), &D);
     }
-    if (run_meta) {
-        *run_meta = RunMeta{};
-        for (int c = 0; c < 64; c++) run_meta->y_of_col[c] = -1;
-    }
-    if (H.n) {
+    RunMeta meta{};
+    for (int c = 0; c < 64; c++) meta.y_of_col[c] = -1;
+    void *sd_todo = nullptr;
+    if (H.n || GS.n) {
         if (!ctx->d_sd_tables) {
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_tables, SD_TABLE_BYTES));
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_fallbacks, 64));
             launch_sd_tables(ctx->d_sd_tables, ctx->stream);
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 8, ctx->stream));
-        void *todo;
-        CHK(ws_get(ctx, WS_DEDUP, sd_todo_words(npad, H.n) * 4, &todo));
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 16, ctx->stream));
+        CHK(ws_get(ctx, WS_DEDUP, (sd_todo_words(npad, H.n) + sd_todo_words(npad, GS.n)) * 4, &sd_todo));
+    }
+    if (H.n) {
         // in a commit job the leaf digests of these columns are left out (virtual): only an opening reads one, and it
         // hashes that value itself
-        const bool virt_leaves = run_meta != nullptr && !ctx->run_aware_materialize;
         launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
-                                (uint32_t *)todo, ctx->stream, stamp(3, 0), !virt_leaves);
-        if (virt_leaves)
-            for (unsigned k = 0; k < H.n; k++) run_meta->virtual_leaves |= 1ull << H.c[k];
+                                (uint32_t *)sd_todo, ctx->stream, stamp(3, 0), !virt);
+        if (virt)
+            for (unsigned k = 0; k < H.n; k++) meta.virtual_leaves |= 1ull << H.c[k];
         ctx->stats.small_domain_columns = H.n;
     }
-    unsigned run_top = 0;  // R columns: levels 0..run_top come from the run-aware kernel
-    if (R.n) {
-        run_top = height - log2_floor(RUN_MIN_NODES);  // the last level with RUN_MIN_NODES nodes per column
-        // scratch: per hinted column and node of the levels >= 1 a "first value" word and a "uniform?" byte | the list of the
-        // current level.  Kept for the openings (virtual copies) or scratch as well (everything written): per level and 64
-        // nodes the bitmap of hashed nodes and the last hashed node before the chunk
-        const size_t uni_bytes = (size_t)R.n * npad, fv_bytes = uni_bytes * 4, list_bytes = runs_list_entries(npad, R.n) * 4;
-        const size_t meta_n = runs_meta_words(npad, R.n);
-        const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;
-        void *w, *mw;
-        CHK(ws_get(ctx, WS_RUNS, fv_bytes + list_bytes + uni_bytes + (virt ? 0 : meta_n * 10 + 64), &w));
-        uint32_t *fv = (uint32_t *)w;
-        uint32_t *list = (uint32_t *)((uint8_t *)w + fv_bytes);
-        uint8_t *uni = (uint8_t *)w + fv_bytes + list_bytes;
-        if (virt) CHK(ws_get(ctx, WS_RUNMETA, meta_n * 10 + 64, &mw));
-        else mw = (uint8_t *)w + ((fv_bytes + list_bytes + uni_bytes + 63) & ~(size_t)63);
-        RunMeta meta{};
-        meta.bitmap = (unsigned long long *)mw;
-        meta.prev = (unsigned short *)((uint8_t *)mw + meta_n * 8);
-        meta.ncols = R.n;
-        meta.virt_levels = virt ? run_top : 0;  // the top run-aware level is always filled in: the dense kernels read it
-        for (int c = 0; c < 64; c++) meta.y_of_col[c] = -1;
-        for (unsigned y = 0; y < R.n; y++) meta.y_of_col[R.c[y]] = (signed char)y;
-        if (run_meta) {
-            meta.virtual_leaves = run_meta->virtual_leaves;
-            *run_meta = meta;
+    MerkleBuild b{};
+    unsigned top = 0;
+    if (lists) {
+        top = run_top_level(npad);
+        b.vals = d_vals;
+        b.val_stride = val_stride;
+        b.n_values = n_values;
+        b.npad = npad;
+        b.tree = d_tree;
+        b.tree_stride_nodes = stride;
+        b.rcols = R;
+        b.gcols = G;
+        b.gcols_sd = GS;
+        uint64_t level_nodes = 0;
+        for (unsigned l = 0; l <= top; l++) level_nodes += npad >> l;
+        if (R.n) {
+            // scratch: the lists of all levels + what the stages hand to each other.  Kept for the openings (virtual copies)
+            // or scratch as well (everything written): per level and 64 nodes the bitmap of hashed nodes and the last hashed
+            // node before the chunk
+            b.r_lists = runs_lists(npad, R.n);
+            const size_t list_bytes = (size_t)b.r_lists.entries * 4, stage_bytes = runs_stage_scratch_bytes(npad, R.n);
+            const size_t meta_n = runs_meta_words(npad, R.n);
+            void *w, *mw;
+            CHK(ws_get(ctx, WS_RUNS, list_bytes + stage_bytes + 64 + (virt ? 0 : meta_n * 10 + 64), &w));
+            b.r_list = (uint32_t *)w;
+            b.r_stage = (uint8_t *)w + ((list_bytes + 63) & ~(size_t)63);
+            if (virt) CHK(ws_get(ctx, WS_RUNMETA, meta_n * 10 + 64, &mw));
+            else mw = (uint8_t *)w + ((list_bytes + stage_bytes + 64 + 63) & ~(size_t)63);
+            meta.bitmap = (unsigned long long *)mw;
+            meta.prev = (unsigned short *)((uint8_t *)mw + meta_n * 8);
+            meta.ncols = R.n;
+            meta.run_levels = top + 1;
+            for (unsigned y = 0; y < R.n; y++) meta.y_of_col[R.c[y]] = (signed char)y;
+            b.r_ctr = ctx->d_run_count;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
+            ctx->stats.run_aware_columns = R.n;
+            ctx->stats.run_aware_dense_nodes = (uint64_t)R.n * level_nodes;
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
-        for (unsigned l = 0; l <= run_top; l++) {
-            launch_keccak_runs(d_vals, val_stride, n_values, npad, d_tree, stride, l, uni, fv, meta, list, ctx->d_run_count, R,
-                               ctx->stream, stamp(4, 0));
-            ctx->stats.run_aware_dense_nodes += (uint64_t)R.n * (npad >> l);
+        if (G.n) {
+            // table (generation-tagged: cleared only when the workspace is new or the generations run out) + lists: scratch;
+            // the representative arrays are kept while the trees are read through them (a workspace of their own, which nothing
+            // but the next commit job touches)
+            b.g_lists = cons_lists(npad);
+            const size_t key_bytes = 2 * npad * 8, idx_bytes = 2 * npad * 4, list_bytes = (size_t)b.g_lists.entries * 4;
+            void *w, *mw;
+            CHK(ws_get(ctx, WS_CONS, key_bytes + idx_bytes + list_bytes + 64 + (virt ? 0 : 2 * npad * 4 + 64), &w));
+            b.g_keys = (unsigned long long *)w;
+            b.g_idx = (uint32_t *)((uint8_t *)w + key_bytes);
+            b.g_list = (uint32_t *)((uint8_t *)w + key_bytes + idx_bytes);
+            if (virt) CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &mw));
+            else mw = (uint8_t *)w + ((key_bytes + idx_bytes + list_bytes + 64 + 63) & ~(size_t)63);
+            b.g_rep = (uint32_t *)mw;
+            if (ctx->cons_table != w || ctx->cons_table_bytes != ctx->ws_bytes[WS_CONS] || ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096) {
+                HIPCHK(ctx, hipMemsetAsync(w, 0, key_bytes, ctx->stream));  // generation 0 = free
+                ctx->cons_table = w;
+                ctx->cons_table_bytes = ctx->ws_bytes[WS_CONS];
+                ctx->cons_gen = 1;
+            }
+            b.g_gen = ctx->cons_gen;
+            ctx->cons_gen += top + 1;
+            b.g_ctr = ctx->d_cons_count;
+            HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
+            meta.cons_rep = b.g_rep;
+            meta.cons_levels = top + 1;
+            meta.cons_dropped = ctx->d_cons_count + 8;
+            for (unsigned k = 0; k < G.n; k++) meta.cons_mask |= 1ull << G.c[k];
+            if (virt)
+                for (unsigned k = 0; k < GS.n; k++) meta.cons_sd_mask |= 1ull << GS.c[k];
+            ctx->build_cons_hinted = G.n;
+            ctx->build_cons_levels_nodes = level_nodes;
+            ctx->build_cons_sd = GS.n;
         }
-        ctx->stats.run_aware_columns = R.n;
+        b.meta = meta;
+        launch_runs_structure(b, ctx->stream, R.n ? stamp(4, 0) : nullptr);
+        launch_cons_structure(b, ctx->stream, G.n ? stamp(4, 0) : nullptr);
+        if (GS.n)  // only if the group was dropped: its small-domain members' levels 0 and 1 by table
+            launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, GS, ctx->d_sd_tables, ctx->d_sd_fallbacks + 1,
+                                    (uint32_t *)sd_todo + sd_todo_words(npad, H.n), ctx->stream, stamp(3, 0), !virt, ctx->d_cons_count + 8);
     }
-    unsigned cons_top = 0;  // G columns: levels 0..cons_top are content-addressed
-    if (G.n) {
-        cons_top = height - log2_floor(RUN_MIN_NODES);
-        const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;
-        void *w = cons_w, *mw = cons_mw;  // table + list (scratch) and the representative arrays (kept while the trees are read
-        unsigned long long *keys = (unsigned long long *)w;  // through them); level 0 was done by the probe above
-        uint32_t *idx = (uint32_t *)((uint8_t *)w + 2 * npad * 8);
-        uint32_t *list = (uint32_t *)((uint8_t *)w + 2 * npad * 12);
-        launch_keccak_cons(d_vals, val_stride, n_values, npad, d_tree, stride, cons_top, virt ? cons_top : 0, (uint32_t *)mw, keys, idx,
-                           list, ctx->d_cons_count, G, ctx->stream, nullptr);
-        if (run_meta && virt) {
-            run_meta->cons_rep = (const uint32_t *)mw;
-            run_meta->cons_levels = cons_top;  // the top content-addressed level is filled in: the dense kernels read it
-            for (unsigned k = 0; k < G.n; k++) run_meta->cons_mask |= 1ull << G.c[k];
-        }
-        for (unsigned l = 0; l <= cons_top; l++) ctx->stats.cons_dense_nodes += (uint64_t)G.n * (npad >> l);
-        ctx->stats.cons_columns = G.n;
-    }
-    for (unsigned l = 0; l < height; l++) {  // level l + 1 from level l, for the columns that do not have it yet
-        const size_t n_out = npad >> (l + 1);
-        const bool with_h = l >= 1, with_r = l >= run_top, with_g = l >= cons_top;
-        if (n_out <= 256) {  // all columns are complete here: run_top, cons_top < height - 9, and H stops at level 1
-            launch_keccak_top(d_tree, stride, npad, l, height, ncols, ctx->stream);
-            break;
-        }
-        ColMap m{};
-        const ColMap *pm = nullptr;
-        size_t nc = ncols;
-        if ((H.n && !with_h) || (R.n && !with_r) || (G.n && !with_g)) {  // a subset: the sorted union of the kinds that take part
+    if (run_meta) *run_meta = meta;
+    unsigned first_top = 0;  // the level the top kernel starts from
+    if (lists) {
+        for (unsigned l = 0; l <= top; l++) {
+            launch_level_hash(b, l, ctx->stream, stamp(5, 0));
+            if (l == top) break;
+            ColMap m{};  // the densely built columns that already have level l: D, and H from level 1
             for (size_t c = 0; c < ncols; c++) {
                 const int kd = kind(c);
-                if ((kd == 1 && with_h) || (kd == 2 && with_r) || (kd == 3 && with_g) || kd == 0) m.c[m.n++] = (uint8_t)c;
+                if (kd == 0 || (kd == 1 && l >= 1)) m.c[m.n++] = (uint8_t)c;
             }
-            if (m.n == 0) continue;
-            pm = &m;
-            nc = m.n;
+            if (m.n)
+                launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), npad >> (l + 1), ncols,
+                                    ctx->stream, stamp(keccak_level_is_wide(npad >> (l + 1), m.n) ? 1 : 2, (uint64_t)m.n * (npad >> (l + 1))), &m);
         }
-        launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols, ctx->stream,
-                            stamp(keccak_level_is_wide(n_out, nc) ? 1 : 2, (uint64_t)nc * n_out), pm);
+        first_top = top;
+    } else {
+        for (unsigned l = 0; l < height; l++) {  // level l + 1 from level l, for the columns that do not have it yet
+            const size_t n_out = npad >> (l + 1);
+            first_top = l;
+            if (n_out <= 256) break;  // all columns are complete here (H stops at level 1): the top kernel takes over
+            ColMap m{};
+            const ColMap *pm = nullptr;
+            size_t nc = ncols;
+            if (H.n && l < 1) {  // the table columns join at level 1
+                for (size_t c = 0; c < ncols; c++)
+                    if (kind(c) == 0) m.c[m.n++] = (uint8_t)c;
+                if (m.n == 0) continue;
+                pm = &m;
+                nc = m.n;
+            }
+            launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols, ctx->stream,
+                                stamp(keccak_level_is_wide(n_out, nc) ? 1 : 2, (uint64_t)nc * n_out), pm);
+        }
     }
+    if (height) {
+        ctx->build_top_perms = (uint64_t)ncols * ((npad >> first_top) - 1);
+        launch_merkle_top(d_tree, stride, npad, first_top, height, ncols, lists ? &meta : nullptr, ctx->stream, stamp(6, ctx->build_top_perms));
+    }
+    if (lists && !virt) launch_fill_virtual(b, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return ZIGZ_OK;
 }
 
 // after the stream has passed the last recorded launch: per-class device time of the last recorded build
 static zigz_status keccak_times_collect(zigz_ctx *ctx) {
-    double us[5] = {0, 0, 0, 0, 0};  // 0 leaves, 1 wide levels, 2 small levels, 3 small-domain table lookups, 4 run-aware levels
-    uint64_t perms[5] = {0, 0, 0, 0, 0};
+    // 0 leaves, 1 wide levels, 2 small levels, 3 small-domain table lookups, 4 structure passes (run-aware stages + content-
+    // addressing table passes: no hashing), 5 list-driven level hashing, 6 the top of the trees
+    double us[7] = {0, 0, 0, 0, 0, 0, 0};
+    uint64_t perms[7] = {0, 0, 0, 0, 0, 0, 0};
     for (int i = 0; i < ctx->kev_n; i++) {
         float ms = 0;
         HIPCHK(ctx, hipEventSynchronize(ctx->kev[2 * i + 1]));
@@ -1307,7 +1339,11 @@ static zigz_status keccak_times_collect(zigz_ctx *ctx) {
     ctx->stats.keccak_level_small_us = us[2];
     ctx->stats.keccak_level_small_perms = perms[2];
     ctx->stats.small_domain_us = us[3];
-    ctx->stats.run_aware_us = us[4];
+    ctx->stats.structure_us = us[4];
+    ctx->stats.list_hash_us = us[5];
+    ctx->stats.top_us = us[6];
+    ctx->stats.top_perms = perms[6];
+    ctx->stats.run_aware_us = us[4] + us[5];
     ctx->kev_n = 0;
     return ZIGZ_OK;
 }
@@ -1468,15 +1504,19 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
                             ncols, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
-        // the two diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later
+        // the diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later:
+        // [0] nodes hashed on the run-aware levels, [1] / [2] waves that left the small-domain tables (hinted columns / members
+        // of a dropped group), [3] digests computed on the content-addressed levels, [4] group dropped?, [5] its distinct leaves
         unsigned long long *h_cnt = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
-        h_cnt[0] = h_cnt[1] = h_cnt[2] = 0;
+        for (int i = 0; i < 6; i++) h_cnt[i] = 0;
         if (ctx->stats.run_aware_columns)
             HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_run_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->stats.small_domain_columns)
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->stats.cons_columns)
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[2], ctx->d_cons_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->stats.small_domain_columns || ctx->build_cons_sd)
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 16, hipMemcpyDeviceToHost, ctx->stream));
+        if (ctx->build_cons_hinted) {
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[3], ctx->d_cons_count, 8, hipMemcpyDeviceToHost, ctx->stream));
+            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[4], ctx->d_cons_count + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
         return ZIGZ_OK;
     };
@@ -1532,12 +1572,29 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     memcpy(roots, ctx->h_roots, job->ncols * 32);
     const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
     // the run-aware levels hashed h_cnt[0] of their run_aware_dense_nodes nodes
+    const uint64_t N = job->N;
     ctx->stats.run_aware_hashed = ctx->stats.run_aware_columns ? h_cnt[0] : 0;
     ctx->stats.keccak_permutations -= ctx->stats.run_aware_dense_nodes - ctx->stats.run_aware_hashed;
-    // likewise the content-addressed levels: h_cnt[2] digests computed for their cons_dense_nodes nodes
-    ctx->stats.cons_hashed = ctx->stats.cons_columns ? h_cnt[2] : 0;
-    ctx->stats.keccak_permutations -= ctx->stats.cons_dense_nodes - ctx->stats.cons_hashed;
     ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
+    ctx->stats.list_hash_perms = ctx->stats.run_aware_hashed;
+    // the group: kept (digests computed for its cons_dense_nodes nodes: h_cnt[3]) or dropped on the device (its small-domain
+    // members then took levels 0 and 1 from the tables, everything else was hashed densely)
+    ctx->stats.cons_columns = ctx->stats.cons_dense_nodes = ctx->stats.cons_hashed = 0;
+    if (ctx->build_cons_hinted) {
+        ctx->stats.cons_probe_distinct = h_cnt[5];
+        if (!h_cnt[4]) {
+            ctx->stats.cons_columns = ctx->build_cons_hinted;
+            ctx->stats.cons_dense_nodes = ctx->build_cons_hinted * ctx->build_cons_levels_nodes;
+            ctx->stats.cons_hashed = h_cnt[3];
+            ctx->stats.keccak_permutations -= ctx->stats.cons_dense_nodes - ctx->stats.cons_hashed;
+            ctx->stats.list_hash_perms += ctx->stats.cons_hashed;
+        } else {
+            ctx->stats.small_domain_columns += ctx->build_cons_sd;
+            ctx->stats.keccak_permutations -= ctx->build_cons_sd * (N + N / 2);
+            ctx->stats.small_domain_fallback_waves += h_cnt[2];
+            ctx->stats.list_hash_perms += ctx->build_cons_hinted * ctx->build_cons_levels_nodes - ctx->build_cons_sd * (N + N / 2);
+        }
+    }
     if (ctx->timing) {
         float ms = 0;
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->ev[2], ctx->ev[3]));

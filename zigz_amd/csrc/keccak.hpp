@@ -146,6 +146,9 @@ __constant__ const uint32_t KECCAK_RC_O[24] = {0x00000000u, 0x00000089u, 0x80000
 #ifndef ZK_KECCAK_UNROLL
 #define ZK_KECCAK_UNROLL 24
 #endif
+// PAUSE = false: no re-arm pauses -- for launches whose waves run (almost) alone on their SIMD (the top of a tree, where a
+// hash is a link in a dependent chain and the ~12 k sleep cycles per permutation are pure latency)
+template <bool PAUSE = true>
 __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) {
 #pragma unroll ZK_KECCAK_UNROLL
     for (int r = 0; r < 24; r++) {
@@ -168,7 +171,7 @@ __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) 
         const uint32_t re2 = ZK_ROT32(co2, 1);
         const uint32_t re3 = ZK_ROT32(co3, 1);
         const uint32_t re4 = ZK_ROT32(co4, 1);
-        ZK_REARM_A();  // phase 3: theta applied, t = a ^ C[x-1] ^ rot(C[x+1], 1)
+        if (PAUSE) ZK_REARM_A();  // phase 3: theta applied, t = a ^ C[x-1] ^ rot(C[x+1], 1)
         te[0] = ZK_X3(e[0], ce4, re1); to[0] = ZK_X3(o[0], co4, ce1);
         te[1] = ZK_X3(e[1], ce0, re2); to[1] = ZK_X3(o[1], co0, ce2);
         te[2] = ZK_X3(e[2], ce1, re3); to[2] = ZK_X3(o[2], co1, ce3);
@@ -220,7 +223,7 @@ __device__ __forceinline__ void keccak_f1600_il(uint32_t e[25], uint32_t o[25]) 
         be[9] = ZK_ROT32(to[22], 31); bo[9] = ZK_ROT32(te[22], 30);  // lane 22, rho 61
         be[19] = ZK_ROT32(te[23], 28); bo[19] = ZK_ROT32(to[23], 28);  // lane 23, rho 56
         be[4] = ZK_ROT32(te[24], 7); bo[4] = ZK_ROT32(to[24], 7);  // lane 24, rho 14
-        ZK_REARM_B();  // phase 5: chi
+        if (PAUSE) ZK_REARM_B();  // phase 5: chi
         e[0] = ZK_CHI(be[0], be[1], be[2]); o[0] = ZK_CHI(bo[0], bo[1], bo[2]);
         e[1] = ZK_CHI(be[1], be[2], be[3]); o[1] = ZK_CHI(bo[1], bo[2], bo[3]);
         e[2] = ZK_CHI(be[2], be[3], be[4]); o[2] = ZK_CHI(bo[2], bo[3], bo[4]);
@@ -295,6 +298,7 @@ __device__ __forceinline__ Digest canonical_digest(const Digest &t) {
 }
 
 // SHA3-256 of the 8 LE bytes of a canonical field element (pad: 0x06 at byte 8, 0x80 at byte 135), tree form
+template <bool PAUSE = true>
 __device__ __forceinline__ Digest sha3_leaf(uint64_t value) {
     uint32_t e[25], o[25];
 #pragma unroll
@@ -305,11 +309,12 @@ __device__ __forceinline__ Digest sha3_leaf(uint64_t value) {
     e[1] = 0x2u;  // lane 1 = 0x06: bit 1 (odd bit 0), bit 2 (even bit 1)
     o[1] = 0x1u;
     o[16] = 0x80000000u;  // lane 16 = 1 << 63: odd bit 31
-    keccak_f1600_il(e, o);
+    keccak_f1600_il<PAUSE>(e, o);
     return digest_of(e, o);
 }
 
 // SHA3-256 of left || right (64 bytes; pad: 0x06 at byte 64, 0x80 at byte 135); inputs and output in tree form
+template <bool PAUSE = true>
 __device__ __forceinline__ Digest sha3_node(const Digest &a, const Digest &b) {
     uint32_t e[25], o[25];
 #pragma unroll
@@ -322,7 +327,7 @@ __device__ __forceinline__ Digest sha3_node(const Digest &a, const Digest &b) {
     e[8] = 0x2u;
     o[8] = 0x1u;
     o[16] = 0x80000000u;
-    keccak_f1600_il(e, o);
+    keccak_f1600_il<PAUSE>(e, o);
     return digest_of(e, o);
 }
 

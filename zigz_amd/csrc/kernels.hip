@@ -12,19 +12,13 @@
 
 #include "field.hpp"
 #include "keccak.hpp"
+#include "tree_dev.hpp"
 
 namespace zk {
 
-constexpr int TPB = 256;      // 4 waves per workgroup
 constexpr int UNROLL = 4;     // 16-byte chunks per thread per tile: 8 x 16 B loads in flight
 constexpr size_t VEC_MIN_HALF = 4096;  // vector path needs half % (4*TPB*UNROLL) == 0
 
-// launch with (kt != nullptr) or without kernel-exact timestamps
-#define ZK_LAUNCH(kt, kern, grid, block, lds, s, ...)                                                             \
-    do {                                                                                                          \
-        if (kt) hipExtLaunchKernelGGL(kern, grid, block, lds, s, (kt)->start, (kt)->stop, 0, __VA_ARGS__);         \
-        else hipLaunchKernelGGL(kern, grid, block, lds, s, __VA_ARGS__);                                          \
-    } while (0)
 
 // ------------------------------------------------------------------ reductions
 __device__ __forceinline__ unsigned long long wave_sum(unsigned long long v) {
@@ -619,28 +613,7 @@ void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream
 // ------------------------------------------------------------------ K5/K6: Keccak Merkle
 // Tree nodes are stored in the bit-interleaved "tree form" of keccak.hpp (32 B per node, the same size as the SHA3
 // byte string); k_paths / k_gather_nodes convert to canonical bytes on the way out.
-// Non-temporal stores: a level's 1-3 GiB of digests are read back once by the next level, from HBM either way; kept out
-// of the caches they do not leave the L2 / 256 MB Infinity Cache full of dirty lines whose write-back would compete
-// with the next reader of the witness columns (the eval pass right after the build runs at 33 us instead of 37 us,
-// tools/merkle_rate.hip; the build itself is unchanged).
-__device__ __forceinline__ void store_digest(uint8_t *tree, size_t node, const Digest &d) {
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
-    __builtin_nontemporal_store(d.w[0], q + 0);  // merged into two global_store_dwordx4 ... nt
-    __builtin_nontemporal_store(d.w[1], q + 1);
-    __builtin_nontemporal_store(d.w[2], q + 2);
-    __builtin_nontemporal_store(d.w[3], q + 3);
-}
-typedef unsigned int zk_v4u __attribute__((ext_vector_type(4)));
-__device__ __forceinline__ void nt_store16(uint4 *dst, const uint4 &v) {  // global_store_dwordx4 ... nt
-    zk_v4u x = {v.x, v.y, v.z, v.w};
-    __builtin_nontemporal_store(x, reinterpret_cast<zk_v4u *>(dst));
-}
-__device__ __forceinline__ Digest load_digest(const uint8_t *tree, size_t node) {
-    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(tree + node * 32);
-    ulonglong2 x = q[0], y = q[1];
-    return Digest{{x.x, x.y, y.x, y.y}};
-}
-
+// (digest loads / stores: tree_dev.hpp)
 // HPT hashes per thread (strided by the workgroup size so loads/stores stay coalesced): amortises wave launch
 // and set-up over several ~4.2 k-instruction permutations.
 // occupancy experiments (tools/merkle_rate.hip): unused dynamic LDS per workgroup caps the workgroups per CU
@@ -715,505 +688,6 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_MIN_WAVES) void k_keccak_level(uint8_
     }
 }
 
-// Finishes a tree from a level of at most 2*TPB nodes up to the root in ONE launch (one workgroup
-// per column; levels hand over through global memory + workgroup barrier on the same CU).
-__global__ __launch_bounds__(TPB) void k_keccak_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                                    unsigned first_level /*level of the input nodes*/,
-                                                    unsigned height) {
-    const size_t col = blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
-    for (unsigned l = first_level; l < height; l++) {
-        const size_t n_out = npad >> (l + 1);
-        const size_t in_off = 2 * npad - 2 * (npad >> l), out_off = 2 * npad - 2 * (npad >> (l + 1));
-        if (threadIdx.x < n_out) {
-            Digest a = load_digest(t, in_off + 2 * threadIdx.x), b = load_digest(t, in_off + 2 * threadIdx.x + 1);
-            store_digest(t, out_off + threadIdx.x, sha3_node(a, b));
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-}
-
-// ------------------------------------------------------------------ run-aware Merkle levels (node-granular)
-// A node whose subtree holds one value everywhere ("uniform") has the same digest as its left neighbour when that one is
-// uniform with the same value.  Per level, two or three launches over the hinted columns:
-//   k_runs_flags  one workgroup per tile of RUN_TILE consecutive nodes: uniform?  (children uniform + the two halves' first
-//                 values equal; leaves are uniform), copy-of-left?  The nodes that are NOT copies go onto ONE device-wide
-//                 list (a tile reserves its block with one atomic); the first node of a tile is always listed, so the
-//                 copies of a tile never depend on another tile.  Per 64-node chunk the "listed" mask and the last listed
-//                 node before the chunk go to RunMeta (kept for the life of a commit job).
-//   k_runs_hash   a fixed grid strides over the list: one hash per thread with every lane busy, whatever mix of constant
-//                 and busy columns produced the list (tile-local hashing left the chip idle behind the few busy tiles:
-//                 2.2 ms for the leaves of 31 columns, 0.22 ms for a level of 4096 nodes).  Children on a level whose
-//                 copies are virtual are read through their leader (run_leader).
-//   k_runs_fill   only on the levels >= RunMeta::virt_levels: per tile, every node takes the digest of the nearest listed
-//                 node at or before it; each store instruction writes 1 KiB of consecutive tree (16 B per lane, two lanes
-//                 per node), chunks without copies are skipped.
-// Whether filled in or read through its leader, every node has the dense tree's digest, bit for bit, for ANY input: the
-// values decide, not a hint.  Cost: (change points + tiles) hashes per level instead of one per node; a filled level also
-// writes 32 B per node.
-__device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, const Digest &d) {
-    unsigned long long *q = reinterpret_cast<unsigned long long *>(tree + node * 32);
-    q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
-}
-constexpr unsigned RUN_NODE_BITS = 26;  // list entry = hinted-column index << 26 | node
-// first entry of level l in RunMeta::bitmap / ::prev (one entry per 64 nodes, levels stored one after the other)
-__device__ __host__ __forceinline__ size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
-    return (size_t)ncols * ((2 * npad - 2 * (npad >> l)) / 64);
-}
-// the node whose digest node k of level l of hinted column y has: itself if it was hashed, else the nearest hashed node
-// before it in its tile
-__device__ __forceinline__ size_t run_leader(const RunMeta &m, size_t npad, unsigned y, unsigned l, size_t k) {
-    const size_t e = run_meta_base(npad, m.ncols, l) + ((size_t)y * (npad >> l) + k) / 64;
-    const unsigned q = (unsigned)(k & 63);
-    const unsigned long long mm = m.bitmap[e] & (q == 63 ? ~0ull : ((2ull << q) - 1));
-    if (mm) return (k & ~(size_t)63) + (63 - __builtin_clzll(mm));
-    return (k & ~(size_t)(RUN_TILE - 1)) + m.prev[e];
-}
-constexpr unsigned RUN_SUBS = 32;       // sub-lists per level (power of two)
-
-template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_runs_flags(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                    size_t npad, unsigned L, uint8_t *__restrict__ uni, uint32_t *__restrict__ fv,
-                                                    RunMeta meta, uint32_t *__restrict__ list,
-                                                    size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap cmap) {
-    constexpr int CH = RUN_TILE / 64;  // chunks of 64 nodes per tile
-    constexpr int NPT = RUN_TILE / TPB;  // nodes per thread
-    static_assert(CH == 64, "one lane per chunk in the scan");
-    __shared__ uint32_t s_x[RUN_TILE];  // first value of every node of the tile
-    __shared__ uint8_t s_u[RUN_TILE];   // uniform?
-    __shared__ unsigned long long s_need[CH];
-    __shared__ unsigned s_off[CH + 1];
-    __shared__ unsigned long long s_base;
-    const size_t col = cmap.c[blockIdx.y];
-    const uint32_t *v = vals + col * val_stride;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
-    const size_t n_nodes = npad >> L;
-    // Per hinted column (blockIdx.y) and level l >= 1, at offset npad - (npad >> (l - 1)): one byte "uniform?" and one word
-    // "first value" per node, written by this kernel for the next level -- so a level reads 10 contiguous bytes per node
-    // instead of two values 2^l words apart in the column.
-    const size_t lvl_in = L >= 2 ? npad - (npad >> (L - 2)) : 0, lvl_out = L >= 1 ? npad - (npad >> (L - 1)) : 0;
-    const uint8_t *u_in = uni + blockIdx.y * npad + lvl_in;
-    uint8_t *u_out = uni + blockIdx.y * npad + lvl_out;
-    const uint32_t *f_in = fv + blockIdx.y * npad + lvl_in;
-    uint32_t *f_out = fv + blockIdx.y * npad + lvl_out;
-    // all loads of the thread's 16 nodes first (independent, in flight together), then the flags
-    uint32_t x[NPT], y[NPT];
-    unsigned short uu[NPT];
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const size_t k = tile_base + j * TPB + threadIdx.x;
-        if (LEAF) {
-            x[j] = k < n_values ? v[k] : 0u;  // padding leaves are hashLeaf(0), merkle_tree.zig:302-306
-        } else if (L == 1) {
-            x[j] = 2 * k < n_values ? v[2 * k] : 0u;
-            y[j] = 2 * k + 1 < n_values ? v[2 * k + 1] : 0u;
-            uu[j] = 0x0101;  // leaves are uniform
-        } else {
-            const uint2 p = *reinterpret_cast<const uint2 *>(f_in + 2 * k);  // first values of the two children
-            x[j] = p.x;
-            y[j] = p.y;
-            uu[j] = *reinterpret_cast<const unsigned short *>(u_in + 2 * k);
-        }
-    }
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const unsigned li = j * TPB + threadIdx.x;
-        const bool u = LEAF ? true : (x[j] == y[j] && uu[j] == 0x0101);  // both children uniform and the halves agree
-        s_x[li] = x[j];
-        s_u[li] = u ? 1 : 0;
-        if (!LEAF) {
-            u_out[tile_base + li] = u ? 1 : 0;
-            f_out[tile_base + li] = x[j];
-        }
-    }
-    __syncthreads();
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const unsigned li = j * TPB + threadIdx.x;
-        // a copy of its left neighbour: both uniform, same value (the first node of a tile is always listed)
-        const bool copy = li != 0 && s_u[li] && s_u[li - 1] && s_x[li] == s_x[li - 1];
-        const unsigned long long need = __ballot(!copy);
-        if (lane == 0) s_need[j * (TPB / 64) + wave] = need;
-    }
-    __syncthreads();
-    if (wave == 0) {
-        const unsigned long long m = s_need[lane];
-        const unsigned cnt = (unsigned)__builtin_popcountll(m);
-        unsigned incl = cnt;
-        int last = m ? (int)(lane * 64 + 63 - __builtin_clzll(m)) : -1;  // last listed node up to the end of this chunk
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned a = __shfl_up(incl, off, 64);
-            const int b = __shfl_up(last, off, 64);
-            if (lane >= (unsigned)off) { incl += a; last = last > b ? last : b; }
-        }
-        int prev = __shfl_up(last, 1, 64);
-        if (lane == 0) prev = 0;
-        const size_t e = run_meta_base(npad, meta.ncols, L) + (blockIdx.y * n_nodes + tile_base) / 64 + lane;
-        meta.bitmap[e] = m;
-        meta.prev[e] = (unsigned short)prev;
-        s_off[lane] = incl - cnt;
-        if (lane == 63) {
-            s_off[CH] = incl;
-            // this tile's block of the level's list.  The list is split into RUN_SUBS sub-lists with a counter each, every
-            // counter in a 128-byte line of its own: reservations into ONE word serialise at ~15 ns each (8 k tiles: 0.2 ms)
-            const unsigned sub = (blockIdx.y * gridDim.x + blockIdx.x) % RUN_SUBS;
-            s_base = (size_t)sub * sub_cap + atomicAdd(&ctr[(1 + L * RUN_SUBS + sub) * 16], (unsigned long long)incl);
-        }
-    }
-    __syncthreads();
-    const size_t base = s_base;
-#pragma unroll
-    for (int j = 0; j < NPT; j++) {
-        const unsigned c = j * (TPB / 64) + wave;
-        const unsigned long long m = s_need[c];
-        if ((m >> lane) & 1)
-            list[base + s_off[c] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] =
-                ((uint32_t)blockIdx.y << RUN_NODE_BITS) | (uint32_t)(tile_base + c * 64 + lane);
-    }
-}
-
-template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_runs_hash(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                   size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes, unsigned L,
-                                                   const uint32_t *__restrict__ list, size_t sub_cap,
-                                                   unsigned long long *__restrict__ ctr, RunMeta meta, ColMap cmap) {
-    __shared__ unsigned long long s_start[RUN_SUBS + 1];  // exclusive prefix of the sub-list lengths
-    if (threadIdx.x < 64) {
-        static_assert(RUN_SUBS <= 64, "one lane per sub-list");
-        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + L * RUN_SUBS + threadIdx.x) * 16] : 0;
-        unsigned long long incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long a = __shfl_up(incl, off, 64);
-            if (threadIdx.x >= (unsigned)off) incl += a;
-        }
-        if (threadIdx.x < RUN_SUBS) s_start[threadIdx.x] = incl - c;
-        if (threadIdx.x == RUN_SUBS - 1) {
-            s_start[RUN_SUBS] = incl;
-            if (blockIdx.x == 0) atomicAdd(&ctr[0], incl);  // nodes hashed by the whole build
-        }
-    }
-    __syncthreads();
-    const size_t cnt = s_start[RUN_SUBS];
-    const size_t out_off = 2 * npad - 2 * (npad >> L);
-    const size_t in_off = LEAF ? 0 : 2 * npad - 2 * (npad >> (L - 1));
-#pragma unroll 1
-    for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < cnt; e += (size_t)gridDim.x * TPB) {
-        unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
-#pragma unroll
-        for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
-            if (s_start[sub + step] <= e) sub += step;
-        const uint32_t ent = list[(size_t)sub * sub_cap + (e - s_start[sub])];
-        const unsigned y = ent >> RUN_NODE_BITS;
-        const size_t col = cmap.c[y], k = ent & ((1u << RUN_NODE_BITS) - 1);
-        uint8_t *t = tree + col * tree_stride_nodes * 32;
-        Digest d;
-        if (LEAF) {
-            d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
-        } else {
-            size_t c0 = 2 * k, c1 = 2 * k + 1;
-            if (L - 1 < meta.virt_levels) {  // the children's level holds hashed nodes only: read their leaders
-                c0 = run_leader(meta, npad, y, L - 1, c0);
-                c1 = run_leader(meta, npad, y, L - 1, c1);
-            }
-            d = sha3_node(load_digest(t, in_off + c0), load_digest(t, in_off + c1));
-        }
-        store_digest_plain(t, out_off + k, d);
-    }
-}
-
-__global__ __launch_bounds__(TPB) void k_runs_fill(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad, unsigned L,
-                                                   RunMeta meta, ColMap cmap) {
-    constexpr int CH = RUN_TILE / 64;
-    __shared__ unsigned long long s_need[CH];
-    __shared__ int s_prev[CH];
-    const size_t col = cmap.c[blockIdx.y];
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const size_t n_nodes = npad >> L;
-    const size_t tile_base = (size_t)blockIdx.x * RUN_TILE;
-    uint8_t *out = tree + (col * tree_stride_nodes + 2 * npad - 2 * n_nodes + tile_base) * 32;  // this tile's digests
-    if (wave == 0) {
-        const unsigned long long m = meta.bitmap[run_meta_base(npad, meta.ncols, L) + (blockIdx.y * n_nodes + tile_base) / 64 + lane];
-        s_need[lane] = m;
-        int last = m ? (int)(lane * 64 + 63 - __builtin_clzll(m)) : -1;  // last listed node at or before the end of the chunk
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int b = __shfl_up(last, off, 64);
-            if (lane >= (unsigned)off) last = last > b ? last : b;
-        }
-        int prev = __shfl_up(last, 1, 64);
-        if (lane == 0) prev = 0;
-        s_prev[lane] = prev;
-    }
-    __syncthreads();
-#pragma unroll 1
-    for (int j = 0; j < RUN_TILE / TPB; j++) {
-        const unsigned c = j * (TPB / 64) + wave;
-        const unsigned long long m = s_need[c];
-        if (m == ~0ull) continue;  // wave-uniform: every node of the chunk was hashed
-#pragma unroll
-        for (int h = 0; h < 2; h++) {  // 32 nodes x 2 halves of 16 B per store instruction: 1 KiB of consecutive tree
-            const unsigned q = 32 * h + (lane >> 1);
-            const unsigned long long mm = m & (q == 63 ? ~0ull : ((2ull << q) - 1));  // listed nodes at or before q
-            const int leader = mm ? (int)(c * 64 + 63 - __builtin_clzll(mm)) : s_prev[c];
-            const uint4 piece = *reinterpret_cast<const uint4 *>(out + (size_t)leader * 32 + (lane & 1) * 16);
-            nt_store16(reinterpret_cast<uint4 *>(out + (size_t)(c * 64 + q) * 32 + (lane & 1) * 16), piece);
-        }
-    }
-}
-
-// capacity of one sub-list: its share of the tiles of the widest level (the leaves), every node listed
-static size_t runs_sub_cap(size_t npad, size_t ncols) {
-    const size_t tiles = ncols * (npad / RUN_TILE);
-    return (tiles + RUN_SUBS - 1) / RUN_SUBS * RUN_TILE;
-}
-size_t runs_list_entries(size_t npad, size_t ncols) { return runs_sub_cap(npad, ncols) * RUN_SUBS; }
-size_t runs_meta_words(size_t npad, size_t ncols) { return ncols * (2 * npad / 64); }
-
-void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
-                        uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols, hipStream_t s, const KTime *kt) {
-    if (cols.n == 0) return;
-    const size_t n_nodes = npad >> level;  // caller: n_nodes >= RUN_TILE (a power of two, so a multiple of it)
-    const size_t sub_cap = runs_sub_cap(npad, cols.n);
-    const bool fill = level >= meta.virt_levels;
-    dim3 grid((unsigned)(n_nodes / RUN_TILE), (unsigned)cols.n);
-    size_t hash_wgs = (n_nodes * cols.n + TPB - 1) / TPB;
-    if (hash_wgs > 16384) hash_wgs = 16384;  // one hash per thread for lists up to 4 M entries; longer lists are strided over
-    // timing: the launches of a level are bracketed as one (start of the first, stop of the last)
-    hipEvent_t ev_start = kt ? kt->start : nullptr, ev_hash_stop = kt && !fill ? kt->stop : nullptr;
-#define ZK_RUN_LAUNCH(e0, e1, kern, g, ...)                                                            \
-    do {                                                                                               \
-        if ((e0) || (e1)) hipExtLaunchKernelGGL(kern, g, dim3(TPB), 0, s, (e0), (e1), 0, __VA_ARGS__); \
-        else hipLaunchKernelGGL(kern, g, dim3(TPB), 0, s, __VA_ARGS__);                                \
-    } while (0)
-    const dim3 hgrid((unsigned)hash_wgs);
-    if (level == 0) {
-        ZK_RUN_LAUNCH(ev_start, (hipEvent_t) nullptr, k_runs_flags<true>, grid, d_vals, val_stride, n_values, npad, level, d_uni, d_fv,
-                      meta, d_list, sub_cap, d_ctr, cols);
-        ZK_RUN_LAUNCH((hipEvent_t) nullptr, ev_hash_stop, k_runs_hash<true>, hgrid, d_vals, val_stride, n_values, npad, d_tree,
-                      tree_stride_nodes, level, d_list, sub_cap, d_ctr, meta, cols);
-    } else {
-        ZK_RUN_LAUNCH(ev_start, (hipEvent_t) nullptr, k_runs_flags<false>, grid, d_vals, val_stride, n_values, npad, level, d_uni, d_fv,
-                      meta, d_list, sub_cap, d_ctr, cols);
-        ZK_RUN_LAUNCH((hipEvent_t) nullptr, ev_hash_stop, k_runs_hash<false>, hgrid, d_vals, val_stride, n_values, npad, d_tree,
-                      tree_stride_nodes, level, d_list, sub_cap, d_ctr, meta, cols);
-    }
-    if (fill)
-        ZK_RUN_LAUNCH((hipEvent_t) nullptr, kt ? kt->stop : (hipEvent_t) nullptr, k_runs_fill, grid, d_tree, tree_stride_nodes, npad,
-                      level, meta, cols);
-#undef ZK_RUN_LAUNCH
-}
-
-// ------------------------------------------------------------------ content-addressed levels of a column group
-// (kernels.hpp, launch_keccak_cons)
-constexpr unsigned long long CONS_EMPTY = ~0ull;
-__device__ __forceinline__ unsigned long long cons_mix(unsigned long long x) {  // splitmix64 finaliser
-    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
-    x ^= x >> 27; x *= 0x94d049bb133111ebull;
-    return x ^ (x >> 31);
-}
-// the key of node k: leaves -- a fingerprint of the group's values at leaf k; above -- the children's representatives
-template <bool LEAF>
-__device__ __forceinline__ unsigned long long cons_key(const uint32_t *vals, size_t val_stride, size_t n_values, const uint32_t *rep_prev,
-                                                       size_t k, const ColMap &g) {
-    if (LEAF) {
-        unsigned long long h = 0x243f6a8885a308d3ull;
-        for (unsigned j = 0; j < g.n; j++)
-            h = cons_mix(h ^ (k < n_values ? vals[(size_t)g.c[j] * val_stride + k] : 0u));  // padding leaves hold 0
-        return h == CONS_EMPTY ? h - 1 : h;
-    }
-    return ((unsigned long long)rep_prev[2 * k] << 32) | rep_prev[2 * k + 1];
-}
-
-template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_cons_insert(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                     size_t n_nodes, const uint32_t *__restrict__ rep_prev,
-                                                     unsigned long long *__restrict__ keys, uint32_t *__restrict__ idx,
-                                                     size_t mask, ColMap g, size_t first) {
-    const size_t k = first + (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (k >= n_nodes) return;
-    const unsigned long long key = cons_key<LEAF>(vals, val_stride, n_values, rep_prev, k, g);
-    size_t slot = cons_mix(key) & mask;
-    for (;;) {  // the table has twice as many slots as the level has nodes: a free or matching slot is always reached
-        // look before the atomic: in a loop-dominated trace a million nodes share a handful of keys, and a million
-        // compare-and-swaps on one word serialise at ~15 ns each
-        unsigned long long cur = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
-        if (cur == CONS_EMPTY) cur = atomicCAS(&keys[slot], CONS_EMPTY, key);
-        if (cur == CONS_EMPTY) {  // this thread inserted the key: it is the representative
-            idx[slot] = (uint32_t)k;
-            return;
-        }
-        if (cur == key) return;
-        slot = (slot + 1) & mask;
-    }
-}
-
-template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_cons_resolve(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values,
-                                                      size_t n_nodes, unsigned L, const uint32_t *__restrict__ rep_prev,
-                                                      const unsigned long long *__restrict__ keys, const uint32_t *__restrict__ idx,
-                                                      size_t mask, uint32_t *__restrict__ rep_out, uint32_t *__restrict__ list,
-                                                      size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap g) {
-    __shared__ unsigned s_cnt[TPB / 64];
-    __shared__ unsigned long long s_base;
-    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    bool is_rep = false;
-    if (k < n_nodes) {
-        const unsigned long long key = cons_key<LEAF>(vals, val_stride, n_values, rep_prev, k, g);
-        size_t slot = cons_mix(key) & mask;
-        while (keys[slot] != key) slot = (slot + 1) & mask;  // inserted by k_cons_insert
-        uint32_t r = idx[slot];
-        if (LEAF && r != k) {  // equal fingerprints are not yet equal tuples: verify, else this leaf stands for itself
-            for (unsigned j = 0; j < g.n; j++) {
-                const uint32_t *v = vals + (size_t)g.c[j] * val_stride;
-                if ((k < n_values ? v[k] : 0u) != (r < n_values ? v[r] : 0u)) { r = (uint32_t)k; break; }
-            }
-        }
-        rep_out[k] = r;
-        is_rep = r == k;
-    }
-    // representatives go onto the level's list (one reservation per workgroup, spread over the sub-list counters)
-    const unsigned long long m = __ballot(is_rep);
-    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned tot = 0;
-        for (int w = 0; w < TPB / 64; w++) { const unsigned c = s_cnt[w]; s_cnt[w] = tot; tot += c; }
-        const unsigned sub = blockIdx.x % RUN_SUBS;
-        s_base = (unsigned long long)sub * sub_cap + atomicAdd(&ctr[(1 + L * RUN_SUBS + sub) * 16], (unsigned long long)tot);
-    }
-    __syncthreads();
-    if (is_rep) list[s_base + s_cnt[wave] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)k;
-}
-
-// one digest per (representative, column of the group)
-template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_cons_hash(const uint32_t *__restrict__ vals, size_t val_stride, size_t n_values, size_t npad,
-                                                   uint8_t *__restrict__ tree, size_t tree_stride_nodes, unsigned L,
-                                                   const uint32_t *__restrict__ rep_all, const uint32_t *__restrict__ list,
-                                                   size_t sub_cap, unsigned long long *__restrict__ ctr, ColMap g) {
-    __shared__ unsigned long long s_start[RUN_SUBS + 1];
-    if (threadIdx.x < 64) {
-        const unsigned long long c = threadIdx.x < RUN_SUBS ? ctr[(1 + L * RUN_SUBS + threadIdx.x) * 16] : 0;
-        unsigned long long incl = c;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const unsigned long long a = __shfl_up(incl, off, 64);
-            if (threadIdx.x >= (unsigned)off) incl += a;
-        }
-        if (threadIdx.x < RUN_SUBS) s_start[threadIdx.x] = incl - c;
-        if (threadIdx.x == RUN_SUBS - 1) {
-            s_start[RUN_SUBS] = incl;
-            if (blockIdx.x == 0) atomicAdd(&ctr[0], incl * g.n);  // digests computed by the whole build
-        }
-    }
-    __syncthreads();
-    const size_t cnt = s_start[RUN_SUBS] * g.n;
-    const size_t out_off = 2 * npad - 2 * (npad >> L);
-    const size_t in_off = LEAF ? 0 : 2 * npad - 2 * (npad >> (L - 1));
-#pragma unroll 1
-    for (size_t t = (size_t)blockIdx.x * TPB + threadIdx.x; t < cnt; t += (size_t)gridDim.x * TPB) {
-        const size_t e = t / g.n;
-        const size_t col = g.c[t % g.n];
-        unsigned sub = 0;
-#pragma unroll
-        for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
-            if (s_start[sub + step] <= e) sub += step;
-        const size_t k = list[(size_t)sub * sub_cap + (e - s_start[sub])];
-        uint8_t *tr = tree + col * tree_stride_nodes * 32;
-        Digest d;
-        if (LEAF) d = sha3_leaf((uint64_t)(k < n_values ? vals[col * val_stride + k] : 0u));
-        else d = sha3_node(load_digest(tr, in_off + rep_all[in_off + 2 * k]), load_digest(tr, in_off + rep_all[in_off + 2 * k + 1]));
-        store_digest_plain(tr, out_off + k, d);
-    }
-}
-
-// every node of the level takes its representative's digest (levels the dense kernels or a whole-tree comparison read)
-__global__ __launch_bounds__(TPB) void k_cons_fill(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad, unsigned L,
-                                                   const uint32_t *__restrict__ rep_all, ColMap g) {
-    const size_t n_nodes = npad >> L, off = 2 * npad - 2 * n_nodes;
-    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (k >= n_nodes) return;
-    const uint32_t r = rep_all[off + k];
-    if (r == k) return;
-    uint8_t *tr = tree + (size_t)g.c[blockIdx.y] * tree_stride_nodes * 32;
-    store_digest(tr, off + k, load_digest(tr, off + r));
-}
-
-size_t cons_list_entries(size_t npad) { return ((npad / TPB + RUN_SUBS - 1) / RUN_SUBS) * TPB * RUN_SUBS; }
-
-// table passes of level L: representatives of its nodes into d_rep, the list of representatives and its sub-list counters
-static void cons_find(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, unsigned L, uint32_t *d_rep,
-                      unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g,
-                      hipStream_t s, hipEvent_t ev_start) {
-    const size_t n_nodes = npad >> L, slots = 2 * n_nodes, off = 2 * npad - 2 * n_nodes;
-    const size_t sub_cap = ((n_nodes + TPB - 1) / TPB + RUN_SUBS - 1) / RUN_SUBS * TPB;
-    const uint32_t *rep_prev = L ? d_rep + (2 * npad - 2 * (npad >> (L - 1))) : nullptr;
-    (void)hipMemsetAsync(d_keys, 0xff, slots * 8, s);
-    (void)hipMemsetAsync(d_idx, 0xff, slots * 4, s);
-    // seeded: the first nodes alone, then the rest -- in a loop-dominated trace the rest then only READS the table (a million
-    // simultaneous first insertions of a handful of keys serialise on those words: 4.3 ms instead of 0.86 per build)
-    const size_t seed = 4096 < n_nodes ? 4096 : n_nodes;
-    const dim3 g_seed((unsigned)((seed + TPB - 1) / TPB)), g_rest((unsigned)((n_nodes - seed + TPB - 1) / TPB)),
-        g_all((unsigned)((n_nodes + TPB - 1) / TPB));
-    if (L == 0) {
-        if (ev_start) hipExtLaunchKernelGGL(k_cons_insert<true>, g_seed, dim3(TPB), 0, s, ev_start, nullptr, 0, d_vals, val_stride,
-                                            n_values, seed, rep_prev, d_keys, d_idx, slots - 1, g, (size_t)0);
-        else hipLaunchKernelGGL(k_cons_insert<true>, g_seed, dim3(TPB), 0, s, d_vals, val_stride, n_values, seed, rep_prev, d_keys,
-                                d_idx, slots - 1, g, (size_t)0);
-        if (n_nodes > seed)
-            hipLaunchKernelGGL(k_cons_insert<true>, g_rest, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, rep_prev, d_keys,
-                               d_idx, slots - 1, g, seed);
-        hipLaunchKernelGGL(k_cons_resolve<true>, g_all, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, L, rep_prev, d_keys,
-                           d_idx, slots - 1, d_rep + off, d_list, sub_cap, d_ctr, g);
-    } else {
-        hipLaunchKernelGGL(k_cons_insert<false>, g_seed, dim3(TPB), 0, s, d_vals, val_stride, n_values, seed, rep_prev, d_keys, d_idx,
-                           slots - 1, g, (size_t)0);
-        if (n_nodes > seed)
-            hipLaunchKernelGGL(k_cons_insert<false>, g_rest, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, rep_prev, d_keys,
-                               d_idx, slots - 1, g, seed);
-        hipLaunchKernelGGL(k_cons_resolve<false>, g_all, dim3(TPB), 0, s, d_vals, val_stride, n_values, n_nodes, L, rep_prev, d_keys,
-                           d_idx, slots - 1, d_rep + off, d_list, sub_cap, d_ctr, g);
-    }
-}
-
-void launch_cons_probe(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint32_t *d_rep,
-                       unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g,
-                       hipStream_t s, const KTime *kt) {
-    cons_find(d_vals, val_stride, n_values, npad, 0, d_rep, d_keys, d_idx, d_list, d_ctr, g, s, kt ? kt->start : nullptr);
-}
-
-void launch_keccak_cons(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned top, unsigned fill_from, uint32_t *d_rep, unsigned long long *d_keys,
-                        uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &g, hipStream_t s, const KTime *kt) {
-    if (g.n == 0) return;
-    for (unsigned L = 0; L <= top; L++) {
-        const size_t n_nodes = npad >> L;
-        const size_t sub_cap = ((n_nodes + TPB - 1) / TPB + RUN_SUBS - 1) / RUN_SUBS * TPB;
-        if (L) cons_find(d_vals, val_stride, n_values, npad, L, d_rep, d_keys, d_idx, d_list, d_ctr, g, s, nullptr);  // (level 0: the probe)
-        size_t hash_wgs = (n_nodes * g.n + TPB - 1) / TPB;
-        if (hash_wgs > 16384) hash_wgs = 16384;
-        const bool last = L == top;
-        if (L == 0)
-            hipLaunchKernelGGL(k_cons_hash<true>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                               tree_stride_nodes, L, d_rep, d_list, sub_cap, d_ctr, g);
-        else
-            hipLaunchKernelGGL(k_cons_hash<false>, dim3((unsigned)hash_wgs), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad,
-                               d_tree, tree_stride_nodes, L, d_rep, d_list, sub_cap, d_ctr, g);
-        if (L >= fill_from || last) {
-            const dim3 fgrid((unsigned)((n_nodes + TPB - 1) / TPB), g.n);
-            if (kt && last) hipExtLaunchKernelGGL(k_cons_fill, fgrid, dim3(TPB), 0, s, nullptr, kt->stop, 0, d_tree, tree_stride_nodes,
-                                                  npad, L, d_rep, g);
-            else hipLaunchKernelGGL(k_cons_fill, fgrid, dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, L, d_rep, g);
-        }
-    }
-}
-
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                           size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
     ColMap cm{};
@@ -1266,7 +740,9 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__rest
                                                           size_t npad, uint8_t *__restrict__ tree, size_t tree_stride_nodes,
                                                           ColMap cmap, const uint8_t *__restrict__ tables,
                                                           unsigned long long *__restrict__ todo_count,
-                                                          uint32_t *__restrict__ todo, int write_leaves) {
+                                                          uint32_t *__restrict__ todo, int write_leaves,
+                                                          const unsigned long long *__restrict__ only_if) {
+    if (only_if && !*only_if) return;  // these columns went another way (a content-addressed group that was kept)
     const size_t col = cmap.c[blockIdx.y];
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;  // level-1 node
     const bool live = i < npad / 2;
@@ -1318,7 +794,9 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
                                                                size_t n_values, size_t npad, uint8_t *__restrict__ tree,
                                                                size_t tree_stride_nodes, ColMap cmap,
                                                                const unsigned long long *__restrict__ todo_count,
-                                                               const uint32_t *__restrict__ todo, int write_leaves) {
+                                                               const uint32_t *__restrict__ todo, int write_leaves,
+                                                               const unsigned long long *__restrict__ only_if) {
+    if (only_if && !*only_if) return;
     const unsigned long long count = *todo_count;
     const unsigned lane = threadIdx.x & 63;
     for (unsigned long long w = (unsigned long long)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6); w < count;
@@ -1341,20 +819,14 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
                              unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt,
-                             bool write_leaves) {
+                             bool write_leaves, const unsigned long long *d_only_if) {
     if (cols.n == 0 || npad < 2) return;
     dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
     ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
-              d_tables, d_todo_count, d_todo, write_leaves ? 1 : 0);
+              d_tables, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if);
     // list-driven; 512 workgroups walk the to-do list (empty unless a hint was wrong: then a few microseconds)
     hipLaunchKernelGGL(k_keccak_small_fallback, dim3(512), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                       tree_stride_nodes, cols, d_todo_count, d_todo, write_leaves ? 1 : 0);
-}
-
-void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
-                       size_t ncols, hipStream_t s) {
-    hipLaunchKernelGGL(k_keccak_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad,
-                       first_level, height);
+                       tree_stride_nodes, cols, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if);
 }
 
 // ------------------------------------------------------------------ K7: authentication paths
@@ -1370,13 +842,11 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
     const uint8_t *t = tree + col * tree_stride_nodes * 32;
     const size_t off = 2 * npad - 2 * (npad >> l);
-    size_t node = ci ^ 1;
-    const int y = col < 64 ? meta.y_of_col[col] : -1;
-    if (y >= 0 && l < meta.virt_levels) node = run_leader(meta, npad, (unsigned)y, l, node);  // a copy: its leader's digest
-    if (col < 64 && ((meta.cons_mask >> col) & 1) && l < meta.cons_levels) node = meta.cons_rep[off + node];  // its representative's
+    const size_t node = resolve_node(meta, npad, col, l, ci ^ 1);  // a copy / non-representative: where its digest is stored
+    bool virt_leaf = l == 0 && col < 64 && ((meta.virtual_leaves >> col) & 1);  // leaf digests of this column were never written
+    if (l == 0 && col < 64 && ((meta.cons_sd_mask >> col) & 1) && *meta.cons_dropped) virt_leaf = true;
     Digest d;
-    if (l == 0 && col < 64 && ((meta.virtual_leaves >> col) & 1))  // leaf digests of this column were never written
-        d = sha3_leaf(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
+    if (virt_leaf) d = sha3_leaf<false>((ci ^ 1) < n_values ? (uint64_t)vals[col * val_stride + (ci ^ 1)] : 0);
     else d = load_digest(t, off + node);
     d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
@@ -1390,7 +860,7 @@ void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, 
                   uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta) {
     RunMeta m{};
     if (meta) m = *meta;
-    else for (int c = 0; c < 64; c++) m.y_of_col[c] = -1;
+    else for (int c = 0; c < 64; c++) m.y_of_col[c] = -1;  // (cons_mask = cons_sd_mask = 0: cons_dropped is never read)
     hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, n_values, height, d_vals,
                        val_stride, d_idx, d_sib, d_dirs, d_leaf, m);
 }

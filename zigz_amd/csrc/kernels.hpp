@@ -103,58 +103,117 @@ struct ColMap {
     uint8_t n;
     uint8_t c[64];
 };
-// Run-aware levels.  A node that is a copy of its left neighbour (both subtrees uniform, same value) is not hashed, and on
-// the levels < RunMeta::virt_levels its digest is not even written: readers (the next level's hashes, the openings) resolve
-// a node to its "leader" -- the nearest hashed node at or before it in its 4096-node tile -- through the per-level bitmap of
-// hashed nodes and a per-chunk "last hashed node before this chunk".  Levels >= virt_levels are filled in (every digest in
-// HBM), which is what the dense kernels above the run-aware levels and single trees that outlive the call need.
+// ---------------------------------------------------------------- structure-aware levels (merkle_levels.hip)
+// The levels 0 .. v - 8 of a tree with >= 2^15 leaves (down to 256 nodes per column) can be built from LISTS of the nodes
+// that have to be hashed instead of densely, for two kinds of hinted columns:
+//   R  run-aware (piecewise constant columns: the registers, mem.address / mem.value): a node whose subtree and whose left
+//      neighbour's are uniform with the same value is a COPY of that neighbour;
+//   G  content-addressed group (the columns that are functions of the instruction at pc): a node with the same content in
+//      ALL columns of the group as an earlier node of its level shares that node's digests (its REPRESENTATIVE).
+// Both are decided from the VALUES on the device, never from the hint, so every node has the dense tree's digest for any
+// input.  Copies / non-representatives are VIRTUAL in a commit job: their 32 bytes are never written, readers (the next
+// level's hashes, the openings) resolve a node to its leader / representative through RunMeta.
+//
+// Structure first, hashing second: which nodes are hashed depends on the values only, not on digests, so ALL levels' lists
+// are produced up front -- R: one pass over the leaves per stage (k_runs_stage: a workgroup takes 4096 leaves of one column
+// and derives the change bitmap and from it, by bit arithmetic in one wave, the lists of levels 0..6; a second, tiny stage
+// takes the 4096-node segments of level 6 to levels 7..12, a third would reach 18); G: one table pass per level
+// (k_cons_pass: resolve level l-1 + insert level l, wave-deduplicated, generation-tagged slots so the table is never
+// cleared) -- and then ONE launch per level hashes the R list, the G list and, when the group was dropped, its columns'
+// dense nodes (k_level_hash).  Nothing on this path is read back by the host: whether the group repeats enough to be kept is
+// decided on the device (k_cons_decide sets RunMeta::cons_dropped) and every later launch reads that flag.
+constexpr unsigned RUN_SEG = 4096;        // input nodes per segment of a stage
+constexpr unsigned RUN_STAGE_LEVELS = 6;  // levels a stage adds above its input level (stage 0 also emits its input level 0)
+constexpr unsigned RUN_MAX_LEVELS = 20;   // list-driven levels 0 .. v - 8 for v <= 26 (+ 1 spare)
+constexpr unsigned RUN_SUBS = 32;         // sub-lists per level, each with a counter in a 128-byte line of its own
+constexpr unsigned RUN_NODE_BITS = 26;    // R list entry = hinted-column index << 26 | node
+constexpr size_t RUN_MIN_LEAVES = 32768;  // smaller trees are built densely
+constexpr size_t RUN_MAX_LEAVES = (size_t)1 << RUN_NODE_BITS;
+// counters of a build: word 0 = nodes hashed in all; word 8 (the group's array only) = "group dropped" flag, word 9 = distinct
+// leaves found; per level l and sub-list s the length at word (1 + l * RUN_SUBS + s) * 16
+constexpr unsigned RUN_CTRS = (1 + RUN_MAX_LEVELS * RUN_SUBS) * 16;
+__host__ __device__ inline size_t run_ctr_index(unsigned level, unsigned sub) { return (size_t)(1 + level * RUN_SUBS + sub) * 16; }
+// the last list-driven level: 256 nodes per column
+inline unsigned run_top_level(size_t npad) { unsigned v = 0; while (((size_t)1 << v) < npad) v++; return v - 8; }
+// Leader rule.  At level l the nodes of a column fall into TILES; the first node of a tile is always hashed, so a copy's
+// leader (the nearest hashed node at or before it) is inside its tile.  A tile is what ONE segment of a stage covers at
+// that level: 4096 >> l nodes at the levels 0..6, (4096 or the whole level-6 row) >> (l - 6) at 7..12, and so on.
+__host__ __device__ inline size_t run_tile_nodes(size_t npad, unsigned l) {
+    if (l == 0) return RUN_SEG;
+    const unsigned s = (l - 1) / RUN_STAGE_LEVELS;           // stage that emits level l
+    const size_t n_in = npad >> (s * RUN_STAGE_LEVELS);      // nodes per column of the stage's input level
+    const size_t seg = n_in < RUN_SEG ? n_in : RUN_SEG;
+    return seg >> (l - s * RUN_STAGE_LEVELS);
+}
 struct RunMeta {
-    unsigned long long *bitmap;  // per level l at word base(l): [hinted column y][node / 64], bit = hashed
+    unsigned long long *bitmap;  // per level l at word run_meta_base(l): [hinted column y][node / 64], bit = hashed
     unsigned short *prev;        // same indexing: local index (in the tile) of the last hashed node before the chunk
-    unsigned ncols;              // hinted columns
-    unsigned virt_levels;        // levels below this hold digests of hashed nodes only
+    unsigned ncols;              // hinted (R) columns
+    unsigned run_levels;         // R: the levels below this were built from lists (copies resolve to their leader)
     unsigned long long virtual_leaves;  // bit c: the leaf digests of column c were not written (small-domain columns of a
                                         // commit job): an opening hashes the sibling value itself
     signed char y_of_col[64];    // column -> hinted index, -1 = not hinted
-    // content-addressed group (launch_keccak_cons): on the levels < cons_levels a node of a column in cons_mask has the
-    // digest stored at node cons_rep[2 npad - 2 (npad >> l) + k] of the same level and column (its representative)
+    // content-addressed group: on the levels < cons_levels a node of a column in cons_mask has the digest stored at node
+    // cons_rep[2 npad - 2 (npad >> l) + k] of the same level and column (its representative) -- unless *cons_dropped
     const uint32_t *cons_rep;
     unsigned cons_levels;
     unsigned long long cons_mask;
+    const unsigned long long *cons_dropped;  // device word: != 0 -> the group did not repeat; its columns were built densely
+    unsigned long long cons_sd_mask;   // columns of the group whose leaf digests are virtual when the group was dropped
 };
-constexpr unsigned RUN_TILE = 4096;
-constexpr size_t RUN_MIN_NODES = 16384;  // levels with fewer nodes per column are built densely (launch latency dominates)
-constexpr unsigned RUN_MAX_LEVELS = 16;  // run-aware levels of a 2^26-leaf tree: 0 .. 26 - 14
-constexpr unsigned RUN_CTRS = (1 + RUN_MAX_LEVELS * 32) * 16;  // u64 words: the build's total + per level 32 sub-list counters,
-                                                               // each in a 128-byte line of its own
-size_t runs_list_entries(size_t npad, size_t ncols);
-size_t runs_meta_words(size_t npad, size_t ncols);  // entries of RunMeta::bitmap and ::prev for all levels
-// Level `level` (0 = leaves) of the columns in `cols`: flags + device-wide list, hash the list, and -- if level >=
-// meta.virt_levels -- fill in the copies.  d_uni / d_fv: cols.n x npad bytes / words of scratch; d_list:
-// runs_list_entries() u32; d_ctr: RUN_CTRS u64, zeroed by the caller before level 0 (d_ctr[0] += nodes hashed).  Levels
-// must be launched in order from 0.  Requires (npad >> level) >= RUN_TILE and npad <= 2^26.
-void launch_keccak_runs(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned level, uint8_t *d_uni, uint32_t *d_fv, const RunMeta &meta,
-                        uint32_t *d_list, unsigned long long *d_ctr, const ColMap &cols, hipStream_t s,
-                        const KTime *kt = nullptr);
-// Content-addressed levels 0..top of a GROUP of columns that repeat in the same places (the columns that are functions of the
-// instruction at pc): per level one device hash table finds, for every node, the first node of the level with the same
-// content in ALL columns of the group -- leaves: the tuple of the group's values (64-bit fingerprint, verified against the
-// representative's tuple); above: the pair of the children's representatives, which IS the identity of the hash input --
-// and only representatives are hashed (once per column).  d_rep: 2 npad u32 (kept while the trees are read through it);
-// d_keys / d_idx: 2 npad u64 / u32 of table; d_list: cons_list_entries() u32; d_ctr: RUN_CTRS u64, zeroed by the caller
-// (d_ctr[0] += digests computed).  Levels >= fill_from are filled in (every node's digest written).
-size_t cons_list_entries(size_t npad);
-// The table passes of the leaf level alone: afterwards the sub-list counters d_ctr[(1 + s) * 16], s < 32, add up to the number
-// of distinct leaves (tuples) of the group -- the caller decides from it whether the group repeats enough to go on
-// (launch_keccak_cons, which starts from this state) or is built like any other columns.
-void launch_cons_probe(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint32_t *d_rep,
-                       unsigned long long *d_keys, uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &group,
-                       hipStream_t s, const KTime *kt = nullptr);
-void launch_keccak_cons(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                        size_t tree_stride_nodes, unsigned top, unsigned fill_from, uint32_t *d_rep, unsigned long long *d_keys,
-                        uint32_t *d_idx, uint32_t *d_list, unsigned long long *d_ctr, const ColMap &group, hipStream_t s,
-                        const KTime *kt = nullptr);
+// first entry of level l in RunMeta::bitmap / ::prev (one entry per 64 nodes, levels stored one after the other)
+__host__ __device__ inline size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
+    return (size_t)ncols * ((2 * npad - 2 * (npad >> l)) / 64);
+}
+inline size_t runs_meta_words(size_t npad, size_t ncols) { return ncols * (2 * npad / 64); }
+// where the lists of the levels live: level l has RUN_SUBS sub-lists of cap[l] entries starting at entry base[l]
+struct LevelLists {
+    unsigned top;                               // levels 0 .. top
+    unsigned long long base[RUN_MAX_LEVELS];
+    unsigned cap[RUN_MAX_LEVELS];
+    unsigned long long entries;                 // total
+};
+LevelLists runs_lists(size_t npad, size_t ncols);  // R: entries are (y << 26 | node)
+LevelLists cons_lists(size_t npad);                // G: entries are nodes (representatives)
+// scratch of the R stages above stage 0: per hinted column the first values of the level-6 (12, 18) nodes and their
+// "not uniform" bits (u32 words, then u64 words)
+size_t runs_stage_scratch_bytes(size_t npad, size_t ncols);
+
+struct MerkleBuild {   // everything the structure-aware launches share (device pointers)
+    const uint32_t *vals;
+    size_t val_stride, n_values, npad;
+    uint8_t *tree;
+    size_t tree_stride_nodes;
+    // R
+    ColMap rcols;
+    RunMeta meta;                 // bitmap / prev / y_of_col; cons_* filled in when there is a group
+    uint32_t *r_list;
+    LevelLists r_lists;
+    unsigned long long *r_ctr;    // RUN_CTRS words, zeroed before the build
+    uint8_t *r_stage;             // runs_stage_scratch_bytes()
+    // G
+    ColMap gcols;                 // the group, ascending
+    ColMap gcols_sd;              // its small-domain members (levels 0-1 from the tables when the group is dropped)
+    unsigned long long *g_keys;   // 2 npad slots: generation << 52 | payload
+    uint32_t *g_idx;              // 2 npad: the node that inserted the slot's key
+    uint32_t *g_rep;              // 2 npad: representative of every node of the levels 0..top (tree_level_offset order)
+    uint32_t *g_list;
+    LevelLists g_lists;
+    unsigned long long *g_ctr;    // RUN_CTRS words, zeroed before the build
+    unsigned g_gen;               // generation of level 0 (level l uses g_gen + l); < 4096 - RUN_MAX_LEVELS
+};
+// R: all lists, bitmaps and leader tables of the levels 0..top (two or three launches, no hashing)
+void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt = nullptr);
+// G: the table passes of the levels 0..top and the keep / drop decision (top + 3 launches, no hashing)
+void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt = nullptr);
+// level L (<= top) of the R and G columns: hashes the two lists (and, when the group was dropped, its columns densely)
+void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt = nullptr);
+// writes the copies / non-representatives of the levels 0..top (whole-tree comparisons, single trees that outlive the call)
+void launch_fill_virtual(const MerkleBuild &b, hipStream_t s);
+// from level `first_level` (at most 512 nodes per column; its nodes are resolved through `meta` when given) to the root,
+// one workgroup per column
+void launch_merkle_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
+                       size_t ncols, const RunMeta *meta, hipStream_t s, const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,
@@ -175,12 +234,9 @@ inline size_t sd_todo_words(size_t npad, size_t ncols) { return 2 * ncols * ((np
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
                              unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr,
-                             bool write_leaves = true);
+                             bool write_leaves = true, const unsigned long long *d_only_if = nullptr);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
-// K6 tail: finishes a tree from level `first_level` (at most 512 nodes) up to the root in one launch.
-void launch_keccak_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
-                       size_t ncols, hipStream_t s);
 // K7: authentication paths.  For column c: index d_idx[c]; siblings -> d_sib[c][l][32], dirs -> d_dirs[c][l],
 // leaf value -> d_leaf[c].
 void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, size_t n_values, unsigned height,

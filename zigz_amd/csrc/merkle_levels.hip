@@ -1,0 +1,547 @@
+// Structure-aware Merkle levels for gfx950 (kernels.hpp: MerkleBuild).  Which nodes of a level have to be hashed -- for the
+// piecewise-constant columns (R) and the content-addressed group (G) -- depends on the VALUES only, so the lists of all
+// levels are produced first (HBM / latency-bound passes, no hashing) and then hashed level by level, one launch each.
+//
+//   k_runs_stage      R: one workgroup = 4096 input nodes of one column -> change bitmap (ballots) -> need-bits of up to
+//                     seven levels by bit arithmetic in one wave -> per-level bitmap / leader table / list entries
+//   k_cons_leaf_insert, k_cons_pass, k_cons_decide
+//                     G: per level a wave-deduplicated pass over a generation-tagged open-addressing table
+//   k_level_hash      one launch per level: the R list, the G list x columns, or the group's columns densely when dropped
+//   k_merkle_top      256 nodes per column -> root, one workgroup per column, no re-arm pauses (a dependent chain)
+//   k_runs_fill_level, k_cons_fill_level   materialise the virtual nodes (tests, single trees)
+//
+// Reference loops: SimpleMerkleTree.build, src/commitments/merkle_tree.zig:283-318 (every digest equals the dense build's).
+#include "kernels.hpp"
+#include "tree_dev.hpp"
+
+namespace zk {
+
+// ------------------------------------------------------------------ layout helpers (host)
+static unsigned log2u(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
+
+// stage s >= 1 reads, per hinted column, the first values (u32) and "not uniform" bits (u64 words) of the nodes of level 6 s
+static size_t stage_fv_bytes(size_t npad, size_t ncols, unsigned s) { return ncols * (npad >> (s * RUN_STAGE_LEVELS)) * 4; }
+static size_t stage_inner_bytes(size_t npad, size_t ncols, unsigned s) {
+    const size_t n = npad >> (s * RUN_STAGE_LEVELS);
+    return ncols * ((n + 63) / 64) * 8;
+}
+static size_t stage_off(size_t npad, size_t ncols, unsigned s) {  // byte offset of stage s's input arrays in r_stage
+    size_t off = 0;
+    for (unsigned t = 1; t < s; t++) off += stage_fv_bytes(npad, ncols, t) + stage_inner_bytes(npad, ncols, t);
+    return off;
+}
+size_t runs_stage_scratch_bytes(size_t npad, size_t ncols) {
+    const unsigned top = run_top_level(npad);
+    size_t b = 64;
+    for (unsigned s = 1; s * RUN_STAGE_LEVELS < top; s++) b += stage_fv_bytes(npad, ncols, s) + stage_inner_bytes(npad, ncols, s);
+    return b;
+}
+
+LevelLists runs_lists(size_t npad, size_t ncols) {
+    LevelLists L{};
+    L.top = run_top_level(npad);
+    unsigned long long at = 0;
+    for (unsigned l = 0; l <= L.top; l++) {
+        const unsigned s = l == 0 ? 0 : (l - 1) / RUN_STAGE_LEVELS;
+        const size_t n_in = npad >> (s * RUN_STAGE_LEVELS);
+        const size_t seg = n_in < RUN_SEG ? n_in : RUN_SEG;
+        const size_t units = ncols * (n_in / seg);  // (column, segment) pairs of the stage
+        const size_t per_unit = seg >> (l - s * RUN_STAGE_LEVELS);
+        L.base[l] = at;
+        L.cap[l] = (unsigned)((units + RUN_SUBS - 1) / RUN_SUBS * per_unit);
+        at += (unsigned long long)L.cap[l] * RUN_SUBS;
+    }
+    L.entries = at;
+    return L;
+}
+LevelLists cons_lists(size_t npad) {
+    LevelLists L{};
+    L.top = run_top_level(npad);
+    unsigned long long at = 0;
+    for (unsigned l = 0; l <= L.top; l++) {
+        const size_t wgs = ((npad >> l) + TPB - 1) / TPB;
+        L.base[l] = at;
+        L.cap[l] = (unsigned)((wgs + RUN_SUBS - 1) / RUN_SUBS * TPB);
+        at += (unsigned long long)L.cap[l] * RUN_SUBS;
+    }
+    L.entries = at;
+    return L;
+}
+
+// ------------------------------------------------------------------ R: run-aware structure
+constexpr unsigned long long BITS_ODD = 0xAAAAAAAAAAAAAAAAull;
+// even bits of x -> its low 32 bits
+__device__ __forceinline__ unsigned long long compress_even64(unsigned long long x) {
+    x &= 0x5555555555555555ull;
+    x = (x | (x >> 1)) & 0x3333333333333333ull;
+    x = (x | (x >> 2)) & 0x0f0f0f0f0f0f0f0full;
+    x = (x | (x >> 4)) & 0x00ff00ff00ff00ffull;
+    x = (x | (x >> 8)) & 0x0000ffff0000ffffull;
+    x = (x | (x >> 16)) & 0x00000000ffffffffull;
+    return x;
+}
+
+// One workgroup = one segment of `seg` = 2^seg_log2 consecutive input nodes (leaves for stage 0, the nodes of level 6 s
+// otherwise) of one hinted column.  With x[i] the first value under input node i, c[i] = (x[i] != x[i-1]) and, per
+// relative level r (node j covers the inputs j 2^r .. (j+1) 2^r - 1):
+//     edge_r[j]  = c[j 2^r]                                   the node starts at a change
+//     inner_r[j] = some change strictly inside the node       (or an input node that is itself not uniform)
+//     need_r[j]  = inner_r[j] | inner_r[j-1] | edge_r[j]      not a copy of its left neighbour -> hashed
+// and the first node of the segment's range is always hashed (need = 1), so a copy's leader lies in the same range.  The
+// words of level r + 1 follow from those of level r by OR-ing bit pairs and compressing the even bits (one lane per
+// 64-bit word, two lanes' halves joined by a cross-lane read) -- a few hundred instructions of ONE wave for all levels.
+template <bool STAGE0>
+__global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax,
+                                                    size_t in_off /*bytes, stage >= 1*/, size_t out_off /*bytes, next stage or ~0*/) {
+    __shared__ uint32_t s_x[RUN_SEG];
+    __shared__ unsigned long long s_c[64], s_i0[64];
+    __shared__ unsigned long long s_need[RUN_STAGE_LEVELS + 1][64];
+    __shared__ unsigned s_off[RUN_STAGE_LEVELS + 1][64];
+    __shared__ unsigned long long s_base[RUN_STAGE_LEVELS + 1];
+    const unsigned y = blockIdx.y, segi = blockIdx.x, nseg = gridDim.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned seg = 1u << seg_log2, words = seg / 64;
+    const unsigned l_in = stage * RUN_STAGE_LEVELS;
+    const size_t n_in = b.npad >> l_in;
+    const size_t first = (size_t)segi * seg;
+    // 1. the segment's values
+    if (STAGE0) {
+        const uint32_t *v = b.vals + (size_t)b.rcols.c[y] * b.val_stride;
+        const bool vec = (((uintptr_t)v | (b.val_stride * 4)) & 15) == 0;
+        for (unsigned i = threadIdx.x * 4; i < seg; i += TPB * 4) {
+            const size_t k = first + i;
+            uint4 x;
+            if (vec && k + 3 < b.n_values) {
+                x = *reinterpret_cast<const uint4 *>(v + k);
+            } else {  // padding leaves hold 0 (merkle_tree.zig:302-306)
+                x.x = k < b.n_values ? v[k] : 0u;
+                x.y = k + 1 < b.n_values ? v[k + 1] : 0u;
+                x.z = k + 2 < b.n_values ? v[k + 2] : 0u;
+                x.w = k + 3 < b.n_values ? v[k + 3] : 0u;
+            }
+            *reinterpret_cast<uint4 *>(&s_x[i]) = x;
+        }
+    } else {
+        const uint32_t *fv = reinterpret_cast<const uint32_t *>(b.r_stage + in_off) + (size_t)y * n_in + first;
+        const unsigned long long *inner = reinterpret_cast<const unsigned long long *>(
+            b.r_stage + in_off + (size_t)b.rcols.n * n_in * 4) + ((size_t)y * n_in + first) / 64;
+        for (unsigned i = threadIdx.x; i < seg; i += TPB) s_x[i] = fv[i];
+        if (threadIdx.x < words) s_i0[threadIdx.x] = inner[threadIdx.x];
+    }
+    __syncthreads();
+    // 2. change bits, one ballot per 64 input nodes
+    for (unsigned q = wave; q < words; q += TPB / 64) {
+        const unsigned i = q * 64 + lane;
+        const bool c = i == 0 || s_x[i] != s_x[i - 1];
+        const unsigned long long m = __ballot(c);
+        if (lane == 0) s_c[q] = m;
+    }
+    __syncthreads();
+    // 3. all levels of the segment, in wave 0
+    if (wave == 0) {
+        unsigned long long E = lane < words ? s_c[lane] : 0, I = (!STAGE0 && lane < words) ? s_i0[lane] : 0;
+        unsigned w = words;
+        unsigned my_tot = 0;
+        for (unsigned r = 0; r <= rmax; r++) {
+            if (r) {
+                const unsigned long long t = I | (E & BITS_ODD);
+                const unsigned long long i32 = compress_even64(t | (t >> 1)), e32 = compress_even64(E);
+                const unsigned long long ilo = __shfl(i32, (2 * lane) & 63), ihi = __shfl(i32, (2 * lane + 1) & 63);
+                const unsigned long long elo = __shfl(e32, (2 * lane) & 63), ehi = __shfl(e32, (2 * lane + 1) & 63);
+                w >>= 1;
+                I = lane < w ? (ilo | (ihi << 32)) : 0;
+                E = lane < w ? (elo | (ehi << 32)) : 0;
+            }
+            if (!STAGE0 && r == 0) continue;  // the input level was emitted by the previous stage
+            unsigned long long carry = __shfl_up(I, 1) >> 63;
+            if (lane == 0) carry = 1;  // the first node of the segment's range is always hashed
+            const unsigned long long need = lane < w ? (I | (I << 1) | carry | E) : 0;
+            const unsigned cnt = (unsigned)__builtin_popcountll(need);
+            unsigned incl = cnt;
+            int last = need ? (int)(lane * 64 + 63 - __builtin_clzll(need)) : -1;  // last hashed node up to the end of this word
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) {
+                const unsigned a = __shfl_up(incl, off);
+                const int bb = __shfl_up(last, off);
+                if (lane >= (unsigned)off) { incl += a; last = last > bb ? last : bb; }
+            }
+            int prev = __shfl_up(last, 1);
+            if (lane == 0) prev = 0;
+            const unsigned tot = __shfl(incl, w - 1);
+            if (lane == r) my_tot = tot;
+            const unsigned l_abs = l_in + r;
+            if (lane < w) {
+                const size_t e = run_meta_base(b.npad, b.meta.ncols, l_abs) + ((size_t)y * (b.npad >> l_abs) + (first >> r)) / 64 + lane;
+                b.meta.bitmap[e] = need;
+                b.meta.prev[e] = (unsigned short)prev;
+                s_need[r][lane] = need;
+                s_off[r][lane] = incl - cnt;
+            }
+        }
+        // what the next stage reads: first value and "not uniform" bit of the 64 nodes of relative level 6
+        if (out_off != ~(size_t)0) {  // (then seg = 4096 and rmax = 6: I is one word)
+            const size_t n_out = n_in >> RUN_STAGE_LEVELS;
+            uint32_t *fv = reinterpret_cast<uint32_t *>(b.r_stage + out_off) + (size_t)y * n_out + (size_t)segi * 64;
+            unsigned long long *inner = reinterpret_cast<unsigned long long *>(b.r_stage + out_off + (size_t)b.rcols.n * n_out * 4) +
+                                        ((size_t)y * n_out) / 64 + segi;
+            fv[lane] = s_x[lane << RUN_STAGE_LEVELS];
+            if (lane == 0) *inner = I;
+        }
+        // one list reservation per level, each by a lane of its own (the sub-list counters sit in lines of their own)
+        if (lane <= rmax && (STAGE0 || lane != 0)) {
+            const unsigned l_abs = l_in + lane;
+            const unsigned sub = (y * nseg + segi) % RUN_SUBS;
+            s_base[lane] = b.r_lists.base[l_abs] + (unsigned long long)sub * b.r_lists.cap[l_abs] +
+                           atomicAdd(&b.r_ctr[run_ctr_index(l_abs, sub)], (unsigned long long)my_tot);
+        }
+    }
+    __syncthreads();
+    // 4. the list entries of every level
+    for (unsigned r = STAGE0 ? 0 : 1; r <= rmax; r++) {
+        const unsigned nodes = seg >> r;
+        const unsigned long long base = s_base[r];
+        const size_t node0 = first >> r;
+        for (unsigned j = threadIdx.x; j < nodes; j += TPB) {
+            const unsigned long long m = s_need[r][j >> 6];
+            if ((m >> (j & 63)) & 1)
+                b.r_list[base + s_off[r][j >> 6] + (unsigned)__builtin_popcountll(m & ((1ull << (j & 63)) - 1))] =
+                    ((uint32_t)y << RUN_NODE_BITS) | (uint32_t)(node0 + j);
+        }
+    }
+}
+
+void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
+    if (b.rcols.n == 0) return;
+    const unsigned top = b.r_lists.top;
+    unsigned nstages = 1;
+    while (nstages * RUN_STAGE_LEVELS < top) nstages++;
+    for (unsigned st = 0; st < nstages; st++) {
+        const size_t n_in = b.npad >> (st * RUN_STAGE_LEVELS);
+        const size_t seg = n_in < RUN_SEG ? n_in : RUN_SEG;
+        const unsigned rmax = top - st * RUN_STAGE_LEVELS < RUN_STAGE_LEVELS ? top - st * RUN_STAGE_LEVELS : RUN_STAGE_LEVELS;
+        const bool has_next = st + 1 < nstages;
+        const size_t in_off = st ? stage_off(b.npad, b.rcols.n, st) : 0;
+        const size_t out_off = has_next ? stage_off(b.npad, b.rcols.n, st + 1) : ~(size_t)0;
+        const dim3 grid((unsigned)(n_in / seg), b.rcols.n);
+        hipEvent_t e0 = kt && st == 0 ? kt->start : nullptr, e1 = kt && st + 1 == nstages ? kt->stop : nullptr;
+        if (st == 0) {
+            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, in_off, out_off);
+            else hipLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, in_off, out_off);
+        } else {
+            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, in_off, out_off);
+            else hipLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, in_off, out_off);
+        }
+    }
+}
+
+// ------------------------------------------------------------------ G: content-addressed structure
+// One open-addressing table of 2 npad slots serves every level.  A slot's word is generation << 52 | payload -- the
+// generation is the level's (b.g_gen + level), so entries of earlier levels and earlier builds read as free and the table
+// is never cleared -- payload = 52 bits of the leaf tuple's fingerprint at level 0 (verified against the representative's
+// tuple when it is read back) and the pair of the children's representatives above, which IS the identity of the hash input.
+// Whoever inserts a key first is the representative of the nodes with that key (idx[slot]).
+constexpr unsigned CONS_GEN_SHIFT = 52;
+__device__ __forceinline__ unsigned long long cons_mix(unsigned long long x) {  // splitmix64 finaliser
+    x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
+    x ^= x >> 27; x *= 0x94d049bb133111ebull;
+    return x ^ (x >> 31);
+}
+__device__ __forceinline__ unsigned long long cons_leaf_payload(const MerkleBuild &b, size_t k) {
+    unsigned long long h = 0x243f6a8885a308d3ull;
+    for (unsigned j = 0; j < b.gcols.n; j++)
+        h = cons_mix(h ^ (k < b.n_values ? b.vals[(size_t)b.gcols.c[j] * b.val_stride + k] : 0u));  // padding leaves hold 0
+    return h & ((1ull << CONS_GEN_SHIFT) - 1);
+}
+// Lanes of a wave that hold the same key elect the lowest of them: in a loop-dominated trace the 64 nodes of a wave share a
+// handful of keys, and one table access per distinct key instead of one per lane is what keeps a million nodes from
+// hammering four words.  Returns the elected lane (the lane itself when it is elected or does not take part).
+__device__ __forceinline__ unsigned wave_leader(unsigned long long key, bool valid, unsigned lane) {
+    unsigned long long pend = __ballot(valid);
+    unsigned mine = lane;
+    while (pend) {  // one round per distinct key of the wave (<= 64)
+        const unsigned ld = (unsigned)__builtin_ctzll(pend);
+        const unsigned long long kk = __shfl(key, ld);
+        const bool same = valid && key == kk;
+        if (same) mine = ld;
+        pend &= ~__ballot(same);
+    }
+    return mine;
+}
+__device__ __forceinline__ void cons_insert(unsigned long long *keys, uint32_t *idx, size_t mask, unsigned long long key,
+                                            unsigned g_cur, unsigned g_prev, uint32_t node) {
+    size_t slot = cons_mix(key) & mask;
+    for (size_t tries = 0; tries <= mask; tries++) {  // live keys fill at most 3/4 of the slots: a free or matching one is reached
+        unsigned long long cur = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
+        for (;;) {  // until this slot holds a live key
+            if (cur == key) return;
+            const unsigned g = (unsigned)(cur >> CONS_GEN_SHIFT);
+            if (g == g_cur || g == g_prev) break;  // somebody else's live key: next slot
+            const unsigned long long old = atomicCAS(&keys[slot], cur, key);
+            if (old == cur) {  // this thread inserted the key: its node is the representative
+                idx[slot] = node;
+                return;
+            }
+            cur = old;
+        }
+        slot = (slot + 1) & mask;
+    }
+}
+__device__ __forceinline__ uint32_t cons_lookup(const unsigned long long *keys, const uint32_t *idx, size_t mask, unsigned long long key) {
+    size_t slot = cons_mix(key) & mask;
+    for (size_t tries = 0; tries <= mask; tries++) {
+        if (keys[slot] == key) return idx[slot];
+        slot = (slot + 1) & mask;
+    }
+    return 0xffffffffu;  // cannot happen: the key was inserted by the previous launch
+}
+
+__global__ __launch_bounds__(TPB) void k_cons_leaf_insert(MerkleBuild b) {
+    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63;
+    const bool valid = k < b.npad;
+    const unsigned long long key = ((unsigned long long)b.g_gen << CONS_GEN_SHIFT) | (valid ? cons_leaf_payload(b, k) : 0);
+    const unsigned ld = wave_leader(key, valid, lane);
+    if (valid && ld == lane) cons_insert(b.g_keys, b.g_idx, 2 * b.npad - 1, key, b.g_gen, b.g_gen, (uint32_t)k);
+}
+
+// Resolves level lr (every node learns its representative; representatives go onto the level's list) and, if do_insert,
+// inserts the keys of level lr + 1: node c / 2's key is the pair of the representatives of c and c + 1, which sit in
+// neighbouring lanes.
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
+    __shared__ unsigned s_cnt[TPB / 64];
+    __shared__ unsigned long long s_base;
+    if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
+    const size_t n = b.npad >> lr, c = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool valid = c < n;
+    const size_t mask = 2 * b.npad - 1;
+    const unsigned g_r = b.g_gen + lr;
+    const size_t off = 2 * b.npad - 2 * n;                            // first node of level lr in g_rep
+    const size_t off_in = LEAF ? 0 : 2 * b.npad - 2 * (b.npad >> (lr - 1));  // ... of level lr - 1
+    unsigned long long key = (unsigned long long)g_r << CONS_GEN_SHIFT;
+    if (valid) {
+        if (LEAF) key |= cons_leaf_payload(b, c);
+        else {
+            const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + off_in + 2 * c);
+            key |= ((unsigned long long)p.x << RUN_NODE_BITS) | p.y;
+        }
+    }
+    const unsigned ld = wave_leader(key, valid, lane);
+    uint32_t r = 0xffffffffu;
+    if (valid && ld == lane) r = cons_lookup(b.g_keys, b.g_idx, mask, key);
+    r = __shfl(r, ld);
+    if (valid) {
+        if (r == 0xffffffffu) r = (uint32_t)c;
+        if (LEAF && r != c) {  // equal fingerprints are not yet equal tuples: verify, else this leaf stands for itself
+            for (unsigned j = 0; j < b.gcols.n; j++) {
+                const uint32_t *v = b.vals + (size_t)b.gcols.c[j] * b.val_stride;
+                if ((c < b.n_values ? v[c] : 0u) != (r < b.n_values ? v[r] : 0u)) { r = (uint32_t)c; break; }
+            }
+        }
+        b.g_rep[off + c] = r;
+    }
+    const bool is_rep = valid && r == c;
+    // representatives go onto the level's list (one reservation per workgroup, spread over the sub-list counters)
+    const unsigned long long m = __ballot(is_rep);
+    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned tot = 0;
+        for (int w = 0; w < TPB / 64; w++) { const unsigned t = s_cnt[w]; s_cnt[w] = tot; tot += t; }
+        const unsigned sub = blockIdx.x % RUN_SUBS;
+        s_base = b.g_lists.base[lr] + (unsigned long long)sub * b.g_lists.cap[lr] +
+                 (tot ? atomicAdd(&b.g_ctr[run_ctr_index(lr, sub)], (unsigned long long)tot) : 0ull);
+    }
+    __syncthreads();
+    if (is_rep) b.g_list[s_base + s_cnt[wave] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)c;
+    if (do_insert) {
+        const uint32_t r_hi = __shfl_down(r, 1);
+        const bool own = valid && !(c & 1);
+        const unsigned long long k2 = ((unsigned long long)(g_r + 1) << CONS_GEN_SHIFT) | ((unsigned long long)r << RUN_NODE_BITS) | r_hi;
+        const unsigned ld2 = wave_leader(k2, own, lane);
+        if (own && ld2 == lane) cons_insert(b.g_keys, b.g_idx, mask, k2, g_r + 1, g_r, (uint32_t)(c >> 1));
+    }
+}
+
+// keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing
+__global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
+    unsigned long long c = threadIdx.x < RUN_SUBS ? b.g_ctr[run_ctr_index(0, threadIdx.x)] : 0;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
+    if (threadIdx.x == 0) {
+        b.g_ctr[9] = c;
+        b.g_ctr[8] = c > b.npad / 4 ? 1 : 0;
+    }
+}
+
+void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
+    if (b.gcols.n == 0) return;
+    const unsigned top = b.g_lists.top;
+    const dim3 g0((unsigned)((b.npad + TPB - 1) / TPB));
+    if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(TPB), 0, s, kt->start, nullptr, 0, b);
+    else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(TPB), 0, s, b);
+    hipLaunchKernelGGL(k_cons_pass<true>, g0, dim3(TPB), 0, s, b, 0u, top >= 1 ? 1 : 0);
+    hipLaunchKernelGGL(k_cons_decide, dim3(1), dim3(64), 0, s, b);
+    for (unsigned lr = 1; lr <= top; lr++) {
+        const dim3 g((unsigned)(((b.npad >> lr) + TPB - 1) / TPB));
+        const int ins = lr < top ? 1 : 0;
+        if (kt && lr == top) hipExtLaunchKernelGGL(k_cons_pass<false>, g, dim3(TPB), 0, s, nullptr, kt->stop, 0, b, lr, ins);
+        else hipLaunchKernelGGL(k_cons_pass<false>, g, dim3(TPB), 0, s, b, lr, ins);
+    }
+}
+
+// ------------------------------------------------------------------ hashing a level from its lists
+// Level L of the R and G columns in ONE launch: [the R list][the G list x the group's columns][when the group was dropped:
+// every node of the columns in gdense].  A fixed grid strides over that index space, one hash per thread and step, every
+// lane busy whatever mix of constant and busy columns produced the lists.  Children are read where their digests are:
+// an R child through its leader, a G child through its representative.
+template <bool LEAF>
+__global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
+    __shared__ unsigned long long s_r[RUN_SUBS + 1], s_g[RUN_SUBS + 1];  // exclusive prefixes of the sub-list lengths
+    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
+    if (wave < 2) {
+        const bool use = wave == 0 ? b.rcols.n != 0 : (b.gcols.n != 0 && !dropped);
+        const unsigned long long *ctr = wave == 0 ? b.r_ctr : b.g_ctr;
+        const unsigned long long c = use && lane < RUN_SUBS ? ctr[run_ctr_index(L, lane)] : 0;
+        unsigned long long incl = c;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const unsigned long long a = __shfl_up(incl, off);
+            if (lane >= (unsigned)off) incl += a;
+        }
+        unsigned long long *dst = wave == 0 ? s_r : s_g;
+        if (lane < RUN_SUBS) dst[lane] = incl - c;
+        if (lane == RUN_SUBS - 1) dst[RUN_SUBS] = incl;
+    }
+    __syncthreads();
+    const size_t n_L = b.npad >> L;
+    const size_t cR = s_r[RUN_SUBS], cG = s_g[RUN_SUBS] * b.gcols.n, cD = dropped ? (size_t)gdense.n * n_L : 0;
+    if (blockIdx.x == 0 && threadIdx.x == 0) {  // nodes hashed by the whole build
+        if (cR) atomicAdd(&b.r_ctr[0], (unsigned long long)cR);
+        if (cG) atomicAdd(&b.g_ctr[0], (unsigned long long)cG);
+    }
+    const size_t total = cR + cG + cD;
+    const size_t out_off = 2 * b.npad - 2 * n_L;
+    const size_t in_off = LEAF ? 0 : 2 * b.npad - 2 * (b.npad >> (L - 1));
+#pragma unroll 1
+    for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * TPB) {
+        size_t col, k, c0, c1;
+        if (e < cR) {
+            unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
+#pragma unroll
+            for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
+                if (s_r[sub + step] <= e) sub += step;
+            const uint32_t ent = b.r_list[b.r_lists.base[L] + (size_t)sub * b.r_lists.cap[L] + (e - s_r[sub])];
+            const unsigned y = ent >> RUN_NODE_BITS;
+            col = b.rcols.c[y];
+            k = ent & ((1u << RUN_NODE_BITS) - 1);
+            if (!LEAF) {
+                c0 = run_leader(b.meta, b.npad, y, L - 1, 2 * k);
+                c1 = run_leader(b.meta, b.npad, y, L - 1, 2 * k + 1);
+            }
+        } else if (e < cR + cG) {
+            const size_t t = e - cR, ei = t / b.gcols.n;
+            col = b.gcols.c[t % b.gcols.n];
+            unsigned sub = 0;
+#pragma unroll
+            for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
+                if (s_g[sub + step] <= ei) sub += step;
+            k = b.g_list[b.g_lists.base[L] + (size_t)sub * b.g_lists.cap[L] + (ei - s_g[sub])];
+            if (!LEAF) {
+                const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + in_off + 2 * k);
+                c0 = p.x;
+                c1 = p.y;
+            }
+        } else {
+            const size_t t = e - cR - cG;
+            col = gdense.c[t / n_L];
+            k = t & (n_L - 1);
+            c0 = 2 * k;
+            c1 = 2 * k + 1;
+        }
+        uint8_t *tr = b.tree + col * b.tree_stride_nodes * 32;
+        Digest d;
+        if (LEAF) d = sha3_leaf((uint64_t)(k < b.n_values ? b.vals[col * b.val_stride + k] : 0u));
+        else d = sha3_node(load_digest(tr, in_off + c0), load_digest(tr, in_off + c1));
+        store_digest_plain(tr, out_off + k, d);
+    }
+}
+
+void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt) {
+    if (b.rcols.n == 0 && b.gcols.n == 0) return;
+    // when the group was dropped its columns are hashed densely here -- except the small-domain members on the levels 0 and 1,
+    // which come from the tables (launch_keccak_small_l01, guarded by the same flag)
+    ColMap gd{};
+    for (unsigned j = 0; j < b.gcols.n; j++) {
+        bool sd = false;
+        for (unsigned i = 0; i < b.gcols_sd.n; i++) sd |= b.gcols_sd.c[i] == b.gcols.c[j];
+        if (L >= 2 || !sd) gd.c[gd.n++] = b.gcols.c[j];
+    }
+    const size_t n_L = b.npad >> L;
+    size_t wgs = ((size_t)(b.rcols.n + b.gcols.n) * n_L + TPB - 1) / TPB;  // an upper bound of the work; the lists say how much
+    if (wgs > 2048) wgs = 2048;                                            // there is (8 workgroups per CU stride over it)
+    if (L == 0) ZK_LAUNCH(kt, k_level_hash<true>, dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+    else ZK_LAUNCH(kt, k_level_hash<false>, dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+}
+
+// ------------------------------------------------------------------ the top of the trees
+// From a level of at most 2 TPB nodes up to the root in ONE launch, one workgroup per column; levels hand over through
+// global memory + a workgroup barrier on the same CU.  Every hash here is a link in a dependent chain run by a few lone
+// waves, so the permutation is the variant without re-arm pauses.
+__global__ __launch_bounds__(TPB) void k_merkle_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
+                                                    unsigned first_level, unsigned height, RunMeta meta, int have_meta) {
+    const size_t col = blockIdx.y;
+    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    for (unsigned l = first_level; l < height; l++) {
+        const size_t n_out = npad >> (l + 1);
+        const size_t in_off = 2 * npad - 2 * (npad >> l), out_off = 2 * npad - 2 * (npad >> (l + 1));
+        if (threadIdx.x < n_out) {
+            size_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
+            if (have_meta && l == first_level) {
+                c0 = resolve_node(meta, npad, col, l, c0);
+                c1 = resolve_node(meta, npad, col, l, c1);
+            }
+            store_digest_plain(t, out_off + threadIdx.x, sha3_node<false>(load_digest(t, in_off + c0), load_digest(t, in_off + c1)));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+void launch_merkle_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
+                       size_t ncols, const RunMeta *meta, hipStream_t s, const KTime *kt) {
+    RunMeta m{};
+    if (meta) m = *meta;
+    ZK_LAUNCH(kt, k_merkle_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, first_level, height, m,
+              meta ? 1 : 0);
+}
+
+// ------------------------------------------------------------------ materialising the virtual nodes
+__global__ __launch_bounds__(TPB) void k_runs_fill_level(MerkleBuild b, unsigned L) {
+    const size_t n = b.npad >> L, k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= n) return;
+    const size_t ld = run_leader(b.meta, b.npad, blockIdx.y, L, k);
+    if (ld == k) return;
+    uint8_t *tr = b.tree + (size_t)b.rcols.c[blockIdx.y] * b.tree_stride_nodes * 32;
+    const size_t off = 2 * b.npad - 2 * n;
+    store_digest(tr, off + k, load_digest(tr, off + ld));
+}
+__global__ __launch_bounds__(TPB) void k_cons_fill_level(MerkleBuild b, unsigned L) {
+    if (b.g_ctr[8]) return;
+    const size_t n = b.npad >> L, k = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (k >= n) return;
+    const size_t off = 2 * b.npad - 2 * n;
+    const uint32_t r = b.g_rep[off + k];
+    if (r == k) return;
+    uint8_t *tr = b.tree + (size_t)b.gcols.c[blockIdx.y] * b.tree_stride_nodes * 32;
+    store_digest(tr, off + k, load_digest(tr, off + r));
+}
+void launch_fill_virtual(const MerkleBuild &b, hipStream_t s) {
+    for (unsigned L = 0; b.rcols.n && L <= b.r_lists.top; L++)
+        hipLaunchKernelGGL(k_runs_fill_level, dim3((unsigned)(((b.npad >> L) + TPB - 1) / TPB), b.rcols.n), dim3(TPB), 0, s, b, L);
+    for (unsigned L = 0; b.gcols.n && L <= b.g_lists.top; L++)
+        hipLaunchKernelGGL(k_cons_fill_level, dim3((unsigned)(((b.npad >> L) + TPB - 1) / TPB), b.gcols.n), dim3(TPB), 0, s, b, L);
+}
+
+}  // namespace zk
