@@ -26,7 +26,11 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--trace", default="add_xor", help="add_xor | round_robin | mixed (RV64IM mix with loads / stores, BASELINE config 4's loop)")
 ap.add_argument("--hint", default="cons", help="run-aware hint: regs | regs+mem | all | cons (regs+mem and the ten "
                 "instruction-determined columns as a content-addressed group)")
+ap.add_argument("--phases", action="store_true", help="also print the host wall time of each call of the commit job")
+ap.add_argument("--blocking-sync", action="store_true", help="waiting host threads sleep instead of spinning")
 args = ap.parse_args()
+if args.blocking_sync:
+    zigz_amd._ffi.lib.zigz_device_set_blocking_sync(0, 1)
 nv = 20
 N = 1 << nv
 REGS = 0x7fffffff << 2
@@ -57,10 +61,16 @@ class Lane:
             self.ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
 
     def once(self):
+        t0 = time.perf_counter()
         job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)
+        t1 = time.perf_counter()
         job.roots()
+        t2 = time.perf_counter()
         job.open_all(self.points)
+        t3 = time.perf_counter()
         job.end()
+        t4 = time.perf_counter()
+        self.t = [a + b for a, b in zip(getattr(self, "t", [0, 0, 0, 0]), (t1 - t0, t2 - t1, t3 - t2, t4 - t3))]
 
 
 lanes = [Lane(k) for k in range(args.lanes)]
@@ -79,5 +89,8 @@ th = [threading.Thread(target=loop, args=(l,)) for l in lanes]
 [t.join() for t in th]
 dt = time.perf_counter() - t0
 n = args.lanes * args.iters
+if args.phases:
+    tot = [sum(l.t[i] for l in lanes) / (args.lanes * (args.iters + 1)) * 1e3 for i in range(4)]
+    print("host wall per proof and lane: begin %.3f  roots %.3f  open_all %.3f  end %.3f ms" % tuple(tot))
 print("%s (hint %s): %d lanes: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
       (args.trace, args.hint, args.lanes, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Per-kernel static instruction mix of the gfx950 code of zigz_amd/csrc/kernels.hip.
+"""Per-kernel static instruction mix of the gfx950 code of zigz_amd/csrc/kernels.hip and merkle_levels.hip.
 
     python tools/isa_counts.py [--write]      # --write refreshes profiles/isa_counts.json
 
@@ -21,15 +21,21 @@ CSRC = os.path.join(ROOT, "zigz_amd", "csrc")
 OUT = os.path.join(ROOT, "profiles", "isa_counts.json")
 
 
+SOURCES = ("kernels.hip", "merkle_levels.hip")
+
+
 def assembly(extra=()):
     hipcc = "/opt/rocm/bin/hipcc"
+    out = []
     with tempfile.TemporaryDirectory() as d:
-        s = os.path.join(d, "kernels.s")
-        subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}",
-                               "--cuda-device-only", "-S", "-o", s, os.path.join(CSRC, "kernels.hip"), *extra,
-                               *os.environ.get("ZIGZ_EXTRA_HIPCC_FLAGS", "").split()],
-                              stderr=subprocess.DEVNULL)
-        return open(s).read()
+        for src in SOURCES:
+            s = os.path.join(d, src + ".s")
+            subprocess.check_call([hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", f"-I{ROOT}/include", f"-I{CSRC}",
+                                   "--cuda-device-only", "-S", "-o", s, os.path.join(CSRC, src), *extra,
+                                   *os.environ.get("ZIGZ_EXTRA_HIPCC_FLAGS", "").split()],
+                                  stderr=subprocess.DEVNULL)
+            out.append(open(s).read())
+    return "\n".join(out)
 
 
 def demangle(names):
@@ -106,8 +112,9 @@ def keccak_per_hash(counts):
 def main():
     counts = count(assembly())
     sel = {k: v for k, v in counts.items() if "keccak" in k or "bind" in k or "sums" in k or "radix" in k or "witness" in k
-           or "lasso" in k}
-    doc = {"source": "zigz_amd/csrc/kernels.hip, hipcc --offload-arch=gfx950 -O3 (tools/isa_counts.py)", "kernels": sel}
+           or "lasso" in k or "k_level_hash" in k or "k_merkle_top" in k or "k_runs_" in k or "k_cons_" in k}
+    doc = {"source": "zigz_amd/csrc/kernels.hip + merkle_levels.hip, hipcc --offload-arch=gfx950 -O3 (tools/isa_counts.py)",
+           "kernels": sel}
     print(json.dumps(doc, indent=1, sort_keys=True))
     if "--write" in sys.argv:
         with open(OUT, "w") as f:

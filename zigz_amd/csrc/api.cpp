@@ -1500,23 +1500,15 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         // roots -> contiguous device buffer -> pinned staging (async), then the "built" event
         void *d_roots;
         CHK(ws_get(ctx, WS_MISC, ncols * 32 + nv * ncols * 4 + 128, &d_roots));
-        launch_gather_nodes(job->d_tree, tree_nodes(job->N), tree_level_offset(job->N, (unsigned)nv), (uint8_t *)d_roots,
-                            ncols, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32, hipMemcpyDeviceToHost, ctx->stream));
-        // the diagnostic counters of the build ride along (pinned words after the roots), no blocking copy later:
+        // the diagnostic counters of the build ride along behind the roots (one kernel gathers both, one copy brings them):
         // [0] nodes hashed on the run-aware levels, [1] / [2] waves that left the small-domain tables (hinted columns / members
         // of a dropped group), [3] digests computed on the content-addressed levels, [4] group dropped?, [5] its distinct leaves
-        unsigned long long *h_cnt = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
-        for (int i = 0; i < 6; i++) h_cnt[i] = 0;
-        if (ctx->stats.run_aware_columns)
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[0], ctx->d_run_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->stats.small_domain_columns || ctx->build_cons_sd)
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[1], ctx->d_sd_fallbacks, 16, hipMemcpyDeviceToHost, ctx->stream));
-        if (ctx->build_cons_hinted) {
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[3], ctx->d_cons_count, 8, hipMemcpyDeviceToHost, ctx->stream));
-            HIPCHK(ctx, hipMemcpyAsync(&h_cnt[4], ctx->d_cons_count + 8, 16, hipMemcpyDeviceToHost, ctx->stream));
-        }
+        launch_job_summary(job->d_tree, tree_nodes(job->N), tree_level_offset(job->N, (unsigned)nv), (uint8_t *)d_roots, ncols,
+                           ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
+                           (ctx->stats.small_domain_columns || ctx->build_cons_sd) ? ctx->d_sd_fallbacks : nullptr,
+                           ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32 + 48, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
         return ZIGZ_OK;
     };
@@ -1570,7 +1562,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
     HIPCHK(ctx, hipEventSynchronize(job->built));
     memcpy(roots, ctx->h_roots, job->ncols * 32);
-    const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32);
+    const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + job->ncols * 32);
     // the run-aware levels hashed h_cnt[0] of their run_aware_dense_nodes nodes
     const uint64_t N = job->N;
     ctx->stats.run_aware_hashed = ctx->stats.run_aware_columns ? h_cnt[0] : 0;

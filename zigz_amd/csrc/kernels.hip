@@ -874,6 +874,33 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
 }
+// roots of a commit job + the build's diagnostic counters behind them (6 u64; a null pointer reads as 0): ONE buffer, one copy
+__global__ void k_job_summary(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t node, uint8_t *__restrict__ out,
+                              size_t ncols, const unsigned long long *r_ctr, const unsigned long long *sd_ctr,
+                              const unsigned long long *g_ctr) {
+    const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < ncols) {
+        const Digest d = canonical_digest(load_digest(tree + c * tree_stride_nodes * 32, node));  // tree form -> SHA3 bytes
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + c * 32);
+        q[0] = make_ulonglong2(d.w[0], d.w[1]);
+        q[1] = make_ulonglong2(d.w[2], d.w[3]);
+    }
+    if (c == 0) {
+        unsigned long long *cnt = reinterpret_cast<unsigned long long *>(out + ncols * 32);
+        cnt[0] = r_ctr ? r_ctr[0] : 0;
+        cnt[1] = sd_ctr ? sd_ctr[0] : 0;
+        cnt[2] = sd_ctr ? sd_ctr[1] : 0;
+        cnt[3] = g_ctr ? g_ctr[0] : 0;
+        cnt[4] = g_ctr ? g_ctr[8] : 0;
+        cnt[5] = g_ctr ? g_ctr[9] : 0;
+    }
+}
+void launch_job_summary(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
+                        const unsigned long long *d_r_ctr, const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr,
+                        hipStream_t s) {
+    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, d_tree, tree_stride_nodes, node, d_out,
+                       ncols, d_r_ctr, d_sd_ctr, d_g_ctr);
+}
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s) {
     hipLaunchKernelGGL(k_gather_nodes, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, d_tree, tree_stride_nodes, node,

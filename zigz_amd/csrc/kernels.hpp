@@ -245,6 +245,11 @@ void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, 
 // copies node `node` of every column's tree into d_out[c][32]
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s);
+// the roots (node `node` of every column, canonical bytes) and behind them six u64 counters of the build -- [0] d_r_ctr[0],
+// [1] / [2] d_sd_ctr[0] / [1], [3] d_g_ctr[0], [4] d_g_ctr[8], [5] d_g_ctr[9]; null pointers read as 0 -- in ONE buffer
+void launch_job_summary(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
+                        const unsigned long long *d_r_ctr, const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr,
+                        hipStream_t s);
 // gather element 0 of each column of a strided table
 void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s);
 // K9: Lasso fingerprints (src/lookups/lasso_prover.zig:208-239): rows x width canonical u32 -> u32

@@ -16,6 +16,8 @@
 
 namespace zk {
 
+constexpr int CONS_TPB = 1024;  // threads per workgroup of the table passes (16 waves share one LDS key set)
+
 // ------------------------------------------------------------------ layout helpers (host)
 static unsigned log2u(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
 
@@ -59,9 +61,9 @@ LevelLists cons_lists(size_t npad) {
     L.top = run_top_level(npad);
     unsigned long long at = 0;
     for (unsigned l = 0; l <= L.top; l++) {
-        const size_t wgs = ((npad >> l) + TPB - 1) / TPB;
+        const size_t wgs = ((npad >> l) + CONS_TPB - 1) / CONS_TPB;
         L.base[l] = at;
-        L.cap[l] = (unsigned)((wgs + RUN_SUBS - 1) / RUN_SUBS * TPB);
+        L.cap[l] = (unsigned)((wgs + RUN_SUBS - 1) / RUN_SUBS * CONS_TPB);
         at += (unsigned long long)L.cap[l] * RUN_SUBS;
     }
     L.entries = at;
@@ -81,131 +83,166 @@ __device__ __forceinline__ unsigned long long compress_even64(unsigned long long
     return x;
 }
 
-// One workgroup = one segment of `seg` = 2^seg_log2 consecutive input nodes (leaves for stage 0, the nodes of level 6 s
-// otherwise) of one hinted column.  With x[i] the first value under input node i, c[i] = (x[i] != x[i-1]) and, per
-// relative level r (node j covers the inputs j 2^r .. (j+1) 2^r - 1):
+// wave-wide inclusive scans on the DPP network (row shifts within the four rows of 16 lanes, then the two row broadcasts):
+// six VALU instructions each instead of six LDS-crossbar round trips -- the scans are the serial part of a segment
+template <int CTRL, int ROW_MASK, int BANK_MASK>
+__device__ __forceinline__ int dpp_i32(int old, int v) { return __builtin_amdgcn_update_dpp(old, v, CTRL, ROW_MASK, BANK_MASK, false); }
+__device__ __forceinline__ unsigned wave_scan_add(unsigned v) {
+    int s = (int)v;
+    s += dpp_i32<0x111, 0xf, 0xf>(0, s);  // row_shr:1
+    s += dpp_i32<0x112, 0xf, 0xf>(0, s);  // row_shr:2
+    s += dpp_i32<0x114, 0xf, 0xf>(0, s);  // row_shr:4
+    s += dpp_i32<0x118, 0xf, 0xf>(0, s);  // row_shr:8
+    s += dpp_i32<0x142, 0xa, 0xf>(0, s);  // row_bcast:15 into rows 1 and 3
+    s += dpp_i32<0x143, 0xc, 0xf>(0, s);  // row_bcast:31 into rows 2 and 3
+    return (unsigned)s;
+}
+__device__ __forceinline__ int wave_scan_max(int v) {  // values >= -1
+    int s = v, t;
+    t = dpp_i32<0x111, 0xf, 0xf>(-1, s); s = s > t ? s : t;
+    t = dpp_i32<0x112, 0xf, 0xf>(-1, s); s = s > t ? s : t;
+    t = dpp_i32<0x114, 0xf, 0xf>(-1, s); s = s > t ? s : t;
+    t = dpp_i32<0x118, 0xf, 0xf>(-1, s); s = s > t ? s : t;
+    t = dpp_i32<0x142, 0xa, 0xf>(-1, s); s = s > t ? s : t;
+    t = dpp_i32<0x143, 0xc, 0xf>(-1, s); s = s > t ? s : t;
+    return s;
+}
+
+// One WAVE = one segment of `seg` = 2^seg_log2 consecutive input nodes (leaves for stage 0, the nodes of level 6 s otherwise)
+// of one hinted column; a workgroup is four neighbouring segments that share nothing (no workgroup barrier anywhere).  With
+// x[i] the first value under input node i, c[i] = (x[i] != x[i-1]) and, per relative level r (node j covers the inputs
+// j 2^r .. (j+1) 2^r - 1):
 //     edge_r[j]  = c[j 2^r]                                   the node starts at a change
 //     inner_r[j] = some change strictly inside the node       (or an input node that is itself not uniform)
 //     need_r[j]  = inner_r[j] | inner_r[j-1] | edge_r[j]      not a copy of its left neighbour -> hashed
-// and the first node of the segment's range is always hashed (need = 1), so a copy's leader lies in the same range.  The
-// words of level r + 1 follow from those of level r by OR-ing bit pairs and compressing the even bits (one lane per
-// 64-bit word, two lanes' halves joined by a cross-lane read) -- a few hundred instructions of ONE wave for all levels.
+// and the first node of the segment's range is always hashed (need = 1), so a copy's leader lies in the same range.  The lane
+// that owns input chunk q (64 nodes) gets its change word from ONE ballot over a coalesced row of the column; the words of
+// level r + 1 follow from those of level r by OR-ing bit pairs and compressing the even bits (one lane per 64-bit word, two
+// lanes' halves joined by a cross-lane read) -- a few hundred instructions for all levels, then the list entries.
+constexpr int RUNS_WAVES = TPB / 64;
 template <bool STAGE0>
-__global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax,
+__global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax, unsigned nseg,
                                                     size_t in_off /*bytes, stage >= 1*/, size_t out_off /*bytes, next stage or ~0*/) {
-    __shared__ uint32_t s_x[RUN_SEG];
-    __shared__ unsigned long long s_c[64], s_i0[64];
-    __shared__ unsigned long long s_need[RUN_STAGE_LEVELS + 1][64];
-    __shared__ unsigned s_off[RUN_STAGE_LEVELS + 1][64];
-    __shared__ unsigned long long s_base[RUN_STAGE_LEVELS + 1];
-    const unsigned y = blockIdx.y, segi = blockIdx.x, nseg = gridDim.x;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned y = blockIdx.y, segi = blockIdx.x * RUNS_WAVES + wave;
+    if (segi >= nseg) return;  // (wave-uniform; the waves of a workgroup never meet)
     const unsigned seg = 1u << seg_log2, words = seg / 64;
     const unsigned l_in = stage * RUN_STAGE_LEVELS;
     const size_t n_in = b.npad >> l_in;
     const size_t first = (size_t)segi * seg;
-    // 1. the segment's values
-    if (STAGE0) {
-        const uint32_t *v = b.vals + (size_t)b.rcols.c[y] * b.val_stride;
-        const bool vec = (((uintptr_t)v | (b.val_stride * 4)) & 15) == 0;
-        for (unsigned i = threadIdx.x * 4; i < seg; i += TPB * 4) {
-            const size_t k = first + i;
-            uint4 x;
-            if (vec && k + 3 < b.n_values) {
-                x = *reinterpret_cast<const uint4 *>(v + k);
-            } else {  // padding leaves hold 0 (merkle_tree.zig:302-306)
-                x.x = k < b.n_values ? v[k] : 0u;
-                x.y = k + 1 < b.n_values ? v[k + 1] : 0u;
-                x.z = k + 2 < b.n_values ? v[k + 2] : 0u;
-                x.w = k + 3 < b.n_values ? v[k + 3] : 0u;
-            }
-            *reinterpret_cast<uint4 *>(&s_x[i]) = x;
+    // 1. change words: lane q ends up with the word of input chunk q (E) and, above stage 0, its "not uniform" word (I)
+    unsigned long long E = 0, I = 0;
+    uint32_t fv_mine = 0;  // lane q: the first value of chunk q (what the next stage reads for relative level 6)
+    {
+        const uint32_t *src;
+        size_t limit;  // inputs at or beyond it read as 0 (padding leaves, merkle_tree.zig:302-306)
+        if (STAGE0) {
+            src = b.vals + (size_t)b.rcols.c[y] * b.val_stride + first;
+            limit = b.n_values > first ? b.n_values - first : 0;
+        } else {
+            src = reinterpret_cast<const uint32_t *>(b.r_stage + in_off) + (size_t)y * n_in + first;
+            limit = seg;
+            const unsigned long long *inner = reinterpret_cast<const unsigned long long *>(
+                b.r_stage + in_off + (size_t)b.rcols.n * n_in * 4) + ((size_t)y * n_in + first) / 64;
+            if (lane < words) I = inner[lane];
         }
-    } else {
-        const uint32_t *fv = reinterpret_cast<const uint32_t *>(b.r_stage + in_off) + (size_t)y * n_in + first;
-        const unsigned long long *inner = reinterpret_cast<const unsigned long long *>(
-            b.r_stage + in_off + (size_t)b.rcols.n * n_in * 4) + ((size_t)y * n_in + first) / 64;
-        for (unsigned i = threadIdx.x; i < seg; i += TPB) s_x[i] = fv[i];
-        if (threadIdx.x < words) s_i0[threadIdx.x] = inner[threadIdx.x];
-    }
-    __syncthreads();
-    // 2. change bits, one ballot per 64 input nodes
-    for (unsigned q = wave; q < words; q += TPB / 64) {
-        const unsigned i = q * 64 + lane;
-        const bool c = i == 0 || s_x[i] != s_x[i - 1];
-        const unsigned long long m = __ballot(c);
-        if (lane == 0) s_c[q] = m;
-    }
-    __syncthreads();
-    // 3. all levels of the segment, in wave 0
-    if (wave == 0) {
-        unsigned long long E = lane < words ? s_c[lane] : 0, I = (!STAGE0 && lane < words) ? s_i0[lane] : 0;
-        unsigned w = words;
-        unsigned my_tot = 0;
-        for (unsigned r = 0; r <= rmax; r++) {
-            if (r) {
-                const unsigned long long t = I | (E & BITS_ODD);
-                const unsigned long long i32 = compress_even64(t | (t >> 1)), e32 = compress_even64(E);
-                const unsigned long long ilo = __shfl(i32, (2 * lane) & 63), ihi = __shfl(i32, (2 * lane + 1) & 63);
-                const unsigned long long elo = __shfl(e32, (2 * lane) & 63), ehi = __shfl(e32, (2 * lane + 1) & 63);
-                w >>= 1;
-                I = lane < w ? (ilo | (ihi << 32)) : 0;
-                E = lane < w ? (elo | (ehi << 32)) : 0;
-            }
-            if (!STAGE0 && r == 0) continue;  // the input level was emitted by the previous stage
-            unsigned long long carry = __shfl_up(I, 1) >> 63;
-            if (lane == 0) carry = 1;  // the first node of the segment's range is always hashed
-            const unsigned long long need = lane < w ? (I | (I << 1) | carry | E) : 0;
-            const unsigned cnt = (unsigned)__builtin_popcountll(need);
-            unsigned incl = cnt;
-            int last = need ? (int)(lane * 64 + 63 - __builtin_clzll(need)) : -1;  // last hashed node up to the end of this word
+        uint32_t prev_last = 0;  // x[64 q - 1] (wave-uniform)
+        for (unsigned q0 = 0; q0 < words; q0 += 32) {
+            uint32_t x[32];
 #pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const unsigned a = __shfl_up(incl, off);
-                const int bb = __shfl_up(last, off);
-                if (lane >= (unsigned)off) { incl += a; last = last > bb ? last : bb; }
+            for (unsigned j = 0; j < 32; j++) {  // 32 coalesced rows (8 KiB per wave) in flight
+                const unsigned i = (q0 + j) * 64 + lane;
+                x[j] = (q0 + j < words && i < limit) ? src[i] : 0u;
             }
-            int prev = __shfl_up(last, 1);
-            if (lane == 0) prev = 0;
-            const unsigned tot = __shfl(incl, w - 1);
-            if (lane == r) my_tot = tot;
-            const unsigned l_abs = l_in + r;
-            if (lane < w) {
-                const size_t e = run_meta_base(b.npad, b.meta.ncols, l_abs) + ((size_t)y * (b.npad >> l_abs) + (first >> r)) / 64 + lane;
-                b.meta.bitmap[e] = need;
-                b.meta.prev[e] = (unsigned short)prev;
-                s_need[r][lane] = need;
-                s_off[r][lane] = incl - cnt;
+#pragma unroll
+            for (unsigned j = 0; j < 32; j++) {
+                const unsigned q = q0 + j;
+                uint32_t left = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x[j], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+                if (lane == 0) left = prev_last;
+                const bool c = (q == 0 && lane == 0) || x[j] != left;
+                const unsigned long long m = __ballot(c);
+                const uint32_t x_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)x[j]);
+                if (q < words) {
+                    if (lane == q) { E = m; fv_mine = x_first; }
+                    prev_last = (uint32_t)__builtin_amdgcn_readlane((int)x[j], 63);
+                }
             }
-        }
-        // what the next stage reads: first value and "not uniform" bit of the 64 nodes of relative level 6
-        if (out_off != ~(size_t)0) {  // (then seg = 4096 and rmax = 6: I is one word)
-            const size_t n_out = n_in >> RUN_STAGE_LEVELS;
-            uint32_t *fv = reinterpret_cast<uint32_t *>(b.r_stage + out_off) + (size_t)y * n_out + (size_t)segi * 64;
-            unsigned long long *inner = reinterpret_cast<unsigned long long *>(b.r_stage + out_off + (size_t)b.rcols.n * n_out * 4) +
-                                        ((size_t)y * n_out) / 64 + segi;
-            fv[lane] = s_x[lane << RUN_STAGE_LEVELS];
-            if (lane == 0) *inner = I;
-        }
-        // one list reservation per level, each by a lane of its own (the sub-list counters sit in lines of their own)
-        if (lane <= rmax && (STAGE0 || lane != 0)) {
-            const unsigned l_abs = l_in + lane;
-            const unsigned sub = (y * nseg + segi) % RUN_SUBS;
-            s_base[lane] = b.r_lists.base[l_abs] + (unsigned long long)sub * b.r_lists.cap[l_abs] +
-                           atomicAdd(&b.r_ctr[run_ctr_index(l_abs, sub)], (unsigned long long)my_tot);
         }
     }
-    __syncthreads();
-    // 4. the list entries of every level
-    for (unsigned r = STAGE0 ? 0 : 1; r <= rmax; r++) {
-        const unsigned nodes = seg >> r;
-        const unsigned long long base = s_base[r];
+    // 2. all levels of the segment: lane j < words >> r holds word j of relative level r
+    unsigned w = words;
+    unsigned long long need_r[RUN_STAGE_LEVELS + 1];
+    unsigned off_r[RUN_STAGE_LEVELS + 1];
+    unsigned my_tot = 0;
+#pragma unroll
+    for (unsigned r = 0; r <= RUN_STAGE_LEVELS; r++) {
+        need_r[r] = 0;
+        off_r[r] = 0;
+        if (r > rmax) continue;
+        if (r) {
+            const unsigned long long t = I | (E & BITS_ODD);
+            const unsigned long long i32 = compress_even64(t | (t >> 1)), e32 = compress_even64(E);
+            const unsigned long long ilo = __shfl(i32, (2 * lane) & 63), ihi = __shfl(i32, (2 * lane + 1) & 63);
+            const unsigned long long elo = __shfl(e32, (2 * lane) & 63), ehi = __shfl(e32, (2 * lane + 1) & 63);
+            w >>= 1;
+            I = lane < w ? (ilo | (ihi << 32)) : 0;
+            E = lane < w ? (elo | (ehi << 32)) : 0;
+        }
+        if (!STAGE0 && r == 0) continue;  // the input level was emitted by the previous stage
+        unsigned carry = (unsigned)__builtin_amdgcn_update_dpp(0, (int)(I >> 63), 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane == 0) carry = 1;  // the first node of the segment's range is always hashed
+        const unsigned long long need = lane < w ? (I | (I << 1) | carry | E) : 0;
+        const unsigned cnt = (unsigned)__builtin_popcountll(need);
+        const unsigned incl = wave_scan_add(cnt);
+        // last hashed node up to the end of this word -> the word before gives "the last hashed node before the chunk"
+        const int last = wave_scan_max(need ? (int)(lane * 64 + 63 - __builtin_clzll(need)) : -1);
+        int prev = __builtin_amdgcn_update_dpp(0, last, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+        if (lane == 0) prev = 0;
+        const unsigned tot = (unsigned)__builtin_amdgcn_readlane((int)incl, 63);  // (lanes >= w add nothing)
+        if (lane == r) my_tot = tot;
+        const unsigned l_abs = l_in + r;
+        if (lane < w) {
+            const size_t e = run_meta_base(b.npad, b.meta.ncols, l_abs) + ((size_t)y * (b.npad >> l_abs) + (first >> r)) / 64 + lane;
+            b.meta.bitmap[e] = need;
+            b.meta.prev[e] = (unsigned short)prev;
+        }
+        need_r[r] = need;
+        off_r[r] = incl - cnt;
+    }
+    // what the next stage reads: first value and "not uniform" bit of the 64 nodes of relative level 6
+    if (out_off != ~(size_t)0) {  // (then seg = 4096 and rmax = 6: I is one word, in lane 0)
+        const size_t n_out = n_in >> RUN_STAGE_LEVELS;
+        uint32_t *fv = reinterpret_cast<uint32_t *>(b.r_stage + out_off) + (size_t)y * n_out + (size_t)segi * 64;
+        unsigned long long *inner = reinterpret_cast<unsigned long long *>(b.r_stage + out_off + (size_t)b.rcols.n * n_out * 4) +
+                                    ((size_t)y * n_out) / 64 + segi;
+        fv[lane] = fv_mine;
+        if (lane == 0) *inner = I;
+    }
+    // one list reservation per level, each by a lane of its own (the sub-list counters sit in lines of their own)
+    unsigned long long my_base = 0;
+    if (lane <= rmax && (STAGE0 || lane != 0)) {
+        const unsigned l_abs = l_in + lane;
+        const unsigned sub = (y * nseg + segi) % RUN_SUBS;
+        my_base = b.r_lists.base[l_abs] + (unsigned long long)sub * b.r_lists.cap[l_abs] +
+                  atomicAdd(&b.r_ctr[run_ctr_index(l_abs, sub)], (unsigned long long)my_tot);
+    }
+    // 3. the list entries of every level: word by word (wave-uniform), lane j <-> node j of the word, so a word's entries go out
+    // as one coalesced store; words without a hashed node are skipped
+#pragma unroll
+    for (unsigned r = 0; r <= RUN_STAGE_LEVELS; r++) {
+        if (r > rmax || (!STAGE0 && r == 0)) continue;
+        const unsigned long long base = __shfl(my_base, r);
         const size_t node0 = first >> r;
-        for (unsigned j = threadIdx.x; j < nodes; j += TPB) {
-            const unsigned long long m = s_need[r][j >> 6];
-            if ((m >> (j & 63)) & 1)
-                b.r_list[base + s_off[r][j >> 6] + (unsigned)__builtin_popcountll(m & ((1ull << (j & 63)) - 1))] =
-                    ((uint32_t)y << RUN_NODE_BITS) | (uint32_t)(node0 + j);
+        const unsigned wr = words >> r;
+        for (unsigned q = 0; q < wr; q++) {
+            const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)need_r[r], q);
+            const unsigned hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(need_r[r] >> 32), q);
+            if ((lo | hi) == 0) continue;
+            const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)off_r[r], q);
+            const unsigned long long m = ((unsigned long long)hi << 32) | lo;
+            if ((m >> lane) & 1)
+                b.r_list[base + o + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0))] =
+                    ((uint32_t)y << RUN_NODE_BITS) | (uint32_t)(node0 + q * 64 + lane);
         }
     }
 }
@@ -222,14 +259,15 @@ void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
         const bool has_next = st + 1 < nstages;
         const size_t in_off = st ? stage_off(b.npad, b.rcols.n, st) : 0;
         const size_t out_off = has_next ? stage_off(b.npad, b.rcols.n, st + 1) : ~(size_t)0;
-        const dim3 grid((unsigned)(n_in / seg), b.rcols.n);
+        const unsigned nseg = (unsigned)(n_in / seg);
+        const dim3 grid((nseg + RUNS_WAVES - 1) / RUNS_WAVES, b.rcols.n);
         hipEvent_t e0 = kt && st == 0 ? kt->start : nullptr, e1 = kt && st + 1 == nstages ? kt->stop : nullptr;
         if (st == 0) {
-            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, in_off, out_off);
-            else hipLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, in_off, out_off);
+            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, nseg, in_off, out_off);
+            else hipLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, nseg, in_off, out_off);
         } else {
-            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, in_off, out_off);
-            else hipLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, in_off, out_off);
+            if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, nseg, in_off, out_off);
+            else hipLaunchKernelGGL(k_runs_stage<false>, grid, dim3(TPB), 0, s, b, st, log2u(seg), rmax, nseg, in_off, out_off);
         }
     }
 }
@@ -271,6 +309,11 @@ __device__ __forceinline__ void cons_insert(unsigned long long *keys, uint32_t *
                                             unsigned g_cur, unsigned g_prev, uint32_t node) {
     size_t slot = cons_mix(key) & mask;
     for (size_t tries = 0; tries <= mask; tries++) {  // live keys fill at most 3/4 of the slots: a free or matching one is reached
+        // look through the caches first: a key, once in its slot, stays for the rest of its generation, so a (possibly stale)
+        // cached copy that shows it is proof enough -- and thousands of waves looking at the same few slots are served by their
+        // CU's L1 instead of queueing at one memory channel (same-address atomic loads serialise at ~15 ns each: 125 us for
+        // the 8192 waves of level 1 of a 4-step loop)
+        if (keys[slot] == key) return;
         unsigned long long cur = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
         for (;;) {  // until this slot holds a live key
             if (cur == key) return;
@@ -295,24 +338,43 @@ __device__ __forceinline__ uint32_t cons_lookup(const unsigned long long *keys, 
     return 0xffffffffu;  // cannot happen: the key was inserted by the previous launch
 }
 
-__global__ __launch_bounds__(TPB) void k_cons_leaf_insert(MerkleBuild b) {
-    const size_t k = (size_t)blockIdx.x * TPB + threadIdx.x;
+// Second filter, per workgroup: of the wave leaders that hold the same key only the first to put it into the workgroup's key
+// set (LDS) goes to the table in memory.  A loop-dominated level then costs a handful of table accesses per 1024 nodes; without
+// it every wave of the level queues at the same few words (same-address atomics serialise at ~15 ns: 85 us for level 1).
+constexpr unsigned CONS_SET = 2048;  // slots: at most 1024 keys arrive
+__device__ __forceinline__ bool wg_first(unsigned long long *set, unsigned long long key) {
+    unsigned slot = (unsigned)(cons_mix(key) >> 40) & (CONS_SET - 1);
+    for (;;) {
+        const unsigned long long old = atomicCAS(&set[slot], 0ull, key);  // (keys are never 0: the generation is >= 1)
+        if (old == 0) return true;
+        if (old == key) return false;
+        slot = (slot + 1) & (CONS_SET - 1);
+    }
+}
+
+__global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
+    __shared__ unsigned long long s_set[CONS_SET];
+    for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
+    __syncthreads();
+    const size_t k = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
     const unsigned lane = threadIdx.x & 63;
     const bool valid = k < b.npad;
     const unsigned long long key = ((unsigned long long)b.g_gen << CONS_GEN_SHIFT) | (valid ? cons_leaf_payload(b, k) : 0);
     const unsigned ld = wave_leader(key, valid, lane);
-    if (valid && ld == lane) cons_insert(b.g_keys, b.g_idx, 2 * b.npad - 1, key, b.g_gen, b.g_gen, (uint32_t)k);
+    if (valid && ld == lane && wg_first(s_set, key)) cons_insert(b.g_keys, b.g_idx, 2 * b.npad - 1, key, b.g_gen, b.g_gen, (uint32_t)k);
 }
 
 // Resolves level lr (every node learns its representative; representatives go onto the level's list) and, if do_insert,
 // inserts the keys of level lr + 1: node c / 2's key is the pair of the representatives of c and c + 1, which sit in
 // neighbouring lanes.
 template <bool LEAF>
-__global__ __launch_bounds__(TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
-    __shared__ unsigned s_cnt[TPB / 64];
+__global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
+    __shared__ unsigned long long s_set[CONS_SET];
+    __shared__ unsigned s_cnt[CONS_TPB / 64];
     __shared__ unsigned long long s_base;
     if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
-    const size_t n = b.npad >> lr, c = (size_t)blockIdx.x * TPB + threadIdx.x;
+    for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
+    const size_t n = b.npad >> lr, c = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool valid = c < n;
     const size_t mask = 2 * b.npad - 1;
@@ -348,7 +410,7 @@ __global__ __launch_bounds__(TPB) void k_cons_pass(MerkleBuild b, unsigned lr, i
     __syncthreads();
     if (threadIdx.x == 0) {
         unsigned tot = 0;
-        for (int w = 0; w < TPB / 64; w++) { const unsigned t = s_cnt[w]; s_cnt[w] = tot; tot += t; }
+        for (int w = 0; w < CONS_TPB / 64; w++) { const unsigned t = s_cnt[w]; s_cnt[w] = tot; tot += t; }
         const unsigned sub = blockIdx.x % RUN_SUBS;
         s_base = b.g_lists.base[lr] + (unsigned long long)sub * b.g_lists.cap[lr] +
                  (tot ? atomicAdd(&b.g_ctr[run_ctr_index(lr, sub)], (unsigned long long)tot) : 0ull);
@@ -360,7 +422,7 @@ __global__ __launch_bounds__(TPB) void k_cons_pass(MerkleBuild b, unsigned lr, i
         const bool own = valid && !(c & 1);
         const unsigned long long k2 = ((unsigned long long)(g_r + 1) << CONS_GEN_SHIFT) | ((unsigned long long)r << RUN_NODE_BITS) | r_hi;
         const unsigned ld2 = wave_leader(k2, own, lane);
-        if (own && ld2 == lane) cons_insert(b.g_keys, b.g_idx, mask, k2, g_r + 1, g_r, (uint32_t)(c >> 1));
+        if (own && ld2 == lane && wg_first(s_set, k2)) cons_insert(b.g_keys, b.g_idx, mask, k2, g_r + 1, g_r, (uint32_t)(c >> 1));
     }
 }
 
@@ -378,16 +440,16 @@ __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
 void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
     if (b.gcols.n == 0) return;
     const unsigned top = b.g_lists.top;
-    const dim3 g0((unsigned)((b.npad + TPB - 1) / TPB));
-    if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(TPB), 0, s, kt->start, nullptr, 0, b);
-    else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(TPB), 0, s, b);
-    hipLaunchKernelGGL(k_cons_pass<true>, g0, dim3(TPB), 0, s, b, 0u, top >= 1 ? 1 : 0);
+    const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB));
+    if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b);
+    else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b);
+    hipLaunchKernelGGL(k_cons_pass<true>, g0, dim3(CONS_TPB), 0, s, b, 0u, top >= 1 ? 1 : 0);
     hipLaunchKernelGGL(k_cons_decide, dim3(1), dim3(64), 0, s, b);
     for (unsigned lr = 1; lr <= top; lr++) {
-        const dim3 g((unsigned)(((b.npad >> lr) + TPB - 1) / TPB));
+        const dim3 g((unsigned)(((b.npad >> lr) + CONS_TPB - 1) / CONS_TPB));
         const int ins = lr < top ? 1 : 0;
-        if (kt && lr == top) hipExtLaunchKernelGGL(k_cons_pass<false>, g, dim3(TPB), 0, s, nullptr, kt->stop, 0, b, lr, ins);
-        else hipLaunchKernelGGL(k_cons_pass<false>, g, dim3(TPB), 0, s, b, lr, ins);
+        if (kt && lr == top) hipExtLaunchKernelGGL(k_cons_pass<false>, g, dim3(CONS_TPB), 0, s, nullptr, kt->stop, 0, b, lr, ins);
+        else hipLaunchKernelGGL(k_cons_pass<false>, g, dim3(CONS_TPB), 0, s, b, lr, ins);
     }
 }
 
@@ -396,7 +458,8 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
 // every node of the columns in gdense].  A fixed grid strides over that index space, one hash per thread and step, every
 // lane busy whatever mix of constant and busy columns produced the lists.  Children are read where their digests are:
 // an R child through its leader, a G child through its representative.
-template <bool LEAF>
+// PAUSE = false for the small levels, whose few waves run alone on their SIMDs (keccak.hpp).
+template <bool LEAF, bool PAUSE>
 __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
     __shared__ unsigned long long s_r[RUN_SUBS + 1], s_g[RUN_SUBS + 1];  // exclusive prefixes of the sub-list lengths
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -427,7 +490,7 @@ __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, C
     const size_t in_off = LEAF ? 0 : 2 * b.npad - 2 * (b.npad >> (L - 1));
 #pragma unroll 1
     for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * TPB) {
-        size_t col, k, c0, c1;
+        size_t col, k, c0 = 0, c1 = 0;
         if (e < cR) {
             unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
 #pragma unroll
@@ -463,8 +526,8 @@ __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, C
         }
         uint8_t *tr = b.tree + col * b.tree_stride_nodes * 32;
         Digest d;
-        if (LEAF) d = sha3_leaf((uint64_t)(k < b.n_values ? b.vals[col * b.val_stride + k] : 0u));
-        else d = sha3_node(load_digest(tr, in_off + c0), load_digest(tr, in_off + c1));
+        if (LEAF) d = sha3_leaf<PAUSE>((uint64_t)(k < b.n_values ? b.vals[col * b.val_stride + k] : 0u));
+        else d = sha3_node<PAUSE>(load_digest(tr, in_off + c0), load_digest(tr, in_off + c1));
         store_digest_plain(tr, out_off + k, d);
     }
 }
@@ -482,8 +545,11 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
     const size_t n_L = b.npad >> L;
     size_t wgs = ((size_t)(b.rcols.n + b.gcols.n) * n_L + TPB - 1) / TPB;  // an upper bound of the work; the lists say how much
     if (wgs > 2048) wgs = 2048;                                            // there is (8 workgroups per CU stride over it)
-    if (L == 0) ZK_LAUNCH(kt, k_level_hash<true>, dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
-    else ZK_LAUNCH(kt, k_level_hash<false>, dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+    // fewer than two waves per SIMD even if every node were hashed: the re-arm pauses would only add latency
+    const bool small = (size_t)(b.rcols.n + b.gcols.n) * n_L <= (size_t)256 * 4 * 2 * 64;
+    if (L == 0) ZK_LAUNCH(kt, (k_level_hash<true, true>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+    else if (small) ZK_LAUNCH(kt, (k_level_hash<false, false>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+    else ZK_LAUNCH(kt, (k_level_hash<false, true>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
 }
 
 // ------------------------------------------------------------------ the top of the trees
@@ -492,20 +558,32 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
 // waves, so the permutation is the variant without re-arm pauses.
 __global__ __launch_bounds__(TPB) void k_merkle_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
                                                     unsigned first_level, unsigned height, RunMeta meta, int have_meta) {
+    __shared__ Digest s_d[TPB];  // the level just computed: the next one reads its children here, not from global memory
     const size_t col = blockIdx.y;
     uint8_t *t = tree + col * tree_stride_nodes * 32;
     for (unsigned l = first_level; l < height; l++) {
         const size_t n_out = npad >> (l + 1);
         const size_t in_off = 2 * npad - 2 * (npad >> l), out_off = 2 * npad - 2 * (npad >> (l + 1));
+        Digest d;
         if (threadIdx.x < n_out) {
-            size_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
-            if (have_meta && l == first_level) {
-                c0 = resolve_node(meta, npad, col, l, c0);
-                c1 = resolve_node(meta, npad, col, l, c1);
+            Digest a, c;
+            if (l == first_level) {
+                size_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
+                if (have_meta) {
+                    c0 = resolve_node(meta, npad, col, l, c0);
+                    c1 = resolve_node(meta, npad, col, l, c1);
+                }
+                a = load_digest(t, in_off + c0);
+                c = load_digest(t, in_off + c1);
+            } else {
+                a = s_d[2 * threadIdx.x];
+                c = s_d[2 * threadIdx.x + 1];
             }
-            store_digest_plain(t, out_off + threadIdx.x, sha3_node<false>(load_digest(t, in_off + c0), load_digest(t, in_off + c1)));
+            d = sha3_node<false>(a, c);
+            store_digest_plain(t, out_off + threadIdx.x, d);
         }
-        __threadfence_block();
+        __syncthreads();  // everybody has read its children
+        if (threadIdx.x < n_out) s_d[threadIdx.x] = d;
         __syncthreads();
     }
 }
