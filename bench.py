@@ -54,7 +54,9 @@ def isa_counts():
     """VALU instructions per hash of the Keccak kernels, counted from the gfx950 code (tools/isa_counts.py)."""
     with open(os.path.join(ROOT, "profiles", "isa_counts.json")) as f:
         k = json.load(f)["kernels"]
-    return {"leaves": k["k_keccak_leaves"]["valu"], "level": k["k_keccak_level<4>"]["valu"]}
+    return {"leaves": k["k_keccak_leaves"]["valu"], "level": k["k_keccak_level<4>"]["valu"],
+            "level_hash": k["k_level_hash<false, true>"]["valu"], "level_hash_leaf": k["k_level_hash<true, true>"]["valu"],
+            "top": k["k_merkle_top"]["valu"]}
 
 
 # ------------------------------------------------------------------ N > 1: self-launch (parent never touches the GPU)
@@ -281,8 +283,8 @@ def main():
     ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
                     "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
                     "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
-                    "bounded by the host cores: 14 lanes, ~480 M steps/s); -1 (default) = a third of this rank's CPUs + 1, at most 6 "
-                    "(48 proofs in flight: 163 GiB of HBM), or 0 without AVX-512F")
+                    "bounded by the host cores: 14 lanes, ~480 M steps/s); -1 (default) = half of this rank's CPUs, at most 8 "
+                    "(64 proofs in flight: 218 GiB of HBM), or 0 without AVX-512F")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
@@ -416,7 +418,7 @@ def main():
     shard = args.mode == "shard"
     servers = args.sponge_servers
     if servers < 0:
-        servers = 0 if shard or not has_avx512f() else max(1, min(6, host_cpus() // max(world, 1) // 3 + 1))
+        servers = 0 if shard or not has_avx512f() else max(1, min(8, host_cpus() // max(world, 1) // 2))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0

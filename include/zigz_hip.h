@@ -63,7 +63,8 @@ enum {
     ZIGZ_ERR_HIP = 101,           /* a HIP runtime call failed; see zigz_last_error */
     ZIGZ_ERR_NOT_CANONICAL = 102, /* a field element >= p crossed the boundary */
     ZIGZ_ERR_INVALID_ARGUMENT = 103,
-    ZIGZ_ERR_BAD_STATE = 104      /* commit-job calls out of order */
+    ZIGZ_ERR_BAD_STATE = 104,     /* commit-job calls out of order */
+    ZIGZ_ERR_COMM = 105           /* a sharded proof's exchange hook failed, or another rank reported an error */
 };
 
 typedef struct zigz_ctx zigz_ctx;
@@ -219,7 +220,8 @@ zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_
 zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
                                               const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride);
 /* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
- * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer. */
+ * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer; page-locking belongs
+ * to the process, so unregister accepts ctx == NULL (the registering context may already be destroyed). */
 zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes);
 zigz_status zigz_host_unregister(zigz_ctx *ctx, void *h_ptr);
 
@@ -242,7 +244,11 @@ zigz_status zigz_dev_sumcheck_prove(zigz_ctx *ctx, const uint32_t *d_in, size_t 
  * rank-local).  Radix form: per stage of k <= 10 rounds the ranks exchange 2^k exact u64 partial block sums, then one
  * exchange re-assembles the last <= 1024 * world entries: 2-3 exchanges per proof, all through `allgather` (every rank
  * contributes `bytes` from `send`; `recv` gets world * bytes in rank order; return 0 on success -- bind it to RCCL,
- * MPI or torch.distributed).  Every rank returns the same rounds / point / final_eval as the unsharded prover. */
+ * MPI or torch.distributed).  Every rank returns the same rounds / point / final_eval as the unsharded prover.
+ * Failure is collective: every payload carries one status word, so a rank whose local pass failed (HIP error, a callback's
+ * status) takes part in the next exchange with that status and ALL ranks stop there -- the failing rank returns its own
+ * error, the others ZIGZ_ERR_COMM -- instead of waiting for the transport's timeout; a hook that returns nonzero is
+ * ZIGZ_ERR_COMM as well. */
 typedef int (*zigz_allgather_fn)(void *user, const void *send, size_t bytes, void *recv);
 zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, int rank, int world,
                                             zigz_allgather_fn allgather, void *user, uint64_t *rounds, uint64_t *point,
@@ -251,13 +257,40 @@ zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint32_t *d_loc
  * exchange is host-resident (it was read back for the SHA3 transcript) and <= 64 KiB, so between processes of a node
  * this is the shortest path (a few microseconds per exchange); across nodes bind the hook to RCCL / MPI.  Every rank
  * calls create with the same job-unique `name` (<= 80 chars, no '/'), world and max_bytes (largest `bytes` of any
- * exchange); rank 0 creates the segment, the others attach (waiting up to timeout_s; <= 0: 60 s).  Pass the comm as the
- * hook's `user`.  A rank that waits longer than timeout_s inside an exchange returns nonzero instead of hanging. */
+ * exchange); rank 0 creates the segment, the others attach (waiting up to timeout_s; <= 0: 60 s).  Creation is a
+ * collective with a handshake: an attacher accepts a segment only once the live rank 0 has echoed the random token it
+ * wrote there (a segment left behind by a crashed job under the same name has nobody to answer and is let go), and rank 0
+ * returns when every rank has been acknowledged.  `name` must still be unique among jobs that START at the same time: put a
+ * job id or a nonce broadcast by rank 0 into it.  Pass the comm as the hook's `user`.  A rank that waits longer than
+ * timeout_s inside an exchange returns nonzero instead of hanging. */
 typedef struct zigz_shm_comm zigz_shm_comm;
 zigz_status zigz_shm_comm_create(const char *name, int rank, int world, size_t max_bytes, double timeout_s,
                                  zigz_shm_comm **out);
 int zigz_shm_allgather(void *comm, const void *send, size_t bytes, void *recv);
 void zigz_shm_comm_destroy(zigz_shm_comm *comm);
+/* RCCL as the transport, without torch: for ranks on different GPUs of an xGMI node (or on several nodes).  The 128-byte
+ * unique id comes from ONE rank (zigz_rccl_unique_id) and reaches the others however the host distributes small blobs
+ * (a file, MPI, its own socket); every rank then creates its communicator for HIP device `device`.  max_bytes: the largest
+ * `bytes` of any exchange.  librccl.so is loaded on first use; ZIGZ_ERR_NO_DEVICE when it cannot be.
+ *  - zigz_rccl_allgather is a zigz_allgather_fn (user = the comm): host buffers, staged through pinned + device memory;
+ *  - zigz_rccl_allreduce_u64 sums n u64 words over the ranks (host buffers); ..._dev does it in place on words already in
+ *    HBM on the given hipStream_t, no staging and no synchronisation;
+ *  - zigz_dev_sumcheck_prove_rccl is zigz_dev_sumcheck_prove_sharded with the partial block sums of every radix stage
+ *    (k <= 10 rounds of round-polynomial sums, sumcheck_prover.zig:50-77) all-reduced in HBM on the context's stream --
+ *    one RCCL all-reduce per stage of rounds -- and the last <= 1024 * world entries all-gathered through the comm. */
+#define ZIGZ_RCCL_UNIQUE_ID_BYTES 128
+typedef struct zigz_rccl_comm zigz_rccl_comm;
+zigz_status zigz_rccl_unique_id(uint8_t id[ZIGZ_RCCL_UNIQUE_ID_BYTES]);
+zigz_status zigz_rccl_comm_create(int device, const uint8_t id[ZIGZ_RCCL_UNIQUE_ID_BYTES], int rank, int world,
+                                  size_t max_bytes, zigz_rccl_comm **out);
+int zigz_rccl_allgather(void *comm, const void *send, size_t bytes, void *recv);
+int zigz_rccl_allreduce_u64(zigz_rccl_comm *comm, const uint64_t *send, size_t n, uint64_t *recv);
+int zigz_rccl_allreduce_u64_dev(zigz_rccl_comm *comm, uint64_t *d_words, size_t n, void *hip_stream);
+int zigz_rccl_comm_rank(const zigz_rccl_comm *comm);
+int zigz_rccl_comm_world(const zigz_rccl_comm *comm);
+void zigz_rccl_comm_destroy(zigz_rccl_comm *comm);
+zigz_status zigz_dev_sumcheck_prove_rccl(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, zigz_rccl_comm *comm,
+                                         uint64_t *rounds, uint64_t *point, uint64_t *final_eval);
 /* The same orchestration over caller-supplied data passes on the local table (what the GPU passes of the call above do):
  * block_sums: exact u64 sums of the 2^k contiguous blocks of the current table; fold: current := sum_b w[b] *
  * current[b*m + i] (2^k canonical weights, m = length / 2^k) and, when k_next != 0, the 2^k_next block sums of the result;
@@ -403,6 +436,9 @@ zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
  *   (128 + 128^2 digests) instead of hashed: 1.5 N of the 2 N permutations of such a column.  The bound is checked per
  *   wave on the device; where it does not hold the digests are hashed, so the trees are identical for ANY input. */
 zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value);
+/* the current value of an option (every name above except the shorthand "merkle_dedup"): lets a caller that changes the
+ * hint masks for one proof put back what the context's owner had set (host/prover.cpp does) */
+zigz_status zigz_ctx_get_option(zigz_ctx *ctx, const char *name, int64_t *value);
 zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out);
 
 #ifdef __cplusplus

@@ -141,3 +141,40 @@ def test_sharded_paths_world2_on_gpu():
             assert np.array_equal(np.array(got[k], dtype=exp[k].dtype), exp[k]), (rank, k)
         assert got["next_challenge"] == nxt
         assert sc["rounds"] == [int(x) for x in r] and sc["point"] == [int(x) for x in p] and sc["fe"] == fe
+
+
+def test_rccl_comm_one_rank_on_the_gpu():
+    """The native RCCL transport (zigz_rccl_comm, csrc/rccl_comm.cpp; no torch involved) with the ONE rank this box allows:
+    communicator init from a unique id, all-gather and all-reduce of host payloads through the staging buffers, the in-place
+    device all-reduce, and zigz_dev_sumcheck_prove_sharded / _rccl through it against the unsharded oracle.  (With one GPU per
+    box RCCL cannot carry a payload between two ranks here; world > 1 is covered over gloo / shared memory on the CPU.)"""
+    import time
+    import zigz_amd
+    from zigz_amd import shard
+    uid = shard.RcclComm.unique_id()
+    assert len(uid) == 128
+    comm = shard.RcclComm(0, uid, 0, 1, max_bytes=1 << 16)
+    ctx = zigz_amd.Context(0)
+    try:
+        for n in (1, 16, 8191, 1 << 16):
+            payload = bytes((7 * i + n) & 255 for i in range(n))
+            assert comm.all_gather(payload) == [payload]
+        words = np.arange(1, 1025, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)
+        assert np.array_equal(comm.all_reduce_u64(words), words)
+        table = O.splitmix64_field(4242, 1 << 16)
+        d = ctx.dev_alloc((1 << 16) * 4)
+        ctx.upload(table, d)
+        r0, p0, fe0 = O.sumcheck_prove(P, table)
+        r, p, fe = shard.sumcheck_prove_row_sharded_radix(ctx, d, 1 << 16, None, comm)    # the hook form
+        assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
+        r, p, fe = ctx.dev_sumcheck_prove_rccl(d, 1 << 16, comm)                           # the native form
+        assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
+        t0 = time.perf_counter()
+        for _ in range(200):
+            comm.all_gather(b"x" * 8192)
+        us = (time.perf_counter() - t0) / 200 * 1e6
+        print("zigz_rccl_allgather, 8 KiB, one rank: %.1f us per exchange" % us)
+        ctx.dev_free(d)
+    finally:
+        ctx.close()
+        comm.close()

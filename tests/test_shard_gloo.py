@@ -1,6 +1,7 @@
 """N > 1 path on CPU: world_size-2/4 gloo runs of zigz_amd.shard's column-sharded generateCommitments and
 row-sharded sumcheck (exchange logic), with oracle-backed compute stand-ins, against the unsharded oracle."""
 import os
+import time
 import socket
 
 import numpy as np
@@ -162,6 +163,49 @@ def _shm_worker(rank, world, name, nv, q):
         comm.close()
 
 
+def _failing_rank_worker(rank, world, name, nv, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from zigz_amd import shard
+    import zigz_amd
+    import fake_engine
+
+    class Broken(fake_engine.FakeRadixOps):
+        def fold(self, k, weights, k_next):
+            if rank == 1:
+                raise ValueError("this rank's data pass fails")
+            return super().fold(k, weights, k_next)
+    comm = shard.ShmComm(name, rank, world, max_bytes=1 << 14, timeout_s=60)
+    t0 = time.perf_counter()
+    try:
+        local = shard.interleave_rows(O.splitmix64_field(5, 1 << nv), rank, world)
+        shard.sumcheck_radix_run(Broken(local), len(local), None, allgather=comm)
+        q.put((rank, "no error", 0.0))
+    except zigz_amd.ZigzError as e:
+        q.put((rank, e.name, time.perf_counter() - t0))
+    except ValueError:
+        q.put((rank, "own error", time.perf_counter() - t0))
+    finally:
+        comm.close()
+
+
+def test_sharded_sumcheck_fails_on_all_ranks_together():
+    """a rank whose local pass fails must not leave its peers in the next all-gather until the transport's
+    timeout (60 s here).  Its status rides in the next exchange: it returns its own error, the others CommError, at once."""
+    world, nv = 4, 14
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "zigz_test_fail_%d" % os.getpid()
+    procs = [ctx.Process(target=_failing_rank_worker, args=(r, world, name, nv, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = {r: (what, dt) for r, what, dt in (q.get(timeout=120) for _ in range(world))}
+    [p.join(timeout=60) for p in procs]
+    assert out[1][0] == "own error"
+    for r in (0, 2, 3):
+        assert out[r][0] == "CommError", out
+    assert max(dt for _, dt in out.values()) < 20.0, out
+
+
 @pytest.mark.parametrize("world,nv", [(2, 13), (4, 14), (8, 14)])
 def test_row_sharded_radix_sumcheck_shm(world, nv):
     """The same orchestration with the built-in same-node transport (zigz_shm_comm, no torch, no sockets):
@@ -182,17 +226,62 @@ def test_row_sharded_radix_sumcheck_shm(world, nv):
 
 
 def test_shm_comm_times_out_instead_of_hanging():
-    """A rank whose peers never arrive gets an error after timeout_s, not a hang ('the others hang')."""
+    """A rank whose peers never arrive gets an error after timeout_s, not a hang ('the others hang').  Creation is
+    a collective with a handshake, so it is the create call that times out -- on either side."""
     from zigz_amd import shard
     import zigz_amd
     with pytest.raises(zigz_amd.ZigzError):      # rank 1 of 2, rank 0 never creates the segment
         shard.ShmComm("zigz_test_absent_%d" % os.getpid(), 1, 2, timeout_s=0.3)
-    comm = shard.ShmComm("zigz_test_alone_%d" % os.getpid(), 0, 2, timeout_s=0.3)
+    with pytest.raises(zigz_amd.ZigzError):      # rank 0 of 2, rank 1 never attaches
+        shard.ShmComm("zigz_test_alone_%d" % os.getpid(), 0, 2, timeout_s=0.3)
+    assert not os.path.exists("/dev/shm/zigz_test_alone_%d" % os.getpid())  # ... and it takes its segment with it
+
+
+def _stale_segment_rank(rank, world, name, q):
+    from zigz_amd import shard
     try:
-        with pytest.raises(RuntimeError):
-            comm.all_gather(b"abc")               # rank 1 never shows up
-    finally:
+        comm = shard.ShmComm(name, rank, world, max_bytes=256, timeout_s=20)
+        outs = [comm.all_gather(bytes([rank + 1]) * 16 + bytes([i]) * 16) for i in range(5)]
         comm.close()
+        q.put((rank, outs))
+    except Exception as e:  # noqa: BLE001
+        q.put((rank, repr(e)))
+
+
+def test_shm_comm_ignores_a_leftover_segment():
+    """names get reused, and a crashed job leaves its segment behind -- initialised (MAGIC set, matching world and
+    max_bytes) and with sequence counters far ahead.  An attacher that opens it before the new rank 0 has replaced it must
+    not take it for the live one (it would return at once from every all-gather with old slot bytes): nobody answers its
+    hello there, so it lets go and finds the new segment."""
+    import multiprocessing as mp
+    import struct
+    world, name = 3, "zigz_test_stale_%d" % os.getpid()
+    max_bytes = 256
+    size = 4096 + world * 64 + 2 * world * max_bytes
+    blob = bytearray(size)
+    struct.pack_into("<IIQ", blob, 0, 0x5A49475A, world, max_bytes)        # ready = MAGIC, world, max_bytes
+    for r in range(world):
+        struct.pack_into("<Q", blob, 4096 + 64 * r, 1 << 40)               # seq[r]: every future all-gather "already done"
+    for i in range(4096 + world * 64, size):
+        blob[i] = 0xEE                                                      # old slot bytes
+    with open("/dev/shm/" + name, "wb") as f:
+        f.write(blob)
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_stale_segment_rank, args=(r, world, name, q)) for r in (1, 2)]
+    for p in procs:
+        p.start()
+    time.sleep(0.5)                                # ranks 1 and 2 are looking at the leftover now
+    p0 = ctx.Process(target=_stale_segment_rank, args=(0, world, name, q))
+    p0.start()
+    res = dict(q.get(timeout=60) for _ in range(world))
+    for p in procs + [p0]:
+        p.join(30)
+    for r in range(world):
+        assert isinstance(res[r], list), res[r]
+        for i, out in enumerate(res[r]):
+            assert b"".join(out) == b"".join(bytes([k + 1]) * 16 + bytes([i]) * 16 for k in range(world)), (r, i)
+    assert not os.path.exists("/dev/shm/" + name)
 
 
 @pytest.mark.parametrize("world,n", [(2, 64), (4, 64), (4, 4), (2, 2)])

@@ -106,6 +106,15 @@ SIGNATURES = {
     "zigz_shm_comm_create": (C.c_int32, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.POINTER(vp)]),
     "zigz_shm_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "zigz_shm_comm_destroy": (None, [vp]),
+    "zigz_rccl_unique_id": (C.c_int32, [u8p]),
+    "zigz_rccl_comm_create": (C.c_int32, [C.c_int, u8p, C.c_int, C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "zigz_rccl_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "zigz_rccl_allreduce_u64": (C.c_int, [vp, u64p, C.c_size_t, u64p]),
+    "zigz_rccl_allreduce_u64_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "zigz_rccl_comm_rank": (C.c_int, [vp]),
+    "zigz_rccl_comm_world": (C.c_int, [vp]),
+    "zigz_rccl_comm_destroy": (None, [vp]),
+    "zigz_dev_sumcheck_prove_rccl": (C.c_int32, [vp, vp, C.c_size_t, vp, u64p, u64p, u64p]),
     "zigz_transcript_new": (vp, []),
     "zigz_transcript_free": (None, [vp]),
     "zigz_transcript_append_bytes": (None, [vp, C.c_char_p, C.c_size_t]),
@@ -121,6 +130,7 @@ SIGNATURES = {
     "zigz_host_keccak_permute_x8": (None, [u64p]),
     "zigz_host_keccak_permute": (None, [u64p, C.c_int]),
     "zigz_ctx_set_option": (C.c_int32, [vp, C.c_char_p, C.c_int64]),
+    "zigz_ctx_get_option": (C.c_int32, [vp, C.c_char_p, C.POINTER(C.c_int64)]),
     "zigz_ctx_enable_timing": (C.c_int32, [vp, C.c_int]),
     "zigz_bench_kernel": (C.c_int32, [vp, C.c_char_p, C.c_size_t, C.c_size_t, C.c_int, C.c_int, C.POINTER(BenchResult)]),
     "zigz_ctx_get_stats": (C.c_int32, [vp, C.POINTER(KernelStats)]),

@@ -69,6 +69,8 @@ def build_hip(force=False):
         ("host_keccak_avx512vl.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
         ("host_sponge_batch.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", "-pthread", f"-I{CSRC}"]),
         ("shm_comm.cpp", [_host_cxx(), "-O2", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
+        # RCCL transport: compiled against rccl.h, librccl.so itself is dlopen-ed on first use (570 MB: never at load time)
+        ("rccl_comm.cpp", [hipcc, "-O2", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}", "-I/opt/rocm/include"]),
     ]
     for src, cmd in units:
         s = os.path.join(CSRC, src)
@@ -78,7 +80,7 @@ def build_hip(force=False):
         objs.append(o)
     so = os.path.join(LIB, "libzigz_hip.so")
     if force or _newer(so, objs):
-        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", so] + objs + ["-lrt", "-pthread"])
+        _run([hipcc, f"--offload-arch={ARCH}", "-shared", "-fPIC", "-o", so] + objs + ["-lrt", "-pthread", "-ldl"])
     return so
 
 

@@ -170,6 +170,7 @@ extern "C" const char *zigz_status_name(zigz_status s) {
     case ZIGZ_ERR_HIP: return "HipError";
     case ZIGZ_ERR_NOT_CANONICAL: return "NotCanonical";
     case ZIGZ_ERR_INVALID_ARGUMENT: return "InvalidArgument";
+    case ZIGZ_ERR_COMM: return "CommError";
     case ZIGZ_ERR_BAD_STATE: return "BadState";
     default: return "Unknown";
     }
@@ -303,6 +304,16 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
+extern "C" zigz_status zigz_ctx_get_option(zigz_ctx *ctx, const char *name, int64_t *value) {
+    if (!ctx || !name || !value) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (strcmp(name, "per_round_sumcheck") == 0) { *value = ctx->per_round_sumcheck; return ZIGZ_OK; }
+    if (strcmp(name, "fold_eval") == 0) { *value = ctx->fold_eval; return ZIGZ_OK; }
+    if (strcmp(name, "run_aware_mask") == 0) { *value = (int64_t)ctx->run_aware_mask; return ZIGZ_OK; }
+    if (strcmp(name, "run_aware_materialize") == 0) { *value = ctx->run_aware_materialize; return ZIGZ_OK; }
+    if (strcmp(name, "cons_group_mask") == 0) { *value = (int64_t)ctx->cons_group_mask; return ZIGZ_OK; }
+    if (strcmp(name, "small_domain_mask") == 0) { *value = (int64_t)ctx->small_domain_mask; return ZIGZ_OK; }
+    return ZIGZ_ERR_INVALID_ARGUMENT;
+}
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -414,8 +425,14 @@ extern "C" zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t byt
 }
 extern "C" zigz_status zigz_host_unregister(zigz_ctx *ctx, void *h_ptr) {
     ZIGZ_ENTER(ctx);
-    if (!ctx || !h_ptr) return ZIGZ_ERR_INVALID_ARGUMENT;
-    HIPCHK(ctx, hipHostUnregister(h_ptr));
+    if (!h_ptr) return ZIGZ_ERR_INVALID_ARGUMENT;
+    // page-locking belongs to the process, not to the context that asked for it: ctx may be NULL (or already destroyed by
+    // the time a buffer is released -- callers then pass NULL)
+    const hipError_t e = hipHostUnregister(h_ptr);
+    if (e != hipSuccess) {
+        if (ctx) set_err(ctx, "hipHostUnregister failed: %s", hipGetErrorString(e));
+        return ZIGZ_ERR_HIP;
+    }
     return ZIGZ_OK;
 }
 
@@ -792,6 +809,7 @@ struct ShardComm {
     int rank, world;
     zigz_allgather_fn allgather;
     void *user;
+    bool sums_global;  // the data passes already return the sums over ALL ranks (reduced on the device: RCCL all-reduce)
 };
 
 zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const ShardComm *comm, const uint64_t *fixed,
@@ -815,15 +833,45 @@ zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const 
         point[round++] = *ch;
         return ZIGZ_OK;
     };
-    std::vector<uint64_t> gather;
+    std::vector<uint64_t> gather, wire;
+    // One exchange: every rank contributes `v` (all ranks the same length) behind ONE status word.  A rank whose local pass
+    // failed still takes part -- with its status and a zero payload -- so that all ranks leave the proof at the same
+    // exchange: the failing rank with its own error, the others with ZIGZ_ERR_COMM (instead of sitting in the transport's
+    // timeout while the failed rank has long returned).
+    zigz_status local = ZIGZ_OK;
+    auto exchange = [&](const std::vector<uint64_t> &v) -> zigz_status {  // gather := world x v
+        const size_t n = v.size();
+        wire.assign(n + 1, 0);
+        wire[0] = (uint64_t)(uint32_t)local;
+        if (local == ZIGZ_OK) memcpy(wire.data() + 1, v.data(), n * 8);
+        std::vector<uint64_t> all(world * (n + 1));
+        if (!comm->allgather || comm->allgather(comm->user, wire.data(), (n + 1) * 8, all.data()) != 0) {
+            set_err(ctx, "sharded sumcheck: the all-gather hook failed");
+            return local != ZIGZ_OK ? local : ZIGZ_ERR_COMM;
+        }
+        gather.resize(world * n);
+        bool peer_failed = false;
+        for (size_t r = 0; r < world; r++) {
+            if (all[r * (n + 1)] != ZIGZ_OK) peer_failed = true;
+            memcpy(gather.data() + r * n, all.data() + r * (n + 1) + 1, n * 8);
+        }
+        if (local != ZIGZ_OK) return local;
+        if (peer_failed) {
+            set_err(ctx, "sharded sumcheck: another rank reported an error");
+            return ZIGZ_ERR_COMM;
+        }
+        return ZIGZ_OK;
+    };
+    // a local data pass: alone, its status is returned at once; sharded, it is carried into the next exchange
+#define ZK_LOCAL(expr)                                     \
+    do {                                                   \
+        if (local == ZIGZ_OK) local = (expr);              \
+        if (local != ZIGZ_OK && world == 1) return local;  \
+    } while (0)
     // partial sums of every rank -> totals (exact: < 2^31 * 2^40 per rank, a few ranks)
     auto sum_over_ranks = [&](std::vector<uint64_t> &v) -> zigz_status {
-        if (world == 1) return ZIGZ_OK;
-        gather.resize(world * v.size());
-        if (!comm->allgather || comm->allgather(comm->user, v.data(), v.size() * 8, gather.data()) != 0) {
-            set_err(ctx, "sharded sumcheck: the all-gather hook failed");
-            return ZIGZ_ERR_INVALID_ARGUMENT;
-        }
+        if (world == 1 || comm->sums_global) return ZIGZ_OK;
+        CHK(exchange(v));
         for (size_t i = 0; i < v.size(); i++) {
             uint64_t t = 0;
             for (size_t r = 0; r < world; r++) t += gather[r * v.size() + i];
@@ -836,7 +884,7 @@ zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const 
     if (len > HOST_TAIL_MAX) {
         unsigned k = log2_floor(len) - 8 < RADIX_MAX_K ? log2_floor(len) - 8 : RADIX_MAX_K;
         B.assign((size_t)1 << k, 0);
-        CHK(ops.block_sums(ops.user, k, B.data()));
+        ZK_LOCAL(ops.block_sums(ops.user, k, B.data()));
         CHK(sum_over_ranks(B));
         for (;;) {
             for (auto &b : B) b %= P;
@@ -858,7 +906,7 @@ zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const 
             const unsigned lm = log2_floor(m);
             const unsigned k_next = m <= HOST_TAIL_MAX ? 0 : (lm - 8 < RADIX_MAX_K ? lm - 8 : RADIX_MAX_K);
             B.assign(k_next ? (size_t)1 << k_next : 0, 0);
-            CHK(ops.fold(ops.user, k, W.data(), k_next, k_next ? B.data() : nullptr));
+            ZK_LOCAL(ops.fold(ops.user, k, W.data(), k_next, k_next ? B.data() : nullptr));
             len = m;
             if (!k_next) break;
             CHK(sum_over_ranks(B));
@@ -867,19 +915,16 @@ zigz_status radix_run(zigz_ctx *ctx, const RadixOps &ops, size_t n_local, const 
     }
     // the remaining table: len local entries per rank, global index j*G + g
     std::vector<uint64_t> mine(len);
-    CHK(ops.read_tail(ops.user, len, mine.data()));
+    ZK_LOCAL(ops.read_tail(ops.user, len, mine.data()));
+#undef ZK_LOCAL
     if (world == 1) {
         tail.swap(mine);
     } else {
-        gather.resize(world * len);
-        if (!comm->allgather || comm->allgather(comm->user, mine.data(), len * 8, gather.data()) != 0) {
-            set_err(ctx, "sharded sumcheck: the all-gather hook failed");
-            return ZIGZ_ERR_INVALID_ARGUMENT;
-        }
+        CHK(exchange(mine));
         tail.resize(world * len);
         for (size_t r = 0; r < world; r++)
             for (size_t j = 0; j < len; j++) {
-                if (gather[r * len + j] >= P) return ZIGZ_ERR_NOT_CANONICAL;
+                if (gather[r * len + j] >= P) return ZIGZ_ERR_NOT_CANONICAL;  // (the same verdict on every rank)
                 tail[j * world + r] = gather[r * len + j];
             }
     }
@@ -908,13 +953,26 @@ struct GpuRadix {
     uint32_t *d_outs;
     void *wbuf;
     unsigned stage;
+    zigz_rccl_comm *rccl;  // != nullptr: block sums are all-reduced over the ranks in HBM, on the context's stream
 };
+// the partial block sums of this rank -> the sums over all ranks, in place, before they are read back.  Issued even after a
+// local launch error (st): the other ranks are inside the same collective and must not be left waiting for this one.
+zigz_status reduce_over_ranks(GpuRadix *g, unsigned long long *d_sums, size_t n, zigz_status st) {
+    if (!g->rccl) return st;
+    const int rc = zigz_rccl_allreduce_u64_dev(g->rccl, (uint64_t *)d_sums, n, g->ctx->stream);
+    if (st != ZIGZ_OK) return st;
+    if (rc != 0) {
+        set_err(g->ctx, "sharded sumcheck: the RCCL all-reduce failed (%d)", rc);
+        return ZIGZ_ERR_COMM;
+    }
+    return ZIGZ_OK;
+}
 zigz_status gpu_block_sums(void *user, unsigned k, uint64_t *sums) {
     GpuRadix *g = (GpuRadix *)user;
     zigz_ctx *ctx = g->ctx;
     HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, ((size_t)1 << k) * 8, ctx->stream));
     launch_block_sums(g->cur, g->len, g->len, log2_floor(g->len >> k), 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream);
-    HIPCHK(ctx, hipGetLastError());
+    CHK(reduce_over_ranks(g, ctx->d_sums, (size_t)1 << k, hipGetLastError() == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP));
     return read_u64(ctx, ctx->d_sums, (size_t)1 << k, sums);
 }
 zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k_next, uint64_t *next_sums) {
@@ -932,7 +990,7 @@ zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k
         unsigned long long *d_B2 = ctx->d_sums + ((g->stage + 1) & 1 ? 1024 : 0);
         HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k_next) * 8, ctx->stream));
         launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
+        CHK(reduce_over_ranks(g, d_B2, (size_t)1 << k_next, hipGetLastError() == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP));
         CHK(read_u64(ctx, d_B2, (size_t)1 << k_next, next_sums));
     } else {
         launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
@@ -956,8 +1014,9 @@ zigz_status gpu_read_tail(void *user, size_t m, uint64_t *out) {
 }  // namespace
 
 static zigz_status sumcheck_radix_sharded(zigz_ctx *ctx, const uint32_t *d_in, size_t n, const ShardComm *comm,
-                                          const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
-    GpuRadix g{ctx, d_in, n, 0, nullptr, nullptr, nullptr, 0};
+                                          const uint64_t *fixed, uint64_t *rounds, uint64_t *point, uint64_t *final_eval,
+                                          zigz_rccl_comm *rccl = nullptr) {
+    GpuRadix g{ctx, d_in, n, 0, nullptr, nullptr, nullptr, 0, rccl};
     if (n > HOST_TAIL_MAX) {
         const unsigned lv = log2_floor(n);
         const unsigned k = lv - 8 < RADIX_MAX_K ? lv - 8 : RADIX_MAX_K;
@@ -988,8 +1047,25 @@ extern "C" zigz_status zigz_dev_sumcheck_prove_sharded(zigz_ctx *ctx, const uint
     if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
     if (!aligned16(d_local)) return ZIGZ_ERR_INVALID_ARGUMENT;
-    const ShardComm comm{rank, world, allgather, user};
+    const ShardComm comm{rank, world, allgather, user, false};
     return sumcheck_radix_sharded(ctx, d_local, n_local, &comm, nullptr, rounds, point, final_eval);
+}
+
+// The same proof with RCCL as the transport, natively: the partial block sums of every radix stage (k <= 10 rounds' worth of
+// round-polynomial sums) are all-reduced IN HBM on the context's stream before they are read back for the transcript -- the
+// north-star's RCCL all-reduce of the round sums, once per stage instead of once per round -- and the last <= 1024 * world
+// table entries are all-gathered through the communicator's staging buffers.
+extern "C" zigz_status zigz_dev_sumcheck_prove_rccl(zigz_ctx *ctx, const uint32_t *d_local, size_t n_local, zigz_rccl_comm *rccl,
+                                                    uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !d_local || !rccl || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n_local));
+    const int world = zigz_rccl_comm_world(rccl), rank = zigz_rccl_comm_rank(rccl);
+    if (world < 1 || !is_pow2((size_t)world)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
+    if (!aligned16(d_local)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const ShardComm comm{rank, world, zigz_rccl_allgather, rccl, true};
+    return sumcheck_radix_sharded(ctx, d_local, n_local, &comm, nullptr, rounds, point, final_eval, world > 1 ? rccl : nullptr);
 }
 
 // The orchestration alone, over caller-supplied data passes (multi-process tests on CPU drive exactly the code path of
@@ -1001,7 +1077,7 @@ extern "C" zigz_status zigz_sumcheck_radix_run(const zigz_radix_ops *ops, size_t
     CHK(mle_check(n_local));
     if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
-    const ShardComm comm{rank, world, allgather, comm_user};
+    const ShardComm comm{rank, world, allgather, comm_user, false};
     const RadixOps r{ops->user, ops->block_sums, ops->fold, ops->read_tail};
     return radix_run(nullptr, r, n_local, &comm, fixed_challenges, rounds, point, final_eval);
 }

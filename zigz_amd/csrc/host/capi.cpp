@@ -89,7 +89,8 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
 }
 extern "C" void zigzh_trace_free(zigzh_trace *t) {
     if (!t) return;
-    if (t->registered) (void)zigz_host_unregister(t->registered, t->trace.steps.data());
+    // (the context that registered the buffer may be gone by now: page-locking is process-wide, so no context is named)
+    if (t->registered) (void)zigz_host_unregister(nullptr, t->trace.steps.data());
     else if (t->trace.steps.capacity() > g_step_pool.capacity()) g_step_pool.swap(t->trace.steps);
     delete t;
 }

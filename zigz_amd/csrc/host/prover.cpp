@@ -134,7 +134,7 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
         // send: nmax records of `rec` bytes (zero padded); all: the NC records in column order
         std::vector<uint8_t> recv((size_t)world * nmax * rec);
         if (!shard_.allgather || shard_.allgather(shard_.user, send.data(), nmax * rec, recv.data()) != 0)
-            throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "sharded prove: the all-gather hook failed");
+            throw Error(ZIGZ_ERR_COMM, "sharded prove: the all-gather hook failed");
         all.resize(NC * rec);
         for (int r = 0; r < world; r++) {
             size_t a, b;
@@ -247,6 +247,22 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     // Columns that hold values < 128 by construction (x0; opcode, rd, rs1, rs2, funct3, funct7; mem.is_read --
     // witness.zig:164-169,239, registers.zig:38-48): their leaf and level-1 digests come from constant tables
     // (zigz_hip.h, option "small_domain_mask"; checked on the device, identical trees for any input).
+    // the hint masks are options of the CONTEXT: remember what its owner had set and put that back when this proof is done
+    // (on every exit path), whatever this proof sets below
+    struct MaskRestore {
+        zigz_ctx *ctx;
+        int64_t sd = 0, ra = 0, cg = 0;
+        explicit MaskRestore(zigz_ctx *c) : ctx(c) {
+            (void)zigz_ctx_get_option(ctx, "small_domain_mask", &sd);
+            (void)zigz_ctx_get_option(ctx, "run_aware_mask", &ra);
+            (void)zigz_ctx_get_option(ctx, "cons_group_mask", &cg);
+        }
+        ~MaskRestore() {
+            (void)zigz_ctx_set_option(ctx, "small_domain_mask", sd);
+            (void)zigz_ctx_set_option(ctx, "run_aware_mask", ra);
+            (void)zigz_ctx_set_option(ctx, "cons_group_mask", cg);
+        }
+    } mask_restore(ctx_);
     if (small_domain_tables) {
         const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
         check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
@@ -270,15 +286,6 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         }
         check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
     }
-    struct MaskReset {
-        zigz_ctx *ctx;
-        bool sd, ra;
-        ~MaskReset() {
-            if (sd) (void)zigz_ctx_set_option(ctx, "small_domain_mask", 0);
-            if (ra) (void)zigz_ctx_set_option(ctx, "run_aware_mask", 0);
-            if (ra) (void)zigz_ctx_set_option(ctx, "cons_group_mask", 0);
-        }
-    } mask_reset{ctx_, small_domain_tables, run_aware != 0};
     if (witness)
         check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
                                       (size_t)1 << num_vars, num_vars, &guard.job));

@@ -34,3 +34,4 @@ HIP_ERROR = 101
 NOT_CANONICAL = 102
 INVALID_ARGUMENT = 103
 BAD_STATE = 104
+COMM_ERROR = 105

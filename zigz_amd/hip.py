@@ -124,6 +124,11 @@ class Context:
     def set_option(self, name, value):
         self.check(lib.zigz_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def get_option(self, name):
+        v = C.c_int64()
+        self.check(lib.zigz_ctx_get_option(self.h, name.encode(), C.byref(v)))
+        return v.value & 0xFFFFFFFFFFFFFFFF
+
     def stats(self):
         s = KernelStats()
         self.check(lib.zigz_ctx_get_stats(self.h, C.byref(s)))
@@ -223,6 +228,16 @@ class Context:
         fe = C.c_uint64()
         self.check(lib.zigz_dev_sumcheck_prove_sharded(self.h, vp(d_local), n_local, rank, world, allgather, user, rp, ptp,
                                                        C.byref(fe)))
+        return r[: 2 * nv].copy(), pt[:nv].copy(), fe.value
+
+    def dev_sumcheck_prove_rccl(self, d_local, n_local, comm):
+        """zigz_dev_sumcheck_prove_rccl: the same proof with a shard.RcclComm as the transport -- the partial block sums of
+        every radix stage are all-reduced in HBM on this context's stream, the tail all-gathered through the comm."""
+        nv = (n_local * comm.world).bit_length() - 1
+        r, rp = _out_u64(2 * nv)
+        pt, ptp = _out_u64(nv)
+        fe = C.c_uint64()
+        self.check(lib.zigz_dev_sumcheck_prove_rccl(self.h, vp(d_local), n_local, comm.h, rp, ptp, C.byref(fe)))
         return r[: 2 * nv].copy(), pt[:nv].copy(), fe.value
 
     # ---- Lasso

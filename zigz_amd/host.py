@@ -179,9 +179,9 @@ class Trace:
         """ONE proof over dist.get_world_size() GPUs, sharded by column (zigzh_prove_trace_sharded): every rank holds
         the same trace and a resident copy of the 43 columns, commits / opens its own block, and returns the complete
         proof (BorrowedProof; identical on every rank and to the unsharded proof)."""
-        from .shard import ShmComm
+        from .shard import ShmComm, RcclComm
         out, n = u8p(), C.c_size_t()
-        if isinstance(allgather, ShmComm):  # the built-in same-node transport: no torch / RCCL involved
+        if isinstance(allgather, (ShmComm, RcclComm)):  # a built-in transport (shared memory / native RCCL): no torch involved
             _check(lib.zigzh_prove_trace_sharded(self.h, ctx.h, vp(d_cols), stride, allgather.rank, allgather.world,
                                                  C.cast(allgather.hook, vp), allgather.user, C.byref(out), C.byref(n)))
             return BorrowedProof(out, n.value)

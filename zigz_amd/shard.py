@@ -174,12 +174,67 @@ class ShmComm:
             self.h = None
 
 
+class RcclComm:
+    """zigz_rccl_comm: RCCL as the exchange transport, bound natively (no torch in the loop).  `unique_id`: the 128 bytes of
+    RcclComm.unique_id() from ONE rank, distributed by the caller (torch.distributed.broadcast_object_list, a file, MPI ...).
+    `hook` / `user` are what the C entry points take as (allgather, user)."""
+
+    @staticmethod
+    def unique_id():
+        import ctypes as C
+        from . import _ffi, errors
+        buf = (C.c_uint8 * 128)()
+        rc = _ffi.lib.zigz_rccl_unique_id(buf)
+        if rc != 0:
+            raise errors.ZigzError(rc, _ffi.lib.zigz_status_name(rc).decode(), "zigz_rccl_unique_id")
+        return bytes(buf)
+
+    def __init__(self, device, unique_id, rank, world, max_bytes=1 << 16):
+        import ctypes as C
+        from . import _ffi, errors
+        h = _ffi.vp()
+        idb = (C.c_uint8 * 128).from_buffer_copy(unique_id)
+        rc = _ffi.lib.zigz_rccl_comm_create(device, idb, rank, world, max_bytes, C.byref(h))
+        if rc != 0:
+            raise errors.ZigzError(rc, _ffi.lib.zigz_status_name(rc).decode(), "zigz_rccl_comm_create")
+        self.h, self.rank, self.world = h, rank, world
+        self.hook = C.cast(_ffi.lib.zigz_rccl_allgather, _ffi.ALLGATHER_FN)
+        self.user = h
+
+    def all_gather(self, payload):
+        import ctypes as C
+        from . import _ffi
+        n = len(payload)
+        send = (C.c_uint8 * max(n, 1)).from_buffer_copy(bytes(payload) or b"\0")
+        recv = (C.c_uint8 * max(n * self.world, 1))()
+        rc = _ffi.lib.zigz_rccl_allgather(self.h, send, n, recv)
+        if rc != 0:
+            raise RuntimeError("zigz_rccl_allgather failed (%d)" % rc)
+        return [bytes(recv[r * n:(r + 1) * n]) for r in range(self.world)]
+
+    def all_reduce_u64(self, words):
+        import numpy as np
+        from . import _ffi
+        a = np.ascontiguousarray(words, dtype=np.uint64)
+        out = np.zeros_like(a)
+        rc = _ffi.lib.zigz_rccl_allreduce_u64(self.h, a.ctypes.data_as(_ffi.u64p), a.size, out.ctypes.data_as(_ffi.u64p))
+        if rc != 0:
+            raise RuntimeError("zigz_rccl_allreduce_u64 failed (%d)" % rc)
+        return out
+
+    def close(self):
+        if self.h:
+            from . import _ffi
+            _ffi.lib.zigz_rccl_comm_destroy(self.h)
+            self.h = None
+
+
 def sumcheck_prove_row_sharded_radix(ctx, d_local, n_local, dist, allgather=None):
     """SumcheckProver.prove (src/proofs/sumcheck_prover.zig:26-91) over a table sharded by rows (interleaved), radix
     form, orchestrated in C++ (zigz_dev_sumcheck_prove_sharded): 2-3 exchanges of <= 1024 u64 per proof through the
     all-gather hook, no per-round collective, no Python in the loop.  d_local: this rank's n_local elements in HBM
     (16-byte aligned).  Returns (rounds[2v], point[v], final_eval), identical on every rank and to the unsharded proof."""
-    if isinstance(allgather, ShmComm):
+    if isinstance(allgather, (ShmComm, RcclComm)):
         return ctx.dev_sumcheck_prove_sharded(d_local, n_local, allgather.rank, allgather.world, allgather.hook, allgather.user)
     cb = allgather or make_allgather(dist)
     return ctx.dev_sumcheck_prove_sharded(d_local, n_local, dist.get_rank(), dist.get_world_size(), cb)
@@ -194,7 +249,7 @@ def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
     world = dist.get_world_size() if dist is not None else 1
     rank = dist.get_rank() if dist is not None else 0
     comm_user = None
-    if isinstance(allgather, ShmComm):
+    if isinstance(allgather, (ShmComm, RcclComm)):
         cb, comm_user, world, rank = allgather.hook, allgather.user, allgather.world, allgather.rank
     else:
         cb = allgather or (make_allgather(dist) if world > 1 else _ffi.ALLGATHER_FN(lambda *a: 1))
