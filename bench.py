@@ -173,9 +173,11 @@ def cpu_baseline_child(nv, sample_cols):
         pass
     return ({
         "value": ns / total, "unit": "trace steps/s", "cores": 1, "kind": "port",
-        "sample": "%d of 43 columns at 2^%d through literal commit + 2 naive evals + recompute-on-open (%.1f s measured), "
-                  "scaled x43/%d; + the full sequential transcript of steps 4-5 (%d lookup absorptions) run for real (%.3f s "
-                  "measured); oracle/zigz_oracle.c, gcc -O2, 1 thread" % (sample_cols, nv, t_cols, sample_cols, num_lookups, t_tr),
+        "sample": "%d/43 columns at 2^%d: literal commit + 2 naive evals + open, x43/%d; + full transcript; oracle, gcc -O2, 1 thread"
+                  % (sample_cols, nv, sample_cols),
+        "sample_detail": "%d of 43 columns at 2^%d through literal commit + 2 naive evals + recompute-on-open (%.1f s measured), "
+                         "scaled x43/%d; + the full sequential transcript of steps 4-5 (%d lookup absorptions) run for real (%.3f s "
+                         "measured); oracle/zigz_oracle.c, gcc -O2, 1 thread" % (sample_cols, nv, t_cols, sample_cols, num_lookups, t_tr),
         "seconds_per_proof": total, "transcript_seconds": t_tr, "columns_seconds_scaled": t_cols * 43.0 / sample_cols,
         "host_cpu": model, "host_nproc": os.cpu_count(), "threads_used": 1})
 
@@ -191,7 +193,7 @@ def run_cpu_baseline(nv, sample_cols):
     except Exception as e:
         sys.stderr.write("bench.py: cpu_baseline child failed (%r); running it in this process\n" % (e,))
         r = cpu_baseline_child(nv, sample_cols)
-        r["sample"] += " (run inside the bench process: no child could be started)"
+        r["sample_detail"] += " (run inside the bench process: no child could be started)"
         return r
 
 
@@ -331,6 +333,16 @@ def main():
                          "n_gpus\n" % (args.gpus, world))
         return 2
 
+    # ---- rank placement: pin this process to the cores of its GPU's NUMA node BEFORE anything initialises HIP (the runtime's
+    # helper threads, the lanes' threads and the sponge servers all inherit the mask).  sysfs only; zigz_amd/placement.py is
+    # loaded as a plain file so that not even the package's libraries are open yet.
+    import importlib.util
+    _ps = importlib.util.spec_from_file_location("zigz_placement", os.path.join(ROOT, "zigz_amd", "placement.py"))
+    placement = importlib.util.module_from_spec(_ps)
+    _ps.loader.exec_module(placement)
+    pin = {"pinned": 0, "numa_node": -1, "why": "ZIGZ_BENCH_NO_PIN"} if os.environ.get("ZIGZ_BENCH_NO_PIN") else \
+        placement.pin_rank(local_rank)
+
     if args.dry_run:
         tok = 1.0
         if world > 1:
@@ -423,6 +435,13 @@ def main():
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
     B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers if servers else default_batch(world)))
+    hbm_free = None
+    if not shard and args.batch <= 0:  # a proof in flight holds ~3.5 GiB of HBM at 2^20 (trees, lists, witness): stay inside it
+        probe = zigz_amd.Context(local_rank)
+        hbm_free = probe.mem_info()[0]
+        probe.close()
+        per_lane = int(3.6 * (1 << 30) * (1 << max(args.nv - 20, 0)))
+        B = max(1, min(B, int(hbm_free * 0.92) // per_lane))
     blocking = B + servers + 2 > host_cpus() // max(world, 1)  # more threads than cores: wait for the GPU asleep, not spinning
     if os.environ.get("ZIGZ_BENCH_BLOCKING_SYNC"):
         blocking = os.environ["ZIGZ_BENCH_BLOCKING_SYNC"] == "1"
@@ -433,25 +452,46 @@ def main():
             blocking = False
 
     class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
-        def __init__(self, k):
+        def __init__(self, k, nv_l=None, prog=None):
+            self.nv = nv if nv_l is None else nv_l
+            self.N = 1 << self.nv
             self.ctx = zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
-            self.prog = programs.add_xor_loop((N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
-            self.trace = host.Trace(self.prog, 0x1000, None, 2 * N)  # [1/6] VM execution: outside the timed region
-            assert self.trace.num_vars == nv, (self.trace.num_vars, nv)
-            self.d_cols = self.ctx.dev_alloc(43 * N * 4)
+            self.prog = prog if prog is not None else \
+                programs.add_xor_loop((self.N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
+            self.trace = host.Trace(self.prog, 0x1000, None, 2 * self.N)  # [1/6] VM execution: outside the timed region
+            assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
+            self.d_cols = self.ctx.dev_alloc(43 * self.N * 4)
             self.trace.pin(self.ctx)  # page-locked trace records (48 B per step): uploads run at PCIe rate
-            self.trace.witness_to_device(self.ctx, self.d_cols, N)   # [2/6] witness resident in HBM before timing
+            self.trace.witness_to_device(self.ctx, self.d_cols, self.N)   # [2/6] witness resident in HBM before timing
             self.ctx.synchronize()
             self.proof = None
             self.up_ctx = None
             self.d_next = None
 
+        def retrace(self, prog):  # the same lane on another program of the same size (overwrites the resident witness)
+            self.prog = prog
+            self.trace = host.Trace(prog, 0x1000, None, 2 * self.N)
+            assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
+            self.trace.witness_to_device(self.ctx, self.d_cols, self.N)
+            self.ctx.synchronize()
+
+        def close(self):
+            if self.up_ctx is not None:
+                self.up_ctx.synchronize()
+                self.up_ctx.dev_free(self.d_next)
+                self.up_ctx.close()
+                self.up_ctx = None
+            if self.ctx is not None:
+                self.ctx.dev_free(self.d_cols)
+                self.ctx.close()
+                self.ctx = None
+
         def prove(self):
             if shard and dist is not None:
-                self.proof = self.trace.prove_sharded(self.ctx, self.d_cols, N, dist, allgather_hook)
+                self.proof = self.trace.prove_sharded(self.ctx, self.d_cols, self.N, dist, allgather_hook)
             else:
-                self.proof = self.trace.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
+                self.proof = self.trace.prove(self.ctx, self.d_cols, self.N, want_bytes="borrow")
             return self.ctx.stats(), host.last_timings()
 
         def prove_and_digest(self):  # self-check steps (untimed): SHA-256 of the proof, taken on the proving thread while
@@ -459,10 +499,6 @@ def main():
             r = self.prove()
             self.digest = hashlib.sha256(self.proof.tobytes()).hexdigest()
             return r
-
-        def prove_worst(self):  # the register-round-robin trace of the worst-case leg (resident in d_cols by then)
-            self.trace_w.prove(self.ctx, self.d_cols, N, want_bytes="borrow")
-            return self.ctx.stats(), host.last_timings()
 
         def upload_and_prove(self):  # PCIe-inclusive: one upload of the compact trace (48 B per step) + one run of the witness
             # kernels per proof, inside the loop -- pipelined as a service would: while this proof runs, the NEXT proof's trace
@@ -534,6 +570,9 @@ def main():
         l.ctx.enable_timing(True)
     dt, acc, phases = timed(args.steps)          # ---- THE timed region
     nproofs = args.steps * B
+    local_steps = float(sum(l.trace.num_steps for l in lanes))
+    trace_steps, trace_lookups, prog = lanes[0].trace.num_steps, lanes[0].trace.num_lookups, lanes[0].prog
+    proof = lanes[0].proof.tobytes()  # (the legs below reuse the borrowed buffers and, at the end, the lanes' traces)
 
     # ---- legs outside the timed region (same run, same resident data)
     extras = not args.no_extras and not shard
@@ -546,9 +585,9 @@ def main():
         if rank == 0:  # Prover.prove from program bytes: VM + compact trace upload + witness kernels + proof + serialisation
             host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
             t0 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(2):
                 host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
-            solo["from_program_ms"] = (time.perf_counter() - t0) / 3 * 1e3
+            solo["from_program_ms"] = (time.perf_counter() - t0) / 2 * 1e3
             t0 = time.perf_counter()
             host.Trace(lanes[0].prog, 0x1000, None, 2 * N)
             solo["vm_ms"] = (time.perf_counter() - t0) * 1e3
@@ -568,7 +607,7 @@ def main():
             run_step(Lane.prove_and_digest)
             # ... must be byte-identical under every other build (dense hashes every node of every tree)
             self_check["all_lanes_equal_under_" + mode] = [l.digest for l in lanes] == digests
-            ks = max(3, min(args.steps, 10))
+            ks = 3 if mode in ("cons", "struct", "regs", "all") else 2
             dtv, accv, _ = timed(ks)
             variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * B)}
         set_merkle_mode(args.merkle)
@@ -578,22 +617,26 @@ def main():
             raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
             kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
-        if args.merkle in ("cons", "struct", "regs", "all"):
-            # The run-aware register levels make the GPU time depend on the trace.  Its worst case by construction: a loop
-            # that writes 30 different registers in turn, so the <= N change points of the 31 register columns are spread
-            # evenly over all of them (tests/programs.py register_round_robin).  Same batch, same everything else; the lanes'
-            # witness buffers are overwritten, so this is the last leg that uses them.
-            lanes[0].proof = lanes[0].proof.tobytes()  # the borrowed buffer is reused by the proofs below
+        # The structure-aware levels make the GPU time depend on the trace, so the same batch also runs on three other traces
+        # (same lanes, same everything else; the lanes' witness buffers are overwritten: these are the last legs on them):
+        #   worst     the worst case BY CONSTRUCTION for the run-aware register levels: a loop that writes 30 different
+        #             registers in turn, so the <= N change points of the 31 register columns are spread evenly over all of them
+        #   straight  a program that never loops (~2^20 different instructions, each executed once): the content-addressed group
+        #             finds nothing and is dropped on the device, its columns are built from the tables / densely
+        #   mixed     BASELINE config 4's RV64IM mix (MUL / DIVU / REM / LD / SD / *W in a 12-step loop) at this size
+        import numpy as np
+
+        def other_trace(make_prog, steps_l):
             for k, l in enumerate(lanes):
-                l.trace_w = host.Trace(programs.register_round_robin((N - 2) // 31 - (rank * B + k)), 0x1000, None, 2 * N)
-                assert l.trace_w.num_vars == nv
-                l.trace_w.witness_to_device(l.ctx, l.d_cols, N)
-                l.ctx.synchronize()
-            run_step(Lane.prove_worst)
-            ks = max(3, min(args.steps, 10))
-            dtw, accw, _ = timed(ks, Lane.prove_worst)
-            pcie["worst"] = {"dt": dtw, "steps": ks, "perms": accw["keccak_permutations"] / (ks * B),
-                             "trace_steps": float(sum(l.trace_w.num_steps for l in lanes))}
+                l.retrace(make_prog(rank * B + k))
+            run_step()
+            dtl, accl, _ = timed(steps_l)
+            return {"dt": dtl, "steps": steps_l, "perms": accl["keccak_permutations"] / (steps_l * B),
+                    "trace_steps": float(sum(l.trace.num_steps for l in lanes))}
+        pcie["worst"] = other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3)
+        base = programs.straight_line_program(1000 + rank, int(0.95 * N))  # one program per rank, a different prefix per lane
+        pcie["straight"] = other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], 3)
+        pcie["mixed"] = other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3)
 
     # ---- N > 1, traces mode: also ONE proof per step sharded by column over the N ranks (the strong-scaling variant of
     # --mode shard), reported in the same line.  Exchanges go through the shared-memory hook (host-resident payloads of a
@@ -638,10 +681,30 @@ def main():
         except Exception:
             pass
 
-    local_steps = float(sum(l.trace.num_steps for l in lanes))
-    trace = lanes[0].trace
-    prog = lanes[0].prog
-    proof = lanes[0].proof
+    # ---- the other trace sizes of the north-star (2^16 .. 2^24), same bench trace, same build: small step counts, after the
+    # main lanes have given their HBM back (a 2^24 proof in flight holds ~55 GiB)
+    sweep = {}
+    if extras:
+        for l in lanes:
+            l.close()
+        lanes_main, lanes = lanes, []
+        probe = zigz_amd.Context(local_rank)
+        free_now = probe.mem_info()[0]
+        probe.close()
+        for nv_s, steps_s in ((16, 10), (22, 3), (24, 2)):
+            if nv_s == nv:
+                continue
+            per_lane = int(3.6 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+            nl = max(1, min(B, int(free_now * 0.85) // per_lane))
+            ls = [Lane(k, nv_s) for k in range(nl)]
+            run_step(which=ls)
+            dts_, _, _ = timed(steps_s, which=ls)
+            sweep[nv_s] = {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
+            for l in ls:
+                l.close()
+    else:
+        lanes_main = lanes
+
     if torch is not None:
         def allmax(x):
             t = torch.tensor([x], dtype=torch.float64, device=tdev)
@@ -656,9 +719,13 @@ def main():
             pcie["dt"] = allmax(pcie["dt"])
             for vv in pcie.get("variants", {}).values():
                 vv["dt"] = allmax(vv["dt"])
-            if "worst" in pcie:
-                pcie["worst"]["dt"] = allmax(pcie["worst"]["dt"])
-                pcie["worst"]["trace_steps"] = allsum(pcie["worst"]["trace_steps"])
+            for leg in ("worst", "straight", "mixed"):
+                if leg in pcie:
+                    pcie[leg]["dt"] = allmax(pcie[leg]["dt"])
+                    pcie[leg]["trace_steps"] = allsum(pcie[leg]["trace_steps"])
+        for sv in sweep.values():
+            sv["dt"] = allmax(sv["dt"])
+            sv["trace_steps"] = allsum(sv["trace_steps"])
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
@@ -666,102 +733,133 @@ def main():
         total_steps = local_steps
 
     if rank == 0:
-        proof = proof if isinstance(proof, bytes) else proof.tobytes()
         assert host.verify(proof, prog) == "Accept"
         ic = isa_counts()
-        perms_leaves = acc["keccak_leaves_perms"]
-        # dominant kernel: k_keccak_leaves.  Per-launch kernel timestamps, all launches of the timed region
-        tr_ach = perms_leaves * ic["leaves"] / (acc["keccak_leaves_us"] / 1e6) / 1e12 if acc.get("keccak_leaves_us") else 0.0
-        keccak_us = acc["keccak_leaves_us"] + acc["keccak_level_wide_us"] + acc["keccak_level_small_us"]
-        sa = solo["acc"] if solo else acc  # kernel-time shares from the single-proof leg (no overlap between proofs)
-        share = sa["keccak_leaves_us"] / max(sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] +
-                                            sa["small_domain_us"] + sa["run_aware_us"] + sa["eval_us"], 1e-9)
-        hash_share = (sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] + sa["run_aware_us"]) / max(
-            sa["keccak_leaves_us"] + sa["keccak_level_wide_us"] + sa["keccak_level_small_us"] + sa["small_domain_us"] +
-            sa["run_aware_us"] + sa["eval_us"], 1e-9)
-        roof = {
-            "kernel": "k_keccak_leaves (SHA3-256 leaf hashes: 1 Keccak-f[1600] = %d VALU instructions per 4 B read + 32 B written), "
-                      "measured back to back over 43 x 2^%d leaves.  The same permutation code is every hashing kernel of a proof "
-                      "(k_keccak_leaves %.0f %% of the kernel time of a lone proof under --merkle %s; with k_keccak_level, "
-                      "k_keccak_top and the run-aware levels -- k_runs_flags / _hash / _fill -- %.0f %%)"
-                      % (ic["leaves"], nv, 100.0 * share, args.merkle, 100.0 * hash_share),
-            "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
-            "valu_instr_per_hash": ic["leaves"],
-            "timed_region_achieved": tr_ach, "timed_region_frac": tr_ach / VALU_PEAK_TOPS,
-            "timed_region_avg_launch_us": acc["keccak_leaves_us"] / nproofs,
-            "timed_region_note": "launches of %d concurrent proofs share the chip: per-launch durations stretch by the overlap"
-                                 % B if B > 1 else "one proof at a time",
-            "traffic": None,
+        # ---- where the kernel time of the TIMED REGION went, by class (every launch carries its own begin / end timestamps
+        # in timing mode; concurrent proofs share the chip, so the per-launch durations are stretched by the overlap)
+        classes = {
+            "level_hash": acc.get("list_hash_us", 0.0),       # k_level_hash: the list-driven levels 0 .. v - 8
+            "structure": acc.get("structure_us", 0.0),        # k_runs_stage + k_cons_*: which nodes are hashed (no hashing)
+            "top": acc.get("top_us", 0.0),                    # k_merkle_top: the last 8 levels
+            "dense": acc["keccak_leaves_us"] + acc["keccak_level_wide_us"] + acc["keccak_level_small_us"],
+            "tables": acc["small_domain_us"],                 # k_keccak_small_l01
+            "eval": acc["eval_us"],                           # k_eq_weights + k_radix_fold + ...
         }
-        tpath = os.path.join(ROOT, "profiles", "keccak_traffic.json")
+        kernel_us = max(sum(classes.values()), 1e-9)
+        share = {k: v / kernel_us for k, v in classes.items()}
+
+        def valu_frac(perms, instr, us):
+            return perms * instr / (us / 1e6) / 1e12 / VALU_PEAK_TOPS if us else None
+        lh_perms = acc.get("list_hash_perms", 0)
+        lh_launches = (nv - 7) * nproofs                      # one k_level_hash launch per level 0 .. v - 8 and proof
+        dense_perms = acc["keccak_leaves_perms"] + acc["keccak_level_wide_perms"] + acc["keccak_level_small_perms"]
+        traffic = traffic_alg = None
+        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
         if os.path.exists(tpath):
             try:
-                tj = json.load(open(tpath))
-                roof["traffic"] = tj["hbm_bytes_per_hash"] * perms_leaves / nproofs  # per launch, like `achieved`
-                roof["traffic_algorithmic"] = 36.0 * perms_leaves / nproofs
-                roof["traffic_source"] = ("profiles/keccak_traffic.json: HBM bytes per hash from the rocprofv3 FETCH_SIZE / WRITE_SIZE "
-                                          "passes of `bench.py --kernels` x the hashes of one launch (not re-measured in this run)")
+                tj = json.load(open(tpath))["k_level_hash"]
+                traffic = tj["hbm_bytes_per_hash"] * lh_perms / max(lh_launches, 1)      # per launch, like `achieved`
+                traffic_alg = tj["algorithmic_bytes_per_hash"] * lh_perms / max(lh_launches, 1)
             except Exception:
                 pass
-        if solo:
+        if share["level_hash"] >= share["dense"]:
+            roof = {"kernel": "k_level_hash", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
+                    "achieved": lh_perms * ic["level_hash"] / (classes["level_hash"] / 1e6) / 1e12 if classes["level_hash"] else 0.0,
+                    "traffic": traffic, "traffic_algorithmic": traffic_alg,
+                    "avg_launch_us": classes["level_hash"] / max(lh_launches, 1), "launches": lh_launches,
+                    "hashes_per_launch": lh_perms / max(lh_launches, 1), "valu_instr_per_hash": ic["level_hash"]}
+        else:  # a dense build (--merkle dense / tables): the dense leaf + level kernels dominate
+            roof = {"kernel": "k_keccak_leaves+k_keccak_level", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
+                    "achieved": dense_perms * ic["level"] / (classes["dense"] / 1e6) / 1e12 if classes["dense"] else 0.0,
+                    "traffic": None, "traffic_algorithmic": None,
+                    "avg_launch_us": classes["dense"] / max(nproofs, 1), "launches": nproofs,
+                    "hashes_per_launch": dense_perms / max(nproofs, 1), "valu_instr_per_hash": ic["level"]}
+        roof["frac"] = roof["achieved"] / VALU_PEAK_TOPS
+        roof = {k: roof[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "traffic", "traffic_algorithmic",
+                                     "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash")}
+        roof["level_hash_share"] = share["level_hash"]
+        roof["structure_share"] = share["structure"]
+        roof["top_share"] = share["top"]
+        roof["eval_share"] = share["eval"]
+        roof["top_frac"] = valu_frac(acc.get("top_perms", 0), ic["top"], classes["top"])
+        roof["eval_hbm_frac"] = ((acc["bind_vec_bytes"] / 1e9) / (acc["bind_vec_us"] / 1e6) / HBM_PEAK_GBS) if acc.get("bind_vec_us") else None
+        if solo:  # the same class with one proof on the GPU at a time (no overlap between proofs)
             a = solo["acc"]
-            # (with the default build no column is hashed densely from the leaves any more: no k_keccak_leaves launch in a proof)
-            ach = a["keccak_leaves_perms"] * ic["leaves"] / (a["keccak_leaves_us"] / 1e6) / 1e12 if a["keccak_leaves_us"] else None
-            roof.update({
-                "in_proof_achieved": ach, "in_proof_frac": ach / VALU_PEAK_TOPS if ach else None,
-                "in_proof_note": "the %d k_keccak_leaves launches of the single-proof leg (one proof on the GPU at a time: every "
-                                 "build starts after ~20 ms of idle GPU while the host absorbs the transcript)" % solo["n"],
-                "in_proof_avg_launch_us": a["keccak_leaves_us"] / solo["n"],
-                "in_proof_gperm_per_s": (a["keccak_leaves_perms"] / 1e9 / (a["keccak_leaves_us"] / 1e6)) if a["keccak_leaves_us"] else None,
-                "level_wide_gperm_per_s": (a["keccak_level_wide_perms"] / 1e9 / (a["keccak_level_wide_us"] / 1e6))
-                if a["keccak_level_wide_us"] else None,
-                "level_wide_frac": (a["keccak_level_wide_perms"] * ic["level"] / (a["keccak_level_wide_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
-                if a["keccak_level_wide_us"] else None,
-                "level_small_gperm_per_s": (a["keccak_level_small_perms"] / 1e9 / (a["keccak_level_small_us"] / 1e6))
-                if a["keccak_level_small_us"] else None,
-                "merkle_build_ms": a["merkle_build_us"] / solo["n"] / 1e3,
-                "small_domain_lookup_us": a["small_domain_us"] / solo["n"],
-                "run_aware_levels_us": a["run_aware_us"] / solo["n"],
-                "run_aware_hashed": a["run_aware_hashed"] / solo["n"],
-                # the other hashing kernels of a lone proof, priced the same way (permutations x VALU instructions per hash /
-                # kernel time / peak): small dense level launches, and the run-aware levels with their flag passes included
-                "level_small_frac": (a["keccak_level_small_perms"] * ic["level"] / (a["keccak_level_small_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
-                if a["keccak_level_small_us"] else None,
-                "run_aware_levels_gperm_per_s": (a["run_aware_hashed"] / 1e9 / (a["run_aware_us"] / 1e6)) if a["run_aware_us"] else None,
-                "run_aware_levels_frac": (a["run_aware_hashed"] * ic["level"] / (a["run_aware_us"] / 1e6) / 1e12 / VALU_PEAK_TOPS)
-                if a["run_aware_us"] else None,
-                "merkle_build_gperm_per_s": a["keccak_permutations"] / 1e9 / (a["merkle_build_us"] / 1e6),
-                "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1),
-                "eval_fold_hbm_frac": (a["bind_vec_bytes"] / 1e9) / (a["bind_vec_us"] / 1e6) / HBM_PEAK_GBS if a["bind_vec_us"] else None,
-            })
-        # all Keccak kernels of the timed region against its wall time: a lower bound on what the chip sustained while the
-        # bench ran (idle gaps and the non-Keccak kernels count against it)
-        agg = acc["keccak_permutations"] * 0.5 * (ic["leaves"] + ic["level"]) / dt / 1e12
-        roof["timed_region_aggregate_achieved"] = agg
-        roof["timed_region_aggregate_frac"] = agg / VALU_PEAK_TOPS
+            roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
+        # all Keccak work of the region over its wall time: a lower bound on what the chip sustained while the bench ran
+        roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * ic["level_hash"] / dt / 1e12 / VALU_PEAK_TOPS
         kl = kern.get("k_keccak_leaves[43x2^%d]" % nv) if kern else None
-        if kl:  # the kernel itself: back-to-back launches on 43 x 2^nv leaves in this process, kernel timestamps
-            roof.update({"achieved": kl["achieved_Tinstr_s"], "frac": kl["frac"], "avg_launch_us": kl["avg_us"],
-                         "gperm_per_s": kl["gperm_per_s"], "hbm_frac": kl["hbm_frac"], "launches": kl["launches"],
-                         "measured": "kernel timestamps of %d back-to-back k_keccak_leaves launches over 43 x 2^%d leaves in this "
-                                     "process after the timed region (the launches of `bench.py --kernels`; "
-                                     "profiles/r02_kernels_kernel_stats.csv)" % (kl["launches"], nv)})
-        elif solo:
-            roof.update({"achieved": roof["in_proof_achieved"], "frac": roof["in_proof_frac"], "measured": roof["in_proof_note"]})
-        else:
-            roof.update({"achieved": tr_ach, "frac": tr_ach / VALU_PEAK_TOPS, "measured": "timed region"})
-        if kern:  # the north-star MLE kernels, cold-HBM launches in this run (flat keys: the driver keeps scalars only)
-            for key, name in (("bind", "k_bind_vec[43x2^%d]" % nv), ("bind_sums", "k_bind_vec_sums[43x2^%d]" % nv),
-                              ("half_sums", "k_half_sums[43x2^%d]" % nv), ("radix_fold", "k_radix_fold[43x2^%d]" % nv),
-                              ("bind_2p24", "k_bind_vec[1x2^24]"), ("bind_sums_2p24", "k_bind_vec_sums[1x2^24]"),
-                              ("half_sums_2p24", "k_half_sums[1x2^24]"), ("block_sums_2p24", "k_block_sums[1x2^24]")):
+        if kl:  # what the permutation code reaches back to back on 43 x 2^nv leaves in this process: the ceiling of its mix
+            roof["permutation_ceiling_frac"] = kl["frac"]
+        if kern:  # the north-star MLE kernels, cold-HBM launches in this run
+            for key, name in (("bind", "k_bind_vec[43x2^%d]" % nv), ("half_sums", "k_half_sums[43x2^%d]" % nv),
+                              ("radix_fold", "k_radix_fold[43x2^%d]" % nv)):
                 if name in kern:
                     roof[key + "_hbm_frac"] = kern[name]["frac"]
-                    roof[key + "_GBs"] = kern[name]["achieved_GBs"]
-                    roof[key + "_avg_us"] = kern[name]["avg_us"]
-            roof["mle_kernels_note"] = ("k_bind_vec = partialEval (6 B per table element), k_half_sums / k_block_sums = "
-                                        "roundPolynomial (4 B), cold-HBM launches (1 GiB read sweep before each), kernel "
-                                        "timestamps, same process right after the timed region")
+
+        def rate(leg):
+            return leg["trace_steps"] * leg["steps"] / leg["dt"]
+        cfg = {
+            "workload": "synthetic RV64I ADD/XOR loop, 2^%d trace, 43 columns in HBM; full Prover.prove hot path; %d proofs/GPU/step" % (nv, B),
+            "trace_steps": trace_steps, "traces_per_step_per_gpu": B, "sponge_servers": servers,
+            "merkle_build": args.merkle, "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
+            "ms_per_proof_per_gpu": dt / nproofs * 1e3,
+            "host_cpus_available": host_cpus(), "cpus_pinned": pin.get("pinned", 0),
+            "parallelism": ("1 proof/step, columns sharded over %d GPUs (strong)" % world) if shard else
+                           ("independent traces: %d GPU(s) x %d proofs in flight, no data-path collective" % (world, B)),
+            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+            "commit_begin_ms": phases.get("commit_begin", 0.0) / nproofs * 1e3,
+        }
+        detail = {"merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle], "lookup_steps": trace_lookups,
+                  "blocking_sync": bool(blocking), "pin": pin, "hbm_free_at_start": hbm_free, "proof_bytes": len(proof),
+                  "host_transcripts": ("%d sponge-server threads per GPU, each advancing up to 8 proofs' transcripts in lock "
+                                       "step (8-way AVX-512 Keccak-f); the proofs' own threads sleep meanwhile" % servers)
+                                      if servers else "every proof absorbs its transcript on its own host thread",
+                  "kernel_time_shares_timed_region": share,
+                  "kernel_us_per_proof_timed_region": {k: v / nproofs for k, v in classes.items()}}
+        if solo:
+            cfg["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
+            a = solo["acc"]
+            detail["single_proof"] = {
+                "steps_per_s": trace_steps * solo["n"] / solo["dt"], "merkle_build_ms": a["merkle_build_us"] / solo["n"] / 1e3,
+                "structure_us": a.get("structure_us", 0.0) / solo["n"], "level_hash_us": a.get("list_hash_us", 0.0) / solo["n"],
+                "top_us": a.get("top_us", 0.0) / solo["n"], "eval_us": a["eval_us"] / solo["n"],
+                "level_hash_gperm_per_s": (a.get("list_hash_perms", 0) / 1e9 / (a["list_hash_us"] / 1e6)) if a.get("list_hash_us") else None,
+                "eval_fold_avg_launch_us": a["bind_vec_us"] / max(a["bind_vec_launches"], 1)}
+            if "from_program_ms" in solo:
+                cfg["from_program_bytes_ms"] = solo["from_program_ms"]  # one Prover.prove incl. VM execution
+                detail["single_proof"]["vm_ms"] = solo["vm_ms"]
+        if pcie:
+            cfg["pcie_inclusive_value"] = total_steps * args.steps / pcie["dt"]  # trace upload + witness kernels inside the loop
+            if "worst" in pcie:
+                cfg["register_worst_case_value"] = rate(pcie["worst"])
+                cfg["straight_line_value"] = rate(pcie["straight"])
+                cfg["config4_mixed_value"] = rate(pcie["mixed"])
+                detail["other_traces_keccak_permutations_per_proof"] = {k: pcie[k]["perms"] for k in ("worst", "straight", "mixed")}
+            if pcie.get("variants"):
+                if "dense" in pcie["variants"]:
+                    vv = pcie["variants"]["dense"]
+                    cfg["dense_merkle_value"] = total_steps * vv["steps"] / vv["dt"]
+                detail["merkle_variants"] = {
+                    m: {"value": total_steps * vv["steps"] / vv["dt"], "keccak_permutations_per_proof": vv["perms"]}
+                    for m, vv in pcie["variants"].items()}
+            if pcie.get("self_check"):
+                cfg["self_check_ok"] = bool(all(pcie["self_check"].values()))
+                detail["self_check"] = dict(pcie["self_check"], note="SHA-256 of every lane's 2^%d proof: identical under every "
+                                            "Merkle build, and lane 0 alone (single-state transcript code) vs in the batch "
+                                            "(sponge service)" % nv)
+        for nv_s, sv in sorted(sweep.items()):
+            cfg["value_nv%d" % nv_s] = rate(sv)
+            detail["value_nv%d_lanes" % nv_s] = sv["lanes"]
+        if shard_leg:
+            for k, v in shard_leg.items():
+                detail["one_proof_over_all_gpus_" + k] = v
+            if "ms_per_proof" in shard_leg:
+                cfg["one_proof_over_all_gpus_ms"] = shard_leg["ms_per_proof"]
+        if kern:
+            detail["kernel_leg"] = {k: {"frac": v["frac"], "avg_us": v["avg_us"]} for k, v in kern.items()}
+        detail["host_phase_ms_per_proof"] = {k: v / nproofs * 1e3 for k, v in phases.items()}
+        detail["host_keccak"] = zigz_amd._ffi.lib.zigz_host_keccak_impl().decode()
         out = {
             "metric": "trace steps/sec proved (BabyBear, 2^%d RV64I trace)" % nv,
             "value": total_steps * args.steps / dt,
@@ -770,88 +868,16 @@ def main():
             "ms_per_step": dt / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong" if shard else "weak", "vs_baseline": None,
             "dtype": "u32", "data": "synthetic",
-            "config": {"workload": "synthetic RV64I ADD/XOR loop, 2^%d trace, 43 witness columns resident in HBM; full "
-                                   "Prover.prove hot path incl. Fiat-Shamir transcript and ZIGZ v1 serialisation; "
-                                   "%d independent traces (proofs) per GPU per step" % (nv, B),
-                       "trace_steps": trace.num_steps, "lookup_steps": trace.num_lookups, "proof_bytes": len(proof),
-                       "merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle],
-                       "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
-                       "traces_per_step_per_gpu": B, "host_cpus_available": host_cpus(),
-                       "sponge_servers": servers, "blocking_sync": bool(blocking), "ms_per_proof_per_gpu": dt / nproofs * 1e3,
-                       "host_transcripts": ("%d sponge-server threads per GPU, each advancing up to 8 proofs' transcripts in lock "
-                                            "step (8-way AVX-512 Keccak-f); the proofs' own threads sleep meanwhile" % servers)
-                                           if servers else "every proof absorbs its transcript on its own host thread",
-                       "parallelism": ("ONE proof per step, its 43 columns sharded over %d GPU(s); strong scaling, bounded by the "
-                                       "sequential host transcript every rank replays" % world) if shard else
-                                      ("independent-trace throughput: %d GPU(s) x %d concurrent proofs, one rank per GPU, no "
-                                       "data-path collective (one proof does not get faster with more GPUs: see --mode shard)"
-                                       % (world, B)),
-                       "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none"},
+            "config": cfg,
             "roofline": roof,
         }
-        if solo:
-            out["config"]["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
-            out["config"]["single_proof_steps_per_s"] = trace.num_steps * solo["n"] / solo["dt"]
-            if "from_program_ms" in solo:
-                out["config"]["from_program_bytes_ms"] = solo["from_program_ms"]  # one Prover.prove incl. VM execution
-                out["config"]["vm_ms"] = solo["vm_ms"]
-        if shard_leg:
-            for k, v in shard_leg.items():
-                out["config"]["one_proof_over_all_gpus_" + k] = v
-            out["config"]["one_proof_over_all_gpus_note"] = ("strong scaling: ONE 2^%d proof per step, its 43 columns sharded over the "
-                                                             "%d ranks (two all-gathers per proof through the shared-memory hook); "
-                                                             "bounded by the sequential host transcript every rank replays" % (nv, world))
-        if pcie:
-            out["config"]["pcie_inclusive_value"] = total_steps * args.steps / pcie["dt"]
-            out["config"]["pcie_inclusive_ms_per_step"] = pcie["dt"] / args.steps * 1e3
-            out["config"]["pcie_inclusive_note"] = ("same batch, but every proof first uploads its trace over PCIe and runs the "
-                                                    "witness kernels inside the loop, one proof ahead on a second stream (never "
-                                                    "reported as value)")
-            if pcie.get("self_check"):
-                out["config"]["self_check"] = dict(pcie["self_check"], note="SHA-256 of every lane's 2^%d proof: identical under every "
-                                                   "Merkle build, and lane 0 alone (single-state transcript code) vs in the batch "
-                                                   "(sponge service)" % nv)
-            if pcie.get("variants"):
-                out["config"]["merkle_variants"] = {
-                    m: {"value": total_steps * vv["steps"] / vv["dt"], "keccak_permutations_per_proof": vv["perms"]}
-                    for m, vv in pcie["variants"].items()}
-            if "worst" in pcie:
-                w = pcie["worst"]
-                out["config"]["register_worst_case_value"] = w["trace_steps"] * w["steps"] / w["dt"]
-                out["config"]["register_worst_case_keccak_permutations_per_proof"] = w["perms"]
-                out["config"]["register_worst_case_note"] = (
-                    "the same batch on the trace that is worst for the run-aware register levels: a loop writing 30 different "
-                    "registers in turn (each register column changes every 31 steps; tests/programs.py register_round_robin)")
-                out["config"]["merkle_variants_note"] = ("the same batch under the other Merkle builds of --merkle (identical "
-                                                         "proofs; cons = default, struct = without the content-addressed group, regs = registers only, all = every column run-aware, "
-                                                         "tables = small-domain tables only, dense = every node hashed)")
-        out["kernels"] = {"timed_region": {
-            "merkle_build_ms_per_proof": acc["merkle_build_us"] / nproofs / 1e3,
-            "keccak_leaves_ms_per_proof": acc["keccak_leaves_us"] / nproofs / 1e3,
-            "keccak_level_wide_ms_per_proof": acc["keccak_level_wide_us"] / nproofs / 1e3,
-            "keccak_level_small_ms_per_proof": acc["keccak_level_small_us"] / nproofs / 1e3,
-            "eval_ms_per_proof": acc["eval_us"] / nproofs / 1e3,
-            "small_domain_lookup_ms_per_proof": acc["small_domain_us"] / nproofs / 1e3,
-            "run_aware_levels_ms_per_proof": acc["run_aware_us"] / nproofs / 1e3,
-            "run_aware_hashed_per_proof": acc["run_aware_hashed"] / nproofs,
-            "run_aware_dense_nodes_per_proof": acc["run_aware_dense_nodes"] / nproofs,
-            "small_domain_fallback_waves": acc["small_domain_fallback_waves"],
-            "host_phase_ms_per_proof": {k: v / nproofs * 1e3 for k, v in phases.items()},
-            "gpu_busy_keccak_gperm_per_s": (acc["keccak_permutations"] / 1e9) / dt},
-            "host_keccak": zigz_amd._ffi.lib.zigz_host_keccak_impl().decode()}
-        # (the per-launch details of the kernel leg are what `bench.py --kernels` prints; the fractions are flat keys of
-        # `roofline` above)
         if cpu is not None:
             out["cpu_baseline"] = cpu
+        out["detail"] = detail
         emit(json.dumps(out))
     pool.shutdown()
-    for l in lanes:
-        if l.up_ctx is not None:
-            l.up_ctx.synchronize()
-            l.up_ctx.dev_free(l.d_next)
-            l.up_ctx.close()
-        l.ctx.dev_free(l.d_cols)
-        l.ctx.close()
+    for l in lanes_main:
+        l.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

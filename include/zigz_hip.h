@@ -92,6 +92,8 @@ zigz_status zigz_ctx_synchronize(zigz_ctx *ctx);
 /* Device memory for callers without their own allocator (hipMalloc / hipFree). */
 zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out);
 zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr);
+/* free / total HBM of the context's device (hipMemGetInfo): a service sizes its number of proofs in flight from it */
+zigz_status zigz_dev_mem_info(zigz_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* canonical u64 host -> packed u32 device (validates < p), and back */
 zigz_status zigz_dev_upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out);
 zigz_status zigz_dev_download_u64(zigz_ctx *ctx, const uint32_t *d_in, size_t n, uint64_t *h_out);

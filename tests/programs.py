@@ -118,3 +118,27 @@ def random_program(rng, n_insts=60):
         else:
             words.append((int(rng.integers(0, 1 << 20)) << 12) | (rd << 7) | (0x17 if rng.integers(0, 2) else 0x37))
     return _pack(words)
+
+
+def straight_line_program(seed, n_insts):
+    """A program that never loops: n_insts random RV64IM instructions over all 31 registers (OP, OP-IMM, M extension, LUI,
+    SD / LD at small addresses off x0), each executed exactly once.  Vectorised (a 2^20-step trace takes ~0.1 s to
+    generate); num_steps = n_insts.  The worst case for the content-addressed group (nothing repeats) and a hard one for the
+    run-aware register levels (one of 31 registers changes at almost every step)."""
+    import numpy as np
+    rng = np.random.default_rng(seed)
+    kind = rng.integers(0, 6, n_insts)
+    rd, rs1, rs2 = (rng.integers(1, 32, n_insts) for _ in range(3))
+    f3 = rng.integers(0, 8, n_insts)
+    imm = rng.integers(0, 1 << 12, n_insts)
+    sh = np.where(f3 == 1, imm & 63, np.where(f3 == 5, (imm & 63) | (rng.integers(0, 2, n_insts) << 10), imm))
+    off = rng.integers(0, 32, n_insts) * 8
+    w = np.select(
+        [kind == 0, kind == 1, kind == 2, kind == 3, kind == 4],
+        [(rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x33,                       # OP, funct7 = 0
+         (sh << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x13,                        # OP-IMM
+         (1 << 25) | (rs2 << 20) | (rs1 << 15) | (f3 << 12) | (rd << 7) | 0x33,           # MUL .. REMU
+         (rng.integers(0, 1 << 20, n_insts) << 12) | (rd << 7) | 0x37,                    # LUI
+         ((off >> 5) << 25) | (rs2 << 20) | (3 << 12) | ((off & 31) << 7) | 0x23],        # SD rs2, off(x0)
+        default=(off << 20) | (3 << 12) | (rd << 7) | 0x03)                               # LD rd, off(x0)
+    return w.astype("<u4").tobytes()

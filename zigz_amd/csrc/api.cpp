@@ -279,6 +279,12 @@ extern "C" zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out)
     HIPCHK(ctx, hipMalloc(d_out, bytes ? bytes : 16));
     return ZIGZ_OK;
 }
+extern "C" zigz_status zigz_dev_mem_info(zigz_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !free_bytes || !total_bytes) return ZIGZ_ERR_INVALID_ARGUMENT;
+    HIPCHK(ctx, hipMemGetInfo(free_bytes, total_bytes));
+    return ZIGZ_OK;
+}
 extern "C" zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr) {
     ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;

@@ -124,6 +124,12 @@ class Context:
     def set_option(self, name, value):
         self.check(lib.zigz_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def mem_info(self):
+        """(free, total) bytes of HBM on this context's device"""
+        f, t = C.c_size_t(), C.c_size_t()
+        self.check(lib.zigz_dev_mem_info(self.h, C.byref(f), C.byref(t)))
+        return f.value, t.value
+
     def get_option(self, name):
         v = C.c_int64()
         self.check(lib.zigz_ctx_get_option(self.h, name.encode(), C.byref(v)))
