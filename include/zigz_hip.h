@@ -390,6 +390,9 @@ typedef struct zigz_kernel_stats {
     uint64_t list_hash_perms;
     double top_us;
     uint64_t top_perms;
+    /* builds that zigz_commit_roots had to repeat on this context because a list of the structure-aware levels ran out of the
+     * room learnt from earlier builds (or the group was dropped and its columns had no slabs): a running count */
+    uint64_t rebuilds;
 } zigz_kernel_stats;
 /* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
  * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per

@@ -23,6 +23,12 @@ using namespace zk;
 enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_CONS, WS_CONSMETA, WS_SLOTS };
 
 constexpr int KEV_MAX = 72;
+struct ListCaps {
+    size_t npad;
+    unsigned rn, gn;
+    unsigned r[RUN_MAX_LEVELS], g[RUN_MAX_LEVELS];  // entries per sub-list and level
+    bool g_slabs;  // this context's traces made the group be dropped: give its columns slabs up front
+};
 struct zigz_ctx {
     int device;
     hipStream_t own_stream;
@@ -67,6 +73,7 @@ struct zigz_ctx {
     unsigned cons_gen;
     // what the last build asked for; turned into stats when its counters have arrived (zigz_commit_roots)
     uint64_t build_cons_hinted, build_cons_levels_nodes, build_cons_sd, build_top_perms;
+    ListCaps caps;  // room for the lists of the structure-aware levels, learnt from earlier builds (caps_for)
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
@@ -211,7 +218,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
         fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTRS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_count, RUN_CTRS * 8)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
-        fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + 64, hipHostMallocDefault)))
+        fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
@@ -1190,12 +1197,31 @@ extern "C" zigz_status zigz_sumcheck_prove_interactive(zigz_ctx *ctx, const uint
 }
 
 // ------------------------------------------------------------------ Merkle
-// builds all levels of `ncols` trees (leaf hashes + level merges), asynchronous on the stream
-// run_meta != nullptr: the caller keeps the trees only as long as the context's WS_RUNMETA workspace stays untouched (a
-// commit job), so the copies of the run-aware levels are left virtual and *run_meta describes how to resolve them; nullptr:
-// every digest is written (single trees that outlive the call, tests that compare whole trees)
+// How much room the lists (and the digests stored in list order) of the structure-aware levels get: learnt from what the
+// context's previous builds needed, not sized for the worst case -- a build that runs out says so and is repeated with more
+// (zigz_commit_roots), which costs one extra build the first time a context meets a new kind of trace.
+static void caps_for(zigz_ctx *ctx, size_t npad, unsigned rn, unsigned gn) {
+    ListCaps &c = ctx->caps;
+    if (c.npad == npad && c.rn == rn && c.gn == gn) return;
+    c.npad = npad;
+    c.rn = rn;
+    c.gn = gn;
+    c.g_slabs = false;
+    const LevelLists rw = runs_lists(npad, rn ? rn : 1), gw = cons_lists(npad);
+    for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) {
+        c.r[l] = l <= rw.top ? (rw.cap[l] / 8 > 256 ? rw.cap[l] / 8 : 256) : 0;  // an eighth of "every node hashed"
+        c.g[l] = l <= gw.top ? 256 : 0;                                           // 8192 distinct nodes per level
+    }
+}
+
+// Builds all levels of `ncols` trees, asynchronously on the stream.
+// ref != nullptr (a commit job): the digests of the list-built levels stay in list order (TreeRef: stores), only densely
+//   built columns get node-addressed slabs (taken from WS_TREE); *ref describes where everything is and stays valid while
+//   the context's WS_RUNMETA / WS_CONSMETA / WS_TREE workspaces are untouched -- until the job ends.
+// ref == nullptr, or option "run_aware_materialize": every digest of every tree is written into node-addressed slabs
+//   (d_slab if given: single trees that outlive the call; else WS_TREE), one per column.
 static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
-                               uint8_t *d_tree, size_t ncols, bool record = false, RunMeta *run_meta = nullptr) {
+                               uint8_t *d_slab, size_t ncols, bool record = false, TreeRef *ref = nullptr) {
     const unsigned height = log2_floor(npad);
     const size_t stride = tree_nodes(npad);
     ctx->stats.small_domain_columns = 0;
@@ -1250,15 +1276,45 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             if (kd == 3 && sd_ok && ((ctx->small_domain_mask >> c) & 1)) GS.c[GS.n++] = (uint8_t)c;
         }
     const bool lists = R.n || G.n;
-    const bool virt = run_meta != nullptr && !ctx->run_aware_materialize;  // copies / non-representatives / table leaves unwritten
-    if (H.n == 0 && R.n == 0 && G.n == 0) {
-        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
-    } else if (D.n) {
-        launch_keccak_leaves(d_vals, val_stride, n_values, npad, d_tree, stride, ncols, ctx->stream,
-                             stamp(0, (uint64_t)D.n * npad), &D);
+    const bool whole = ref == nullptr || ctx->run_aware_materialize;  // every digest into node-addressed slabs
+    const bool virt = !whole;  // copies / non-representatives / table leaves never written
+    if (lists) caps_for(ctx, npad, R.n, G.n);
+    // ---- where the digests go
+    TreeRef t{};
+    t.npad = npad;
+    for (int c = 0; c < 64; c++) {
+        t.slab_of_col[c] = -1;
+        t.y_of_col[c] = -1;
+        t.g_j_of_col[c] = -1;
     }
-    RunMeta meta{};
-    for (int c = 0; c < 64; c++) meta.y_of_col[c] = -1;
+    size_t nslab = 0;
+    if (whole || !lists) {
+        nslab = ncols;
+        for (size_t c = 0; c < ncols && c < 64; c++) t.slab_of_col[c] = (signed char)c;
+    } else {
+        for (size_t c = 0; c < ncols; c++) {
+            const int kd = kind(c);
+            if (kd == 0 || kd == 1 || (kd == 3 && ctx->caps.g_slabs)) t.slab_of_col[c] = (signed char)nslab++;
+        }
+    }
+    if (d_slab) t.slab = d_slab;  // (a single tree: ncols slabs of the caller's)
+    else if (nslab) {
+        void *w;
+        CHK(ws_get(ctx, WS_TREE, nslab * stride * 32, &w));
+        t.slab = (uint8_t *)w;
+    }
+    auto slab_map = [&](const ColMap &m) {  // for the dense kernels: entry k of m -> its slab
+        ColMap o{};
+        o.n = m.n;
+        for (unsigned k = 0; k < m.n; k++) o.c[k] = (uint8_t)t.slab_of_col[m.c[k]];
+        return o;
+    };
+    if (H.n == 0 && R.n == 0 && G.n == 0) {
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, t.slab, stride, ncols, ctx->stream, stamp(0, (uint64_t)ncols * npad));
+    } else if (D.n) {
+        const ColMap ds = slab_map(D);
+        launch_keccak_leaves(d_vals, val_stride, n_values, npad, t.slab, stride, ncols, ctx->stream, stamp(0, (uint64_t)D.n * npad), &D, &ds);
+    }
     void *sd_todo = nullptr;
     if (H.n || GS.n) {
         if (!ctx->d_sd_tables) {
@@ -1272,64 +1328,80 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     if (H.n) {
         // in a commit job the leaf digests of these columns are left out (virtual): only an opening reads one, and it
         // hashes that value itself
-        launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
-                                (uint32_t *)sd_todo, ctx->stream, stamp(3, 0), !virt);
+        const ColMap hs = slab_map(H);
+        launch_keccak_small_l01(d_vals, val_stride, n_values, npad, t.slab, stride, H, ctx->d_sd_tables, ctx->d_sd_fallbacks,
+                                (uint32_t *)sd_todo, ctx->stream, stamp(3, 0), !virt, nullptr, &hs);
         if (virt)
-            for (unsigned k = 0; k < H.n; k++) meta.virtual_leaves |= 1ull << H.c[k];
+            for (unsigned k = 0; k < H.n; k++) t.virtual_leaves |= 1ull << H.c[k];
         ctx->stats.small_domain_columns = H.n;
     }
     MerkleBuild b{};
     unsigned top = 0;
     if (lists) {
         top = run_top_level(npad);
+        t.lists = 1;
+        t.top = top;
         b.vals = d_vals;
         b.val_stride = val_stride;
         b.n_values = n_values;
         b.npad = npad;
-        b.tree = d_tree;
-        b.tree_stride_nodes = stride;
         b.rcols = R;
         b.gcols = G;
         b.gcols_sd = GS;
         uint64_t level_nodes = 0;
         for (unsigned l = 0; l <= top; l++) level_nodes += npad >> l;
+        // what outlives the build (read by the openings): a commit job keeps it in workspaces of its own, which nothing but
+        // the next commit job touches; otherwise it is scratch like the rest
+        const bool keep = ref != nullptr;
+        const size_t upper_bytes = ncols * 512 * 32;
         if (R.n) {
-            // scratch: the lists of all levels + what the stages hand to each other.  Kept for the openings (virtual copies)
-            // or scratch as well (everything written): per level and 64 nodes the bitmap of hashed nodes and the last hashed
-            // node before the chunk
-            b.r_lists = runs_lists(npad, R.n);
-            const size_t list_bytes = (size_t)b.r_lists.entries * 4, stage_bytes = runs_stage_scratch_bytes(npad, R.n);
+            // (only a commit job can repeat a build that ran out of room: anything else gets the worst case)
+            t.r_lists = runs_lists(npad, R.n, ref ? ctx->caps.r : nullptr);
+            unsigned long long uoff[RUN_MAX_LEVELS] = {0};
+            const size_t units = runs_units(npad, R.n, uoff);
+            for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) t.ubase_off[l] = uoff[l];
+            const size_t list_bytes = (size_t)t.r_lists.entries * 4, stage_bytes = runs_stage_scratch_bytes(npad, R.n);
             const size_t meta_n = runs_meta_words(npad, R.n);
+            // kept: bitmap | prev | woff | ubase | digests in list order
+            const size_t kept = meta_n * 12 + units * 4 + 64 + (size_t)t.r_lists.entries * 32 + 64;
             void *w, *mw;
-            CHK(ws_get(ctx, WS_RUNS, list_bytes + stage_bytes + 64 + (virt ? 0 : meta_n * 10 + 64), &w));
+            CHK(ws_get(ctx, WS_RUNS, ((list_bytes + 63) & ~(size_t)63) + stage_bytes + 64 + (keep ? 0 : kept), &w));
             b.r_list = (uint32_t *)w;
             b.r_stage = (uint8_t *)w + ((list_bytes + 63) & ~(size_t)63);
-            if (virt) CHK(ws_get(ctx, WS_RUNMETA, meta_n * 10 + 64, &mw));
-            else mw = (uint8_t *)w + ((list_bytes + stage_bytes + 64 + 63) & ~(size_t)63);
-            meta.bitmap = (unsigned long long *)mw;
-            meta.prev = (unsigned short *)((uint8_t *)mw + meta_n * 8);
-            meta.ncols = R.n;
-            meta.run_levels = top + 1;
-            for (unsigned y = 0; y < R.n; y++) meta.y_of_col[R.c[y]] = (signed char)y;
+            if (keep) CHK(ws_get(ctx, WS_RUNMETA, kept + upper_bytes, &mw));
+            else mw = (uint8_t *)w + ((((list_bytes + 63) & ~(size_t)63) + stage_bytes + 64 + 63) & ~(size_t)63);
+            uint8_t *q = (uint8_t *)mw;
+            t.bitmap = (unsigned long long *)q; q += meta_n * 8;
+            t.prev = (unsigned short *)q; q += meta_n * 2;
+            t.woff = (unsigned short *)q; q += meta_n * 2;
+            t.ubase = (uint32_t *)q; q += (units * 4 + 63) & ~(size_t)63;
+            t.r_store = q; q += (size_t)t.r_lists.entries * 32;
+            if (keep) t.upper = (uint8_t *)mw + kept;
+            t.ncols = R.n;
+            for (unsigned y = 0; y < R.n; y++) t.y_of_col[R.c[y]] = (signed char)y;
             b.r_ctr = ctx->d_run_count;
             HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
             ctx->stats.run_aware_columns = R.n;
             ctx->stats.run_aware_dense_nodes = (uint64_t)R.n * level_nodes;
         }
         if (G.n) {
-            // table (generation-tagged: cleared only when the workspace is new or the generations run out) + lists: scratch;
-            // the representative arrays are kept while the trees are read through them (a workspace of their own, which nothing
-            // but the next commit job touches)
-            b.g_lists = cons_lists(npad);
-            const size_t key_bytes = 2 * npad * 8, idx_bytes = 2 * npad * 4, list_bytes = (size_t)b.g_lists.entries * 4;
+            // table (generation-tagged: cleared only when the workspace is new or the generations run out) + list: scratch;
+            // the representative slots and the digests in list order are kept while the trees are read through them
+            t.g_lists = cons_lists(npad, ref ? ctx->caps.g : nullptr);
+            const size_t key_bytes = 2 * npad * 8, idx_bytes = 2 * npad * 4, list_bytes = ((size_t)t.g_lists.entries * 4 + 63) & ~(size_t)63;
+            const size_t kept = 2 * npad * 4 + (size_t)t.g_lists.entries * G.n * 32 + 64;
+            const bool upper_here = keep && !R.n;
             void *w, *mw;
-            CHK(ws_get(ctx, WS_CONS, key_bytes + idx_bytes + list_bytes + 64 + (virt ? 0 : 2 * npad * 4 + 64), &w));
+            CHK(ws_get(ctx, WS_CONS, key_bytes + idx_bytes + list_bytes + 64 + (keep ? 0 : kept), &w));
             b.g_keys = (unsigned long long *)w;
             b.g_idx = (uint32_t *)((uint8_t *)w + key_bytes);
             b.g_list = (uint32_t *)((uint8_t *)w + key_bytes + idx_bytes);
-            if (virt) CHK(ws_get(ctx, WS_CONSMETA, 2 * npad * 4, &mw));
+            if (keep) CHK(ws_get(ctx, WS_CONSMETA, kept + (upper_here ? upper_bytes : 0), &mw));
             else mw = (uint8_t *)w + ((key_bytes + idx_bytes + list_bytes + 64 + 63) & ~(size_t)63);
             b.g_rep = (uint32_t *)mw;
+            t.g_rep = b.g_rep;
+            t.g_store = (uint8_t *)mw + 2 * npad * 4;
+            if (upper_here) t.upper = (uint8_t *)mw + kept;
             if (ctx->cons_table != w || ctx->cons_table_bytes != ctx->ws_bytes[WS_CONS] || ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096) {
                 HIPCHK(ctx, hipMemsetAsync(w, 0, key_bytes, ctx->stream));  // generation 0 = free
                 ctx->cons_table = w;
@@ -1339,25 +1411,33 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             b.g_gen = ctx->cons_gen;
             ctx->cons_gen += top + 1;
             b.g_ctr = ctx->d_cons_count;
+            b.g_has_slabs = whole || ctx->caps.g_slabs;
             HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
-            meta.cons_rep = b.g_rep;
-            meta.cons_levels = top + 1;
-            meta.cons_dropped = ctx->d_cons_count + 8;
-            for (unsigned k = 0; k < G.n; k++) meta.cons_mask |= 1ull << G.c[k];
+            t.g_ncols = G.n;
+            t.g_dropped = ctx->d_cons_count + 8;
+            for (unsigned k = 0; k < G.n; k++) t.g_j_of_col[G.c[k]] = (signed char)k;
             if (virt)
-                for (unsigned k = 0; k < GS.n; k++) meta.cons_sd_mask |= 1ull << GS.c[k];
+                for (unsigned k = 0; k < GS.n; k++) t.g_sd_mask |= 1ull << GS.c[k];
             ctx->build_cons_hinted = G.n;
             ctx->build_cons_levels_nodes = level_nodes;
             ctx->build_cons_sd = GS.n;
         }
-        b.meta = meta;
+        if (!t.upper) {  // not a job: the top levels are scratch too
+            void *u;
+            CHK(ws_get(ctx, WS_OUT64, upper_bytes, &u));
+            t.upper = (uint8_t *)u;
+        }
+        b.t = t;
         launch_runs_structure(b, ctx->stream, R.n ? stamp(4, 0) : nullptr);
         launch_cons_structure(b, ctx->stream, G.n ? stamp(4, 0) : nullptr);
-        if (GS.n)  // only if the group was dropped: its small-domain members' levels 0 and 1 by table
-            launch_keccak_small_l01(d_vals, val_stride, n_values, npad, d_tree, stride, GS, ctx->d_sd_tables, ctx->d_sd_fallbacks + 1,
-                                    (uint32_t *)sd_todo + sd_todo_words(npad, H.n), ctx->stream, stamp(3, 0), !virt, ctx->d_cons_count + 8);
+        if (GS.n && b.g_has_slabs) {  // only if the group was dropped: its small-domain members' levels 0 and 1 by table
+            const ColMap gs = slab_map(GS);
+            launch_keccak_small_l01(d_vals, val_stride, n_values, npad, t.slab, stride, GS, ctx->d_sd_tables, ctx->d_sd_fallbacks + 1,
+                                    (uint32_t *)sd_todo + sd_todo_words(npad, H.n), ctx->stream, stamp(3, 0), !virt, ctx->d_cons_count + 8,
+                                    &gs);
+        }
     }
-    if (run_meta) *run_meta = meta;
+    if (ref) *ref = t;
     unsigned first_top = 0;  // the level the top kernel starts from
     if (lists) {
         for (unsigned l = 0; l <= top; l++) {
@@ -1368,9 +1448,11 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
                 const int kd = kind(c);
                 if (kd == 0 || (kd == 1 && l >= 1)) m.c[m.n++] = (uint8_t)c;
             }
-            if (m.n)
-                launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), npad >> (l + 1), ncols,
-                                    ctx->stream, stamp(keccak_level_is_wide(npad >> (l + 1), m.n) ? 1 : 2, (uint64_t)m.n * (npad >> (l + 1))), &m);
+            if (m.n) {
+                const ColMap ms = slab_map(m);
+                launch_keccak_level(t.slab, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), npad >> (l + 1), ncols,
+                                    ctx->stream, stamp(keccak_level_is_wide(npad >> (l + 1), m.n) ? 1 : 2, (uint64_t)m.n * (npad >> (l + 1))), &ms);
+            }
         }
         first_top = top;
     } else {
@@ -1388,15 +1470,15 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
                 pm = &m;
                 nc = m.n;
             }
-            launch_keccak_level(d_tree, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols, ctx->stream,
+            launch_keccak_level(t.slab, stride, tree_level_offset(npad, l), tree_level_offset(npad, l + 1), n_out, ncols, ctx->stream,
                                 stamp(keccak_level_is_wide(n_out, nc) ? 1 : 2, (uint64_t)nc * n_out), pm);
         }
     }
     if (height) {
         ctx->build_top_perms = (uint64_t)ncols * ((npad >> first_top) - 1);
-        launch_merkle_top(d_tree, stride, npad, first_top, height, ncols, lists ? &meta : nullptr, ctx->stream, stamp(6, ctx->build_top_perms));
+        launch_merkle_top(t, first_top, height, ncols, ctx->stream, stamp(6, ctx->build_top_perms));
     }
-    if (lists && !virt) launch_fill_virtual(b, ctx->stream);
+    if (lists && whole) launch_fill_virtual(b, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     return ZIGZ_OK;
 }
@@ -1486,9 +1568,9 @@ extern "C" zigz_status zigz_merkle_commit(zigz_ctx *ctx, const uint64_t *values,
     return ZIGZ_OK;
 }
 
-static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad, unsigned height, const uint32_t *d_vals,
+static zigz_status open_paths(zigz_ctx *ctx, const TreeRef &tree, unsigned height, const uint32_t *d_vals,
                               size_t val_stride, const uint64_t *h_idx, size_t ncols, uint8_t *siblings, uint8_t *dirs,
-                              uint64_t *leaves, const RunMeta *run_meta = nullptr) {
+                              uint64_t *leaves) {
     ZIGZ_NOTHROW_BEGIN
     // device scratch layout: idx[ncols] u64 | sib[ncols*h*32] | leaf[ncols] u32 | dirs[ncols*h]
     const size_t sib_b = ncols * height * 32, idx_b = ncols * 8, leaf_b = ncols * 4, dir_b = ncols * height;
@@ -1501,8 +1583,7 @@ static zigz_status open_paths(zigz_ctx *ctx, const uint8_t *d_tree, size_t npad,
     uint8_t *d_dirs = (uint8_t *)(d_leaf + ncols);
     HIPCHK(ctx, hipMemcpyAsync(d_idx, h_idx, idx_b, hipMemcpyHostToDevice, ctx->stream));
     // (n_values = npad: leaf digests are virtual only in commit jobs, whose columns have exactly npad values)
-    launch_paths(d_tree, tree_nodes(npad), npad, npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols,
-                 ctx->stream, run_meta);
+    launch_paths(tree, tree.npad, height, d_vals, val_stride, d_idx, d_sib, d_dirs, d_leaf, ncols, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
     std::vector<uint32_t> hl(ncols);
     if (sib_b) HIPCHK(ctx, hipMemcpyAsync(siblings, d_sib, sib_b, hipMemcpyDeviceToHost, ctx->stream));
@@ -1521,7 +1602,7 @@ extern "C" zigz_status zigz_merkle_open(zigz_ctx *ctx, const zigz_merkle *t, siz
     if (index >= t->n_values) return ZIGZ_ERR_INDEX_OUT_OF_BOUNDS;  // merkle_tree.zig:325 (values.len)
     if (t->height && (!siblings || !dirs)) return ZIGZ_ERR_INVALID_ARGUMENT;
     uint64_t idx = index;
-    return open_paths(ctx, t->d_tree, t->npad, t->height, t->d_vals, t->n_values, &idx, 1, siblings, dirs, leaf_value);
+    return open_paths(ctx, slab_tree_ref(t->d_tree, t->npad), t->height, t->d_vals, t->n_values, &idx, 1, siblings, dirs, leaf_value);
 }
 
 extern "C" zigz_status zigz_commit_open(zigz_ctx *ctx, const uint64_t *evals, size_t n, const zigz_merkle *tree,
@@ -1550,11 +1631,58 @@ struct zigz_commit_job {
     zigz_ctx *ctx;
     size_t ncols, nv, N, col_stride;
     const uint32_t *d_cols;
-    uint8_t *d_tree;
     int state;  // 0 begun, 1 roots read, 2 opened
     hipEvent_t built;
-    RunMeta run_meta;  // how to resolve the virtual copies of the run-aware levels (WS_RUNMETA of the context)
+    TreeRef tree;  // where the digests are (the context's WS_TREE / WS_RUNMETA / WS_CONSMETA workspaces)
+    bool whole;    // built with every digest in node-addressed slabs (option run_aware_materialize)
+    // the hints the job was begun with (a repeated build -- zigz_commit_roots, when a list ran out of room -- uses the same) and
+    // what its build asked for (turned into stats when the counters have arrived; other calls may run in between)
+    uint64_t m_small, m_run, m_cons;
+    bool m_whole;
+    uint64_t run_cols, run_dense, sd_cols, cons_hinted, cons_levels_nodes, cons_sd, perms0;
 };
+
+// enqueues the builds of a job, the gather of its roots + counters into ONE pinned buffer, and the "built" event
+static zigz_status job_build(zigz_commit_job *job) {
+    zigz_ctx *ctx = job->ctx;
+    const size_t ncols = job->ncols, nv = job->nv;
+    CHK(timed_begin(ctx, 2));
+    job->whole = job->m_whole;
+    {   // build with the hints of the job's begin, whatever the context's options say by now
+        const uint64_t s0 = ctx->small_domain_mask, r0 = ctx->run_aware_mask, c0 = ctx->cons_group_mask;
+        const bool w0 = ctx->run_aware_materialize;
+        ctx->small_domain_mask = job->m_small;
+        ctx->run_aware_mask = job->m_run;
+        ctx->cons_group_mask = job->m_cons;
+        ctx->run_aware_materialize = job->m_whole;
+        const zigz_status bs = build_trees(ctx, job->d_cols, job->col_stride, job->N, job->N, nullptr, ncols, ctx->timing, &job->tree);
+        ctx->small_domain_mask = s0;
+        ctx->run_aware_mask = r0;
+        ctx->cons_group_mask = c0;
+        ctx->run_aware_materialize = w0;
+        CHK(bs);
+    }
+    if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
+    // roots + the counters of the build -> contiguous device buffer -> pinned staging (async), then the "built" event
+    void *d_roots;
+    CHK(ws_get(ctx, WS_MISC, ncols * 32 + JOB_SUMMARY_WORDS * 8 + nv * ncols * 4 + 128, &d_roots));
+    launch_job_summary(job->tree, (unsigned)nv, (uint8_t *)d_roots, ncols, ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
+                       (ctx->stats.small_domain_columns || ctx->build_cons_sd) ? ctx->d_sd_fallbacks : nullptr,
+                       ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32 + JOB_SUMMARY_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
+    // hinted columns take levels 0 and 1 (N + N/2 digests) from the tables (waves that had to hash are counted in
+    // small_domain_fallback_waves, read in zigz_commit_roots; they are not added back here)
+    job->run_cols = ctx->stats.run_aware_columns;
+    job->run_dense = ctx->stats.run_aware_dense_nodes;
+    job->sd_cols = ctx->stats.small_domain_columns;
+    job->cons_hinted = ctx->build_cons_hinted;
+    job->cons_levels_nodes = ctx->build_cons_levels_nodes;
+    job->cons_sd = ctx->build_cons_sd;
+    job->perms0 = (uint64_t)ncols * (2 * job->N - 1) - job->sd_cols * (job->N + job->N / 2);
+    return ZIGZ_OK;
+}
 
 static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride, size_t nv,
                              zigz_commit_job **out) {
@@ -1571,28 +1699,13 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
     job->N = (size_t)1 << nv;
     job->col_stride = col_stride;
     job->d_cols = d_cols;
+    job->m_small = ctx->small_domain_mask;
+    job->m_run = ctx->run_aware_mask;
+    job->m_cons = ctx->cons_group_mask;
+    job->m_whole = ctx->run_aware_materialize;
     auto body = [&]() -> zigz_status {
-        void *tree;
-        CHK(ws_get(ctx, WS_TREE, ncols * tree_nodes(job->N) * 32, &tree));
-        job->d_tree = (uint8_t *)tree;
         HIPCHK(ctx, hipEventCreateWithFlags(&job->built, hipEventDisableTiming));
-        CHK(timed_begin(ctx, 2));
-        CHK(build_trees(ctx, d_cols, col_stride, job->N, job->N, job->d_tree, ncols, ctx->timing, &job->run_meta));
-        if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
-        // roots -> contiguous device buffer -> pinned staging (async), then the "built" event
-        void *d_roots;
-        CHK(ws_get(ctx, WS_MISC, ncols * 32 + nv * ncols * 4 + 128, &d_roots));
-        // the diagnostic counters of the build ride along behind the roots (one kernel gathers both, one copy brings them):
-        // [0] nodes hashed on the run-aware levels, [1] / [2] waves that left the small-domain tables (hinted columns / members
-        // of a dropped group), [3] digests computed on the content-addressed levels, [4] group dropped?, [5] its distinct leaves
-        launch_job_summary(job->d_tree, tree_nodes(job->N), tree_level_offset(job->N, (unsigned)nv), (uint8_t *)d_roots, ncols,
-                           ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
-                           (ctx->stats.small_domain_columns || ctx->build_cons_sd) ? ctx->d_sd_fallbacks : nullptr,
-                           ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream);
-        HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32 + 48, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
-        return ZIGZ_OK;
+        return job_build(job);
     };
     zigz_status st = body();
     if (st != ZIGZ_OK) {
@@ -1600,9 +1713,6 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
         delete job;
         return st;
     }
-    // hinted columns take levels 0 and 1 (N + N/2 digests) from the tables (waves that had to hash are counted in
-    // small_domain_fallback_waves, read in zigz_commit_roots; they are not added back here)
-    ctx->stats.keccak_permutations = (uint64_t)ncols * (2 * job->N - 1) - (uint64_t)ctx->stats.small_domain_columns * (job->N + job->N / 2);
     ctx->active_job = job;
     *out = job;
     return ZIGZ_OK;
@@ -1642,31 +1752,64 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     if (!job || !roots) return ZIGZ_ERR_INVALID_ARGUMENT;
     zigz_ctx *ctx = job->ctx;
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
-    HIPCHK(ctx, hipEventSynchronize(job->built));
-    memcpy(roots, ctx->h_roots, job->ncols * 32);
     const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + job->ncols * 32);
-    // the run-aware levels hashed h_cnt[0] of their run_aware_dense_nodes nodes
+    for (int attempt = 0;; attempt++) {
+        HIPCHK(ctx, hipEventSynchronize(job->built));
+        // What the lists of the structure-aware levels needed: the context remembers it for its next builds, and a build that
+        // ran out of room (or found its group dropped with nowhere to build the columns densely) is repeated here with more.
+        // This is the one place where a proof may pay for a second build: the first time a context meets a new kind of trace.
+        const unsigned long long flags = h_cnt[6];
+        const bool r_over = (flags & 1) != 0, g_over = ((flags >> 8) & 1) != 0, g_noslab = ((flags >> 8) & 2) != 0;
+        const bool dropped = h_cnt[4] != 0;
+        ListCaps &c = ctx->caps;
+        bool again = false;
+        if (job->tree.lists && c.npad == job->N) {
+            for (unsigned l = 0; l <= job->tree.top; l++) {
+                const unsigned long long ru = h_cnt[8 + l], gu = h_cnt[8 + RUN_MAX_LEVELS + l];
+                if (job->run_cols && (r_over ? ru > c.r[l] : ru * 10 > (unsigned long long)c.r[l] * 8))
+                    c.r[l] = (unsigned)(ru + ru / 4 + 64);
+                if (job->cons_hinted && !dropped && (g_over ? gu > c.g[l] : gu * 10 > (unsigned long long)c.g[l] * 8))
+                    c.g[l] = (unsigned)(gu + gu / 4 + 64);
+            }
+            if (dropped) c.g_slabs = true;  // this context's traces do not repeat: give the group's columns slabs from now on
+            again = r_over || (g_over && !dropped) || g_noslab;
+        }
+        if (!again) break;
+        if (attempt >= 3) {
+            set_err(ctx, "commit job: the lists of the structure-aware levels still do not fit after %d builds", attempt + 1);
+            return ZIGZ_ERR_BAD_STATE;
+        }
+        ctx->stats.rebuilds++;
+        CHK(job_build(job));
+    }
+    memcpy(roots, ctx->h_roots, job->ncols * 32);
+    // the run-aware levels hashed h_cnt[0] of their run_dense nodes
     const uint64_t N = job->N;
-    ctx->stats.run_aware_hashed = ctx->stats.run_aware_columns ? h_cnt[0] : 0;
+    ctx->stats.run_aware_columns = job->run_cols;
+    ctx->stats.run_aware_dense_nodes = job->run_dense;
+    ctx->stats.small_domain_columns = job->sd_cols;
+    ctx->stats.keccak_permutations = job->perms0;
+    ctx->stats.run_aware_hashed = job->run_cols ? h_cnt[0] : 0;
     ctx->stats.keccak_permutations -= ctx->stats.run_aware_dense_nodes - ctx->stats.run_aware_hashed;
-    ctx->stats.small_domain_fallback_waves = ctx->stats.small_domain_columns ? h_cnt[1] : 0;
+    ctx->stats.small_domain_fallback_waves = job->sd_cols ? h_cnt[1] : 0;
     ctx->stats.list_hash_perms = ctx->stats.run_aware_hashed;
     // the group: kept (digests computed for its cons_dense_nodes nodes: h_cnt[3]) or dropped on the device (its small-domain
     // members then took levels 0 and 1 from the tables, everything else was hashed densely)
     ctx->stats.cons_columns = ctx->stats.cons_dense_nodes = ctx->stats.cons_hashed = 0;
-    if (ctx->build_cons_hinted) {
+    ctx->stats.cons_probe_distinct = 0;
+    if (job->cons_hinted) {
         ctx->stats.cons_probe_distinct = h_cnt[5];
         if (!h_cnt[4]) {
-            ctx->stats.cons_columns = ctx->build_cons_hinted;
-            ctx->stats.cons_dense_nodes = ctx->build_cons_hinted * ctx->build_cons_levels_nodes;
+            ctx->stats.cons_columns = job->cons_hinted;
+            ctx->stats.cons_dense_nodes = job->cons_hinted * job->cons_levels_nodes;
             ctx->stats.cons_hashed = h_cnt[3];
             ctx->stats.keccak_permutations -= ctx->stats.cons_dense_nodes - ctx->stats.cons_hashed;
             ctx->stats.list_hash_perms += ctx->stats.cons_hashed;
         } else {
-            ctx->stats.small_domain_columns += ctx->build_cons_sd;
-            ctx->stats.keccak_permutations -= ctx->build_cons_sd * (N + N / 2);
+            ctx->stats.small_domain_columns += job->cons_sd;
+            ctx->stats.keccak_permutations -= job->cons_sd * (N + N / 2);
             ctx->stats.small_domain_fallback_waves += h_cnt[2];
-            ctx->stats.list_hash_perms += ctx->build_cons_hinted * ctx->build_cons_levels_nodes - ctx->build_cons_sd * (N + N / 2);
+            ctx->stats.list_hash_perms += job->cons_hinted * job->cons_levels_nodes - job->cons_sd * (N + N / 2);
         }
     }
     if (ctx->timing) {
@@ -1700,8 +1843,7 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         idx[c] = nv == 0 ? 0 : points[c * nv] % ((uint64_t)1 << nv);  // pointToIndex
         indices[c] = idx[c];
     }
-    CHK(open_paths(ctx, job->d_tree, job->N, (unsigned)nv, job->d_cols, job->col_stride, idx.data(), ncols, siblings,
-                   dirs, leaves, &job->run_meta));
+    CHK(open_paths(ctx, job->tree, (unsigned)nv, job->d_cols, job->col_stride, idx.data(), ncols, siblings, dirs, leaves));
     for (size_t c = 0; c < ncols; c++) values[c] = hv[c];
     CHK(bind_pool_collect(ctx));
     job->state = 2;
@@ -1712,8 +1854,11 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
 extern "C" zigz_status zigz_commit_job_tree(zigz_commit_job *job, const void **d_tree, size_t *bytes_per_column) {
     if (job) ZIGZ_ENTER(job->ctx);
     if (!job || !d_tree || !bytes_per_column) return ZIGZ_ERR_INVALID_ARGUMENT;
+    // node-addressed trees of every column exist only when nothing was list-built, or the job was begun with
+    // "run_aware_materialize" (otherwise the list-built levels live in list order: there is no whole tree to look at)
+    if (job->tree.lists && !job->whole) return ZIGZ_ERR_BAD_STATE;
     HIPCHK(job->ctx, hipEventSynchronize(job->built));
-    *d_tree = job->d_tree;
+    *d_tree = job->tree.slab;
     *bytes_per_column = tree_nodes(job->N) * 32;
     return ZIGZ_OK;
 }

@@ -632,9 +632,9 @@ constexpr int HPT = ZK_HPT;
 #endif
 __global__ __launch_bounds__(TPB, ZK_LEAVES_MIN_WAVES) void k_keccak_leaves(const uint32_t *__restrict__ vals, size_t val_stride,
                                                        size_t n_values, size_t npad, uint8_t *__restrict__ tree,
-                                                       size_t tree_stride_nodes, ColMap cmap) {
+                                                       size_t tree_stride_nodes, ColMap cmap, ColMap tmap) {
     const size_t col = cmap.n ? cmap.c[blockIdx.y] : blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    uint8_t *t = tree + (tmap.n ? (size_t)tmap.c[blockIdx.y] : col) * tree_stride_nodes * 32;  // (the column's slab)
     const uint32_t *v = vals + col * val_stride;
 #pragma unroll 1
     for (int h = 0; h < HPT; h++) {
@@ -689,13 +689,15 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_MIN_WAVES) void k_keccak_level(uint8_
 }
 
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
-                          size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols) {
-    ColMap cm{};
+                          size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt, const ColMap *cols,
+                          const ColMap *slabs) {
+    ColMap cm{}, tm{};
     if (cols) cm = *cols;
+    if (slabs) tm = *slabs;
     if (cols && cm.n == 0) return;  // an explicit, empty column list
     dim3 grid((unsigned)((npad + TPB * HPT - 1) / (TPB * HPT)), (unsigned)(cols ? cm.n : ncols));
     ZK_LAUNCH(kt, k_keccak_leaves, grid, dim3(TPB), ZK_LEAVES_DYN_LDS, s, d_vals, val_stride, n_values, npad, d_tree,
-              tree_stride_nodes, cm);
+              tree_stride_nodes, cm, tm);
 }
 
 #ifndef ZK_WIDE_MIN_WGS
@@ -741,12 +743,12 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_l01(const uint32_t *__rest
                                                           ColMap cmap, const uint8_t *__restrict__ tables,
                                                           unsigned long long *__restrict__ todo_count,
                                                           uint32_t *__restrict__ todo, int write_leaves,
-                                                          const unsigned long long *__restrict__ only_if) {
+                                                          const unsigned long long *__restrict__ only_if, ColMap tmap) {
     if (only_if && !*only_if) return;  // these columns went another way (a content-addressed group that was kept)
     const size_t col = cmap.c[blockIdx.y];
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;  // level-1 node
     const bool live = i < npad / 2;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
+    uint8_t *t = tree + (tmap.n ? (size_t)tmap.c[blockIdx.y] : col) * tree_stride_nodes * 32;  // (the column's slab)
     const uint2 *v = reinterpret_cast<const uint2 *>(vals + col * val_stride);
     // padding leaves hash the value 0 (merkle_tree.zig:302-306)
     uint2 x = make_uint2(0, 0);
@@ -795,7 +797,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
                                                                size_t tree_stride_nodes, ColMap cmap,
                                                                const unsigned long long *__restrict__ todo_count,
                                                                const uint32_t *__restrict__ todo, int write_leaves,
-                                                               const unsigned long long *__restrict__ only_if) {
+                                                               const unsigned long long *__restrict__ only_if, ColMap tmap) {
     if (only_if && !*only_if) return;
     const unsigned long long count = *todo_count;
     const unsigned lane = threadIdx.x & 63;
@@ -804,7 +806,7 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
         const size_t col = cmap.c[todo[2 * w]];
         const size_t i = (size_t)todo[2 * w + 1] * 64 + lane;
         if (i >= npad / 2) continue;
-        uint8_t *t = tree + col * tree_stride_nodes * 32;
+        uint8_t *t = tree + (tmap.n ? (size_t)tmap.c[todo[2 * w]] : col) * tree_stride_nodes * 32;
         const uint32_t *v = vals + col * val_stride;
         const uint64_t v0 = 2 * i < n_values ? v[2 * i] : 0, v1 = 2 * i + 1 < n_values ? v[2 * i + 1] : 0;
         const Digest l0 = sha3_leaf(v0), l1 = sha3_leaf(v1);
@@ -819,35 +821,34 @@ __global__ __launch_bounds__(TPB) void k_keccak_small_fallback(const uint32_t *_
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
                              unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt,
-                             bool write_leaves, const unsigned long long *d_only_if) {
+                             bool write_leaves, const unsigned long long *d_only_if, const ColMap *slabs) {
     if (cols.n == 0 || npad < 2) return;
+    ColMap tm{};
+    if (slabs) tm = *slabs;
     dim3 grid((unsigned)((npad / 2 + TPB - 1) / TPB), (unsigned)cols.n);
     ZK_LAUNCH(kt, k_keccak_small_l01, grid, dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree, tree_stride_nodes, cols,
-              d_tables, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if);
+              d_tables, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if, tm);
     // list-driven; 512 workgroups walk the to-do list (empty unless a hint was wrong: then a few microseconds)
     hipLaunchKernelGGL(k_keccak_small_fallback, dim3(512), dim3(TPB), 0, s, d_vals, val_stride, n_values, npad, d_tree,
-                       tree_stride_nodes, cols, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if);
+                       tree_stride_nodes, cols, d_todo_count, d_todo, write_leaves ? 1 : 0, d_only_if, tm);
 }
 
 // ------------------------------------------------------------------ K7: authentication paths
-__global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                              size_t n_values, unsigned height, const uint32_t *__restrict__ vals, size_t val_stride,
-                                              const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
-                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, RunMeta meta) {
+__global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsigned height, const uint32_t *__restrict__ vals,
+                                              size_t val_stride, const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
+                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf) {
     const size_t col = blockIdx.x;
     const size_t index = idx[col];
     const unsigned l = threadIdx.x;
     if (l == 0) leaf[col] = vals[col * val_stride + index];
     if (l >= height) return;
     const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
-    const uint8_t *t = tree + col * tree_stride_nodes * 32;
-    const size_t off = 2 * npad - 2 * (npad >> l);
-    const size_t node = resolve_node(meta, npad, col, l, ci ^ 1);  // a copy / non-representative: where its digest is stored
-    bool virt_leaf = l == 0 && col < 64 && ((meta.virtual_leaves >> col) & 1);  // leaf digests of this column were never written
-    if (l == 0 && col < 64 && ((meta.cons_sd_mask >> col) & 1) && *meta.cons_dropped) virt_leaf = true;
+    const size_t node = ci ^ 1;    // the sibling: a copy / non-representative resolves to where its digest is stored (node_ptr)
+    bool virt_leaf = l == 0 && col < 64 && ((t.virtual_leaves >> col) & 1);  // leaf digests of this column were never written
+    if (l == 0 && col < 64 && ((t.g_sd_mask >> col) & 1) && *t.g_dropped) virt_leaf = true;
     Digest d;
-    if (virt_leaf) d = sha3_leaf<false>((ci ^ 1) < n_values ? (uint64_t)vals[col * val_stride + (ci ^ 1)] : 0);
-    else d = load_digest(t, off + node);
+    if (virt_leaf) d = sha3_leaf<false>(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
+    else d = load_digest_at(node_ptr(t, col, l, node));
     d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
     ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
@@ -855,14 +856,21 @@ __global__ __launch_bounds__(64) void k_paths(const uint8_t *__restrict__ tree, 
     dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
 }
 
-void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, size_t n_values, unsigned height,
-                  const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs,
-                  uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta) {
-    RunMeta m{};
-    if (meta) m = *meta;
-    else for (int c = 0; c < 64; c++) m.y_of_col[c] = -1;  // (cons_mask = cons_sd_mask = 0: cons_dropped is never read)
-    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, d_tree, tree_stride_nodes, npad, n_values, height, d_vals,
-                       val_stride, d_idx, d_sib, d_dirs, d_leaf, m);
+void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
+                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s) {
+    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx, d_sib, d_dirs,
+                       d_leaf);
+}
+TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad) {
+    TreeRef t{};
+    t.npad = npad;
+    t.slab = d_tree;
+    for (int c = 0; c < 64; c++) {
+        t.slab_of_col[c] = (signed char)c;
+        t.y_of_col[c] = -1;
+        t.g_j_of_col[c] = -1;
+    }
+    return t;
 }
 
 __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t node,
@@ -874,32 +882,44 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
     q[0] = make_ulonglong2(d.w[0], d.w[1]);
     q[1] = make_ulonglong2(d.w[2], d.w[3]);
 }
-// roots of a commit job + the build's diagnostic counters behind them (6 u64; a null pointer reads as 0): ONE buffer, one copy
-__global__ void k_job_summary(const uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t node, uint8_t *__restrict__ out,
-                              size_t ncols, const unsigned long long *r_ctr, const unsigned long long *sd_ctr,
-                              const unsigned long long *g_ctr) {
+// roots of a commit job + the build's counters behind them (kernels.hpp: JOB_SUMMARY_WORDS u64; a null pointer reads as 0): ONE
+// buffer, one copy
+__global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ out, size_t ncols, const unsigned long long *r_ctr,
+                              const unsigned long long *sd_ctr, const unsigned long long *g_ctr) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ncols) {
-        const Digest d = canonical_digest(load_digest(tree + c * tree_stride_nodes * 32, node));  // tree form -> SHA3 bytes
+        const Digest d = canonical_digest(load_digest_at(node_ptr(t, c, height, 0)));  // tree form -> SHA3 bytes
         ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + c * 32);
         q[0] = make_ulonglong2(d.w[0], d.w[1]);
         q[1] = make_ulonglong2(d.w[2], d.w[3]);
     }
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(out + ncols * 32);
     if (c == 0) {
-        unsigned long long *cnt = reinterpret_cast<unsigned long long *>(out + ncols * 32);
         cnt[0] = r_ctr ? r_ctr[0] : 0;
         cnt[1] = sd_ctr ? sd_ctr[0] : 0;
         cnt[2] = sd_ctr ? sd_ctr[1] : 0;
         cnt[3] = g_ctr ? g_ctr[0] : 0;
         cnt[4] = g_ctr ? g_ctr[8] : 0;
         cnt[5] = g_ctr ? g_ctr[9] : 0;
+        cnt[6] = (r_ctr ? r_ctr[10] : 0) | ((g_ctr ? g_ctr[10] : 0) << 8);
+        cnt[7] = 0;
+    }
+    if (blockIdx.x == 0 && threadIdx.x < 2 * RUN_MAX_LEVELS) {  // the longest sub-list of every level (what the next build needs)
+        const unsigned l = threadIdx.x % RUN_MAX_LEVELS;
+        const unsigned long long *ctr = threadIdx.x < RUN_MAX_LEVELS ? r_ctr : g_ctr;
+        unsigned long long mx = 0;
+        if (ctr)
+            for (unsigned sub = 0; sub < RUN_SUBS; sub++) {
+                const unsigned long long v = ctr[run_ctr_index(l, sub)];
+                mx = v > mx ? v : mx;
+            }
+        cnt[8 + threadIdx.x] = mx;
     }
 }
-void launch_job_summary(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
-                        const unsigned long long *d_r_ctr, const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr,
-                        hipStream_t s) {
-    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, d_tree, tree_stride_nodes, node, d_out,
-                       ncols, d_r_ctr, d_sd_ctr, d_g_ctr);
+void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
+                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s) {
+    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr, d_sd_ctr,
+                       d_g_ctr);
 }
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s) {

@@ -145,27 +145,6 @@ __host__ __device__ inline size_t run_tile_nodes(size_t npad, unsigned l) {
     const size_t seg = n_in < RUN_SEG ? n_in : RUN_SEG;
     return seg >> (l - s * RUN_STAGE_LEVELS);
 }
-struct RunMeta {
-    unsigned long long *bitmap;  // per level l at word run_meta_base(l): [hinted column y][node / 64], bit = hashed
-    unsigned short *prev;        // same indexing: local index (in the tile) of the last hashed node before the chunk
-    unsigned ncols;              // hinted (R) columns
-    unsigned run_levels;         // R: the levels below this were built from lists (copies resolve to their leader)
-    unsigned long long virtual_leaves;  // bit c: the leaf digests of column c were not written (small-domain columns of a
-                                        // commit job): an opening hashes the sibling value itself
-    signed char y_of_col[64];    // column -> hinted index, -1 = not hinted
-    // content-addressed group: on the levels < cons_levels a node of a column in cons_mask has the digest stored at node
-    // cons_rep[2 npad - 2 (npad >> l) + k] of the same level and column (its representative) -- unless *cons_dropped
-    const uint32_t *cons_rep;
-    unsigned cons_levels;
-    unsigned long long cons_mask;
-    const unsigned long long *cons_dropped;  // device word: != 0 -> the group did not repeat; its columns were built densely
-    unsigned long long cons_sd_mask;   // columns of the group whose leaf digests are virtual when the group was dropped
-};
-// first entry of level l in RunMeta::bitmap / ::prev (one entry per 64 nodes, levels stored one after the other)
-__host__ __device__ inline size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
-    return (size_t)ncols * ((2 * npad - 2 * (npad >> l)) / 64);
-}
-inline size_t runs_meta_words(size_t npad, size_t ncols) { return ncols * (2 * npad / 64); }
 // where the lists of the levels live: level l has RUN_SUBS sub-lists of cap[l] entries starting at entry base[l]
 struct LevelLists {
     unsigned top;                               // levels 0 .. top
@@ -173,8 +152,53 @@ struct LevelLists {
     unsigned cap[RUN_MAX_LEVELS];
     unsigned long long entries;                 // total
 };
-LevelLists runs_lists(size_t npad, size_t ncols);  // R: entries are (y << 26 | node)
-LevelLists cons_lists(size_t npad);                // G: entries are nodes (representatives)
+// Where the digest of (column, level, node) of a build lives (tree_dev.hpp: node_ptr).  Three kinds of storage:
+//   slab    node-addressed, 2 npad nodes per column (level l at node offset 2 npad - 2 (npad >> l)): the columns that are
+//           built densely -- and every column of a build that materialises whole trees (single trees, whole-tree tests);
+//   stores  the list levels 0..top of the R and G columns in LIST ORDER: a hashed node's digest sits at its list slot, a copy
+//           / non-representative resolves to its leader's / representative's slot.  Sized from what the context's previous
+//           builds needed, not for the worst case (every node hashed): a build that runs out of room says so (counter word
+//           10) and zigz_commit_roots repeats it with more -- so a proof in flight holds ~0.5 GiB of HBM instead of 3.4;
+//   upper   the levels above the list levels (255 nodes per column) of all columns of a build with lists.
+struct TreeRef {
+    size_t npad;
+    uint8_t *slab;
+    signed char slab_of_col[64];  // column -> index of its slab, -1 = none (columns >= 64: their own index)
+    int lists;                    // != 0: levels 0..top of the R / G columns are list-built
+    unsigned top;
+    uint8_t *upper;               // [column][512 nodes]: level l > top at node offset 512 - 2 (256 >> (l - top))
+    // R (run-aware)
+    unsigned long long *bitmap;   // per level l at word run_meta_base(l): [hinted column y][node / 64], bit = hashed
+    unsigned short *prev;         // same indexing: local index (in the tile) of the last hashed node before the chunk
+    unsigned short *woff;         // same indexing: list offset (within its unit) of the chunk's first hashed node
+    uint32_t *ubase;              // per level l at ubase_off[l]: [unit = y * (n_l / tile_l) + node / tile_l]: the list slot (within
+    unsigned long long ubase_off[RUN_MAX_LEVELS];  // the level: sub-list * capacity + position) of the unit's first hashed node
+    unsigned ncols;               // hinted (R) columns
+    signed char y_of_col[64];     // column -> hinted index, -1 = not hinted
+    uint8_t *r_store;             // digest of list slot i of level l: r_store + (r_lists.base[l] + i) * 32
+    LevelLists r_lists;
+    // G (content-addressed group)
+    signed char g_j_of_col[64];   // column -> index in the group, -1 = not a member
+    unsigned g_ncols;
+    const uint32_t *g_rep;        // per level (tree_level_offset order): the list slot of the node's representative
+    uint8_t *g_store;             // digest of (list slot i, group column j) of level l: g_store + ((g_lists.base[l] + i) * g_ncols + j) * 32
+    LevelLists g_lists;
+    const unsigned long long *g_dropped;  // device word: != 0 -> the group did not repeat; its columns live in slabs
+    unsigned long long g_sd_mask;         // columns of the group whose leaf digests are virtual when the group was dropped
+    unsigned long long virtual_leaves;    // bit c: the leaf digests of column c were not written (small-domain columns of a
+                                          // commit job): an opening hashes the sibling value itself
+};
+// first entry of level l in TreeRef::bitmap / ::prev / ::woff (one entry per 64 nodes, levels stored one after the other)
+__host__ __device__ inline size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
+    return (size_t)ncols * ((2 * npad - 2 * (npad >> l)) / 64);
+}
+inline size_t runs_meta_words(size_t npad, size_t ncols) { return ncols * (2 * npad / 64); }
+// cap_in[l] = entries per sub-list the caller wants for level l (0 or nullptr: the worst case -- every node hashed); the
+// result holds min(cap_in, worst case)
+LevelLists runs_lists(size_t npad, size_t ncols, const unsigned *cap_in = nullptr);  // R: entries are (y << 26 | node)
+LevelLists cons_lists(size_t npad, const unsigned *cap_in = nullptr);                // G: entries are nodes (representatives)
+// units (column, segment) of the R stages per level and where each level's ubase entries start
+size_t runs_units(size_t npad, size_t ncols, unsigned long long ubase_off[RUN_MAX_LEVELS]);
 // scratch of the R stages above stage 0: per hinted column the first values of the level-6 (12, 18) nodes and their
 // "not uniform" bits (u32 words, then u64 words)
 size_t runs_stage_scratch_bytes(size_t npad, size_t ncols);
@@ -182,24 +206,22 @@ size_t runs_stage_scratch_bytes(size_t npad, size_t ncols);
 struct MerkleBuild {   // everything the structure-aware launches share (device pointers)
     const uint32_t *vals;
     size_t val_stride, n_values, npad;
-    uint8_t *tree;
-    size_t tree_stride_nodes;
+    TreeRef t;                    // where digests go (and how copies / non-representatives resolve)
     // R
     ColMap rcols;
-    RunMeta meta;                 // bitmap / prev / y_of_col; cons_* filled in when there is a group
     uint32_t *r_list;
-    LevelLists r_lists;
-    unsigned long long *r_ctr;    // RUN_CTRS words, zeroed before the build
+    unsigned long long *r_ctr;    // RUN_CTRS words, zeroed before the build; word 10: != 0 -> a list ran out of room
     uint8_t *r_stage;             // runs_stage_scratch_bytes()
     // G
     ColMap gcols;                 // the group, ascending
     ColMap gcols_sd;              // its small-domain members (levels 0-1 from the tables when the group is dropped)
+    int g_has_slabs;              // the group's columns have slabs to be built into when the group is dropped
     unsigned long long *g_keys;   // 2 npad slots: generation << 52 | payload
-    uint32_t *g_idx;              // 2 npad: the node that inserted the slot's key
-    uint32_t *g_rep;              // 2 npad: representative of every node of the levels 0..top (tree_level_offset order)
-    uint32_t *g_list;
-    LevelLists g_lists;
-    unsigned long long *g_ctr;    // RUN_CTRS words, zeroed before the build
+    uint32_t *g_idx;              // 2 npad: the list slot of the node that inserted the slot's key
+    uint32_t *g_rep;              // 2 npad: list slot of the representative of every node of the levels 0..top
+    uint32_t *g_list;             // list slot -> node
+    unsigned long long *g_ctr;    // RUN_CTRS words, zeroed before the build; word 10: bit 0 a list ran out of room, bit 1 the
+                                  // group was dropped but its columns have no slabs
     unsigned g_gen;               // generation of level 0 (level l uses g_gen + l); < 4096 - RUN_MAX_LEVELS
 };
 // R: all lists, bitmaps and leader tables of the levels 0..top (two or three launches, no hashing)
@@ -210,17 +232,17 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt 
 void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt = nullptr);
 // writes the copies / non-representatives of the levels 0..top (whole-tree comparisons, single trees that outlive the call)
 void launch_fill_virtual(const MerkleBuild &b, hipStream_t s);
-// from level `first_level` (at most 512 nodes per column; its nodes are resolved through `meta` when given) to the root,
-// one workgroup per column
-void launch_merkle_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
-                       size_t ncols, const RunMeta *meta, hipStream_t s, const KTime *kt = nullptr);
+// from level `first_level` (at most 512 nodes per column, found through t) to the root, one workgroup per column; the levels
+// it computes go to t.upper (a build with lists) or the slabs
+void launch_merkle_top(const TreeRef &t, unsigned first_level, unsigned height, size_t ncols, hipStream_t s, const KTime *kt = nullptr);
 // K5: leaf hashes.  tree[c][i] = SHA3(LE64(i < n_values ? vals[c][i] : 0)), i < npad
+// (cols: the columns to work on, default all; slabs: for entry k of cols the index of its slab in d_tree, default the column)
 void launch_keccak_leaves(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad,
                           uint8_t *d_tree, size_t tree_stride_nodes, size_t ncols, hipStream_t s, const KTime *kt = nullptr,
-                          const ColMap *cols = nullptr);
+                          const ColMap *cols = nullptr, const ColMap *slabs = nullptr);
 // K6: one level.  out node i = SHA3(in node 2i || in node 2i+1), i < n_out  (node offsets per column)
 void launch_keccak_level(uint8_t *d_tree, size_t tree_stride_nodes, size_t in_off, size_t out_off, size_t n_out,
-                         size_t ncols, hipStream_t s, const KTime *kt = nullptr, const ColMap *cols = nullptr);
+                         size_t ncols, hipStream_t s, const KTime *kt = nullptr, const ColMap *slabs = nullptr);
 // Small-domain columns (values < 128 by construction: the instruction-field columns of the witness, x0, is_read): leaf
 // digests and level-1 nodes are looked up in two constant tables instead of hashed -- T0[v] = SHA3(LE64(v)), v < 128, and
 // T1[a*128+b] = SHA3(T0[a] || T0[b]) (128 + 16384 digests in tree form, 516 KiB) -- whenever all 128 values under a
@@ -234,22 +256,27 @@ inline size_t sd_todo_words(size_t npad, size_t ncols) { return 2 * ncols * ((np
 void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n_values, size_t npad, uint8_t *d_tree,
                              size_t tree_stride_nodes, const ColMap &cols, const uint8_t *d_tables,
                              unsigned long long *d_todo_count, uint32_t *d_todo, hipStream_t s, const KTime *kt = nullptr,
-                             bool write_leaves = true, const unsigned long long *d_only_if = nullptr);
+                             bool write_leaves = true, const unsigned long long *d_only_if = nullptr,
+                             const ColMap *slabs = nullptr);
 // true when launch_keccak_level runs k_keccak_level<HPT> (several hashes per thread) for this level
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K7: authentication paths.  For column c: index d_idx[c]; siblings -> d_sib[c][l][32], dirs -> d_dirs[c][l],
 // leaf value -> d_leaf[c].
-void launch_paths(const uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, size_t n_values, unsigned height,
-                  const uint32_t *d_vals, size_t val_stride, const uint64_t *d_idx, uint8_t *d_sib,
-                  uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s, const RunMeta *meta = nullptr);
+void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
+                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s);
+// a TreeRef for plain node-addressed trees (column c -> slab c)
+TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad);
 // copies node `node` of every column's tree into d_out[c][32]
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s);
-// the roots (node `node` of every column, canonical bytes) and behind them six u64 counters of the build -- [0] d_r_ctr[0],
-// [1] / [2] d_sd_ctr[0] / [1], [3] d_g_ctr[0], [4] d_g_ctr[8], [5] d_g_ctr[9]; null pointers read as 0 -- in ONE buffer
-void launch_job_summary(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
-                        const unsigned long long *d_r_ctr, const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr,
-                        hipStream_t s);
+// The roots (canonical bytes) and behind them the counters of the build, in ONE buffer: ncols x 32 B, then JOB_SUMMARY_WORDS u64:
+//   [0] d_r_ctr[0] (nodes hashed on the run-aware levels), [1] / [2] d_sd_ctr[0] / [1] (waves that left the small-domain
+//   tables), [3] d_g_ctr[0] (digests computed on the content-addressed levels), [4] d_g_ctr[8] (group dropped?), [5] d_g_ctr[9]
+//   (its distinct leaves), [6] d_r_ctr[10] | d_g_ctr[10] << 8 (out of room / slabs missing), then per level l < RUN_MAX_LEVELS
+//   the longest sub-list of the R lists [8 + l] and of the G lists [8 + RUN_MAX_LEVELS + l]; null pointers read as 0
+constexpr unsigned JOB_SUMMARY_WORDS = 8 + 2 * RUN_MAX_LEVELS;
+void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
+                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s);
 // gather element 0 of each column of a strided table
 void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s);
 // K9: Lasso fingerprints (src/lookups/lasso_prover.zig:208-239): rows x width canonical u32 -> u32

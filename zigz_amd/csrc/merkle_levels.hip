@@ -39,31 +39,50 @@ size_t runs_stage_scratch_bytes(size_t npad, size_t ncols) {
     return b;
 }
 
-LevelLists runs_lists(size_t npad, size_t ncols) {
+static void stage_shape(size_t npad, unsigned l, size_t &seg, size_t &nseg, unsigned &rel) {  // the stage that emits level l
+    const unsigned s = l == 0 ? 0 : (l - 1) / RUN_STAGE_LEVELS;
+    const size_t n_in = npad >> (s * RUN_STAGE_LEVELS);
+    seg = n_in < RUN_SEG ? n_in : RUN_SEG;
+    nseg = n_in / seg;
+    rel = l - s * RUN_STAGE_LEVELS;
+}
+LevelLists runs_lists(size_t npad, size_t ncols, const unsigned *cap_in) {
     LevelLists L{};
     L.top = run_top_level(npad);
     unsigned long long at = 0;
     for (unsigned l = 0; l <= L.top; l++) {
-        const unsigned s = l == 0 ? 0 : (l - 1) / RUN_STAGE_LEVELS;
-        const size_t n_in = npad >> (s * RUN_STAGE_LEVELS);
-        const size_t seg = n_in < RUN_SEG ? n_in : RUN_SEG;
-        const size_t units = ncols * (n_in / seg);  // (column, segment) pairs of the stage
-        const size_t per_unit = seg >> (l - s * RUN_STAGE_LEVELS);
+        size_t seg, nseg;
+        unsigned rel;
+        stage_shape(npad, l, seg, nseg, rel);
+        const size_t units = ncols * nseg;  // (column, segment) pairs of the stage
+        const size_t worst = (units + RUN_SUBS - 1) / RUN_SUBS * (seg >> rel);
         L.base[l] = at;
-        L.cap[l] = (unsigned)((units + RUN_SUBS - 1) / RUN_SUBS * per_unit);
+        L.cap[l] = (unsigned)(cap_in && cap_in[l] && cap_in[l] < worst ? cap_in[l] : worst);
         at += (unsigned long long)L.cap[l] * RUN_SUBS;
     }
     L.entries = at;
     return L;
 }
-LevelLists cons_lists(size_t npad) {
+size_t runs_units(size_t npad, size_t ncols, unsigned long long ubase_off[RUN_MAX_LEVELS]) {
+    size_t at = 0;
+    const unsigned top = run_top_level(npad);
+    for (unsigned l = 0; l <= top; l++) {
+        size_t seg, nseg;
+        unsigned rel;
+        stage_shape(npad, l, seg, nseg, rel);
+        ubase_off[l] = at;
+        at += ncols * nseg;
+    }
+    return at;
+}
+LevelLists cons_lists(size_t npad, const unsigned *cap_in) {
     LevelLists L{};
     L.top = run_top_level(npad);
     unsigned long long at = 0;
     for (unsigned l = 0; l <= L.top; l++) {
-        const size_t wgs = ((npad >> l) + CONS_TPB - 1) / CONS_TPB;
-        L.base[l] = at;
-        L.cap[l] = (unsigned)((wgs + RUN_SUBS - 1) / RUN_SUBS * CONS_TPB);
+        const size_t worst = ((npad >> l) + RUN_SUBS - 1) / RUN_SUBS + 64;  // every node its own representative (+ slack: the
+        L.base[l] = at;                                                     // sub-lists fill unevenly by at most a wave each)
+        L.cap[l] = (unsigned)(cap_in && cap_in[l] && cap_in[l] < worst ? cap_in[l] : worst);
         at += (unsigned long long)L.cap[l] * RUN_SUBS;
     }
     L.entries = at;
@@ -202,9 +221,10 @@ __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stag
         if (lane == r) my_tot = tot;
         const unsigned l_abs = l_in + r;
         if (lane < w) {
-            const size_t e = run_meta_base(b.npad, b.meta.ncols, l_abs) + ((size_t)y * (b.npad >> l_abs) + (first >> r)) / 64 + lane;
-            b.meta.bitmap[e] = need;
-            b.meta.prev[e] = (unsigned short)prev;
+            const size_t e = run_meta_base(b.npad, b.t.ncols, l_abs) + ((size_t)y * (b.npad >> l_abs) + (first >> r)) / 64 + lane;
+            b.t.bitmap[e] = need;
+            b.t.prev[e] = (unsigned short)prev;
+            b.t.woff[e] = (unsigned short)(incl - cnt);
         }
         need_r[r] = need;
         off_r[r] = incl - cnt;
@@ -218,20 +238,26 @@ __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stag
         fv[lane] = fv_mine;
         if (lane == 0) *inner = I;
     }
-    // one list reservation per level, each by a lane of its own (the sub-list counters sit in lines of their own)
-    unsigned long long my_base = 0;
+    // one list reservation per level, each by a lane of its own (the sub-list counters sit in lines of their own).  The unit's
+    // first slot goes to t.ubase: with the per-chunk offsets above it is how a reader finds a node's digest in list order.
+    unsigned my_slot = 0, my_room = 0;  // lane r: first list slot of this unit at relative level r, and how many entries fit
     if (lane <= rmax && (STAGE0 || lane != 0)) {
         const unsigned l_abs = l_in + lane;
         const unsigned sub = (y * nseg + segi) % RUN_SUBS;
-        my_base = b.r_lists.base[l_abs] + (unsigned long long)sub * b.r_lists.cap[l_abs] +
-                  atomicAdd(&b.r_ctr[run_ctr_index(l_abs, sub)], (unsigned long long)my_tot);
+        const unsigned cap = b.t.r_lists.cap[l_abs];
+        const unsigned long long pos = atomicAdd(&b.r_ctr[run_ctr_index(l_abs, sub)], (unsigned long long)my_tot);
+        if (pos + my_tot > cap) atomicOr(&b.r_ctr[10], 1ull);  // out of room: zigz_commit_roots repeats the build with more
+        my_room = pos >= cap ? 0u : (unsigned)(cap - pos < my_tot ? cap - pos : my_tot);
+        my_slot = sub * cap + (unsigned)(pos < cap ? pos : cap);
+        b.t.ubase[b.t.ubase_off[l_abs] + (size_t)y * nseg + segi] = my_slot;
     }
     // 3. the list entries of every level: word by word (wave-uniform), lane j <-> node j of the word, so a word's entries go out
     // as one coalesced store; words without a hashed node are skipped
 #pragma unroll
     for (unsigned r = 0; r <= RUN_STAGE_LEVELS; r++) {
         if (r > rmax || (!STAGE0 && r == 0)) continue;
-        const unsigned long long base = __shfl(my_base, r);
+        const unsigned slot0 = __shfl(my_slot, r), room = __shfl(my_room, r);
+        uint32_t *list = b.r_list + b.t.r_lists.base[l_in + r];
         const size_t node0 = first >> r;
         const unsigned wr = words >> r;
         for (unsigned q = 0; q < wr; q++) {
@@ -240,16 +266,15 @@ __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stag
             if ((lo | hi) == 0) continue;
             const unsigned o = (unsigned)__builtin_amdgcn_readlane((int)off_r[r], q);
             const unsigned long long m = ((unsigned long long)hi << 32) | lo;
-            if ((m >> lane) & 1)
-                b.r_list[base + o + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0))] =
-                    ((uint32_t)y << RUN_NODE_BITS) | (uint32_t)(node0 + q * 64 + lane);
+            const unsigned at = o + __builtin_amdgcn_mbcnt_hi(hi, __builtin_amdgcn_mbcnt_lo(lo, 0));
+            if (((m >> lane) & 1) && at < room) list[slot0 + at] = ((uint32_t)y << RUN_NODE_BITS) | (uint32_t)(node0 + q * 64 + lane);
         }
     }
 }
 
 void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
     if (b.rcols.n == 0) return;
-    const unsigned top = b.r_lists.top;
+    const unsigned top = b.t.r_lists.top;
     unsigned nstages = 1;
     while (nstages * RUN_STAGE_LEVELS < top) nstages++;
     for (unsigned st = 0; st < nstages; st++) {
@@ -277,7 +302,10 @@ void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
 // generation is the level's (b.g_gen + level), so entries of earlier levels and earlier builds read as free and the table
 // is never cleared -- payload = 52 bits of the leaf tuple's fingerprint at level 0 (verified against the representative's
 // tuple when it is read back) and the pair of the children's representatives above, which IS the identity of the hash input.
-// Whoever inserts a key first is the representative of the nodes with that key (idx[slot]).
+// Whoever inserts a key first makes its node the representative of the nodes with that key: it takes the next LIST SLOT of
+// the level (idx[table slot] = list slot, list[list slot] = node), and a node's representative is known by that slot from
+// then on -- the slot is where its digests are stored (TreeRef::g_store), and the pair of the children's slots is the key of
+// the next level.
 constexpr unsigned CONS_GEN_SHIFT = 52;
 __device__ __forceinline__ unsigned long long cons_mix(unsigned long long x) {  // splitmix64 finaliser
     x ^= x >> 30; x *= 0xbf58476d1ce4e5b9ull;
@@ -305,29 +333,50 @@ __device__ __forceinline__ unsigned wave_leader(unsigned long long key, bool val
     }
     return mine;
 }
-__device__ __forceinline__ void cons_insert(unsigned long long *keys, uint32_t *idx, size_t mask, unsigned long long key,
-                                            unsigned g_cur, unsigned g_prev, uint32_t node) {
+// the next list slots of level l for the lanes of this wave that ask for one (one atomic per wave; the wave's sub-list is
+// fixed by its position in the level, so a sub-list receives at most the nodes of its own waves).  Out of room: the slot is
+// clamped to the sub-list's last one (nothing out of bounds is ever written) and the build is flagged.
+__device__ __forceinline__ unsigned cons_take_slot(const MerkleBuild &b, unsigned l, bool want, unsigned lane, size_t wave_global) {
+    const unsigned long long m = __ballot(want);
+    if (!m) return 0;
+    const unsigned sub = (unsigned)(wave_global % RUN_SUBS);
+    const unsigned cap = b.t.g_lists.cap[l];
+    unsigned long long base = 0;
+    if (lane == (unsigned)__builtin_ctzll(m)) base = atomicAdd(&b.g_ctr[run_ctr_index(l, sub)], (unsigned long long)__builtin_popcountll(m));
+    base = __shfl(base, (unsigned)__builtin_ctzll(m));
+    unsigned long long pos = base + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1));
+    if (want && pos >= cap) {
+        atomicOr(&b.g_ctr[10], 1ull);
+        pos = cap - 1;
+    }
+    return sub * cap + (unsigned)pos;
+}
+// Inserts `key`; returns true when THIS thread put it there (its node becomes the representative and must publish its list
+// slot with cons_publish).
+__device__ __forceinline__ bool cons_insert(unsigned long long *keys, size_t mask, unsigned long long key, unsigned g_cur, unsigned g_prev,
+                                            size_t *where) {
     size_t slot = cons_mix(key) & mask;
     for (size_t tries = 0; tries <= mask; tries++) {  // live keys fill at most 3/4 of the slots: a free or matching one is reached
         // look through the caches first: a key, once in its slot, stays for the rest of its generation, so a (possibly stale)
         // cached copy that shows it is proof enough -- and thousands of waves looking at the same few slots are served by their
         // CU's L1 instead of queueing at one memory channel (same-address atomic loads serialise at ~15 ns each: 125 us for
         // the 8192 waves of level 1 of a 4-step loop)
-        if (keys[slot] == key) return;
+        if (keys[slot] == key) return false;
         unsigned long long cur = __atomic_load_n(&keys[slot], __ATOMIC_RELAXED);
         for (;;) {  // until this slot holds a live key
-            if (cur == key) return;
+            if (cur == key) return false;
             const unsigned g = (unsigned)(cur >> CONS_GEN_SHIFT);
             if (g == g_cur || g == g_prev) break;  // somebody else's live key: next slot
             const unsigned long long old = atomicCAS(&keys[slot], cur, key);
-            if (old == cur) {  // this thread inserted the key: its node is the representative
-                idx[slot] = node;
-                return;
+            if (old == cur) {
+                *where = slot;
+                return true;
             }
             cur = old;
         }
         slot = (slot + 1) & mask;
     }
+    return false;
 }
 __device__ __forceinline__ uint32_t cons_lookup(const unsigned long long *keys, const uint32_t *idx, size_t mask, unsigned long long key) {
     size_t slot = cons_mix(key) & mask;
@@ -337,7 +386,6 @@ __device__ __forceinline__ uint32_t cons_lookup(const unsigned long long *keys, 
     }
     return 0xffffffffu;  // cannot happen: the key was inserted by the previous launch
 }
-
 // Second filter, per workgroup: of the wave leaders that hold the same key only the first to put it into the workgroup's key
 // set (LDS) goes to the table in memory.  A loop-dominated level then costs a handful of table accesses per 1024 nodes; without
 // it every wave of the level queues at the same few words (same-address atomics serialise at ~15 ns: 85 us for level 1).
@@ -351,6 +399,20 @@ __device__ __forceinline__ bool wg_first(unsigned long long *set, unsigned long 
         slot = (slot + 1) & (CONS_SET - 1);
     }
 }
+// the common tail of both passes: the elected lanes insert their key; the ones that put it there take a list slot for their
+// node and publish it
+__device__ __forceinline__ void cons_insert_level(const MerkleBuild &b, unsigned long long *s_set, unsigned l, unsigned long long key,
+                                                  bool elected, uint32_t node, unsigned lane, size_t wave_global) {
+    const size_t mask = 2 * b.npad - 1;
+    size_t where = 0;
+    const unsigned g = b.g_gen + l;
+    const bool won = elected && wg_first(s_set, key) && cons_insert(b.g_keys, mask, key, g, l ? g - 1 : g, &where);
+    const unsigned slot = cons_take_slot(b, l, won, lane, wave_global);
+    if (won) {
+        b.g_list[b.t.g_lists.base[l] + slot] = node;
+        b.g_idx[where] = slot;
+    }
+}
 
 __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
     __shared__ unsigned long long s_set[CONS_SET];
@@ -361,21 +423,19 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
     const bool valid = k < b.npad;
     const unsigned long long key = ((unsigned long long)b.g_gen << CONS_GEN_SHIFT) | (valid ? cons_leaf_payload(b, k) : 0);
     const unsigned ld = wave_leader(key, valid, lane);
-    if (valid && ld == lane && wg_first(s_set, key)) cons_insert(b.g_keys, b.g_idx, 2 * b.npad - 1, key, b.g_gen, b.g_gen, (uint32_t)k);
+    cons_insert_level(b, s_set, 0, key, valid && ld == lane, (uint32_t)k, lane, k / 64);
 }
 
-// Resolves level lr (every node learns its representative; representatives go onto the level's list) and, if do_insert,
-// inserts the keys of level lr + 1: node c / 2's key is the pair of the representatives of c and c + 1, which sit in
-// neighbouring lanes.
+// Resolves level lr (every node learns the list slot of its representative) and, if do_insert, inserts the keys of level
+// lr + 1: node c / 2's key is the pair of the slots of c and c + 1, which sit in neighbouring lanes.
 template <bool LEAF>
 __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
     __shared__ unsigned long long s_set[CONS_SET];
-    __shared__ unsigned s_cnt[CONS_TPB / 64];
-    __shared__ unsigned long long s_base;
     if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
+    __syncthreads();
     const size_t n = b.npad >> lr, c = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
-    const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const unsigned lane = threadIdx.x & 63;
     const bool valid = c < n;
     const size_t mask = 2 * b.npad - 1;
     const unsigned g_r = b.g_gen + lr;
@@ -393,36 +453,28 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
     uint32_t r = 0xffffffffu;
     if (valid && ld == lane) r = cons_lookup(b.g_keys, b.g_idx, mask, key);
     r = __shfl(r, ld);
-    if (valid) {
-        if (r == 0xffffffffu) r = (uint32_t)c;
-        if (LEAF && r != c) {  // equal fingerprints are not yet equal tuples: verify, else this leaf stands for itself
+    bool alone = false;  // (leaves only) equal fingerprints are not yet equal tuples: verify against the representative's tuple,
+    if (LEAF && valid && r != 0xffffffffu) {  // else this leaf stands for itself, in a list slot of its own
+        const size_t rn = b.g_list[b.t.g_lists.base[0] + r];
+        if (rn != c)
             for (unsigned j = 0; j < b.gcols.n; j++) {
                 const uint32_t *v = b.vals + (size_t)b.gcols.c[j] * b.val_stride;
-                if ((c < b.n_values ? v[c] : 0u) != (r < b.n_values ? v[r] : 0u)) { r = (uint32_t)c; break; }
+                if ((c < b.n_values ? v[c] : 0u) != (rn < b.n_values ? v[rn] : 0u)) { alone = true; break; }
             }
-        }
-        b.g_rep[off + c] = r;
     }
-    const bool is_rep = valid && r == c;
-    // representatives go onto the level's list (one reservation per workgroup, spread over the sub-list counters)
-    const unsigned long long m = __ballot(is_rep);
-    if (lane == 0) s_cnt[wave] = (unsigned)__builtin_popcountll(m);
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned tot = 0;
-        for (int w = 0; w < CONS_TPB / 64; w++) { const unsigned t = s_cnt[w]; s_cnt[w] = tot; tot += t; }
-        const unsigned sub = blockIdx.x % RUN_SUBS;
-        s_base = b.g_lists.base[lr] + (unsigned long long)sub * b.g_lists.cap[lr] +
-                 (tot ? atomicAdd(&b.g_ctr[run_ctr_index(lr, sub)], (unsigned long long)tot) : 0ull);
+    if (valid && r == 0xffffffffu) alone = true;  // (cannot happen)
+    const unsigned own = cons_take_slot(b, lr, alone, lane, c / 64);
+    if (alone) {
+        r = own;
+        b.g_list[b.t.g_lists.base[lr] + own] = (uint32_t)c;
     }
-    __syncthreads();
-    if (is_rep) b.g_list[s_base + s_cnt[wave] + (unsigned)__builtin_popcountll(m & ((1ull << lane) - 1))] = (uint32_t)c;
+    if (valid) b.g_rep[off + c] = r;
     if (do_insert) {
         const uint32_t r_hi = __shfl_down(r, 1);
-        const bool own = valid && !(c & 1);
+        const bool mine = valid && !(c & 1);
         const unsigned long long k2 = ((unsigned long long)(g_r + 1) << CONS_GEN_SHIFT) | ((unsigned long long)r << RUN_NODE_BITS) | r_hi;
-        const unsigned ld2 = wave_leader(k2, own, lane);
-        if (own && ld2 == lane && wg_first(s_set, k2)) cons_insert(b.g_keys, b.g_idx, mask, k2, g_r + 1, g_r, (uint32_t)(c >> 1));
+        const unsigned ld2 = wave_leader(k2, mine, lane);
+        cons_insert_level(b, s_set, lr + 1, k2, mine && ld2 == lane, (uint32_t)(c >> 1), lane, c / 128);
     }
 }
 
@@ -432,14 +484,16 @@ __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if (threadIdx.x == 0) {
+        const bool drop = c > b.npad / 4;
         b.g_ctr[9] = c;
-        b.g_ctr[8] = c > b.npad / 4 ? 1 : 0;
+        b.g_ctr[8] = drop ? 1 : 0;
+        if (drop && !b.g_has_slabs) atomicOr(&b.g_ctr[10], 2ull);  // nowhere to build the columns densely: the build is repeated
     }
 }
 
 void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
     if (b.gcols.n == 0) return;
-    const unsigned top = b.g_lists.top;
+    const unsigned top = b.t.g_lists.top;
     const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB));
     if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b);
     else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b);
@@ -456,8 +510,8 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
 // ------------------------------------------------------------------ hashing a level from its lists
 // Level L of the R and G columns in ONE launch: [the R list][the G list x the group's columns][when the group was dropped:
 // every node of the columns in gdense].  A fixed grid strides over that index space, one hash per thread and step, every
-// lane busy whatever mix of constant and busy columns produced the lists.  Children are read where their digests are:
-// an R child through its leader, a G child through its representative.
+// lane busy whatever mix of constant and busy columns produced the lists.  A list entry's digest is stored at ITS LIST SLOT;
+// children are read where their digests are: an R child at its leader's slot, a G child at its representative's.
 // PAUSE = false for the small levels, whose few waves run alone on their SIMDs (keccak.hpp).
 template <bool LEAF, bool PAUSE>
 __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
@@ -467,7 +521,9 @@ __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, C
     if (wave < 2) {
         const bool use = wave == 0 ? b.rcols.n != 0 : (b.gcols.n != 0 && !dropped);
         const unsigned long long *ctr = wave == 0 ? b.r_ctr : b.g_ctr;
-        const unsigned long long c = use && lane < RUN_SUBS ? ctr[run_ctr_index(L, lane)] : 0;
+        const unsigned cap = wave == 0 ? b.t.r_lists.cap[L] : b.t.g_lists.cap[L];
+        unsigned long long c = use && lane < RUN_SUBS ? ctr[run_ctr_index(L, lane)] : 0;
+        if (c > cap) c = cap;  // (a list that ran out of room: the build is flagged and will be repeated)
         unsigned long long incl = c;
 #pragma unroll
         for (int off = 1; off < 64; off <<= 1) {
@@ -480,55 +536,62 @@ __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, C
     }
     __syncthreads();
     const size_t n_L = b.npad >> L;
-    const size_t cR = s_r[RUN_SUBS], cG = s_g[RUN_SUBS] * b.gcols.n, cD = dropped ? (size_t)gdense.n * n_L : 0;
+    const size_t cR = s_r[RUN_SUBS], cG = s_g[RUN_SUBS] * b.gcols.n, cD = (dropped && b.g_has_slabs) ? (size_t)gdense.n * n_L : 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // nodes hashed by the whole build
         if (cR) atomicAdd(&b.r_ctr[0], (unsigned long long)cR);
         if (cG) atomicAdd(&b.g_ctr[0], (unsigned long long)cG);
     }
     const size_t total = cR + cG + cD;
-    const size_t out_off = 2 * b.npad - 2 * n_L;
-    const size_t in_off = LEAF ? 0 : 2 * b.npad - 2 * (b.npad >> (L - 1));
 #pragma unroll 1
     for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * TPB) {
-        size_t col, k, c0 = 0, c1 = 0;
+        size_t col, k;
+        uint8_t *out;
+        const uint8_t *in0 = nullptr, *in1 = nullptr;
         if (e < cR) {
             unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
 #pragma unroll
             for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
                 if (s_r[sub + step] <= e) sub += step;
-            const uint32_t ent = b.r_list[b.r_lists.base[L] + (size_t)sub * b.r_lists.cap[L] + (e - s_r[sub])];
+            const size_t slot = (size_t)sub * b.t.r_lists.cap[L] + (e - s_r[sub]);
+            const uint32_t ent = b.r_list[b.t.r_lists.base[L] + slot];
             const unsigned y = ent >> RUN_NODE_BITS;
             col = b.rcols.c[y];
             k = ent & ((1u << RUN_NODE_BITS) - 1);
+            out = r_slot_ptr(b.t, L, slot);
             if (!LEAF) {
-                c0 = run_leader(b.meta, b.npad, y, L - 1, 2 * k);
-                c1 = run_leader(b.meta, b.npad, y, L - 1, 2 * k + 1);
+                in0 = r_slot_ptr(b.t, L - 1, r_slot(b.t, y, L - 1, 2 * k));
+                in1 = r_slot_ptr(b.t, L - 1, r_slot(b.t, y, L - 1, 2 * k + 1));
             }
         } else if (e < cR + cG) {
             const size_t t = e - cR, ei = t / b.gcols.n;
-            col = b.gcols.c[t % b.gcols.n];
+            const unsigned j = (unsigned)(t % b.gcols.n);
+            col = b.gcols.c[j];
             unsigned sub = 0;
 #pragma unroll
             for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
                 if (s_g[sub + step] <= ei) sub += step;
-            k = b.g_list[b.g_lists.base[L] + (size_t)sub * b.g_lists.cap[L] + (ei - s_g[sub])];
+            const size_t slot = (size_t)sub * b.t.g_lists.cap[L] + (ei - s_g[sub]);
+            k = b.g_list[b.t.g_lists.base[L] + slot];
+            out = g_slot_ptr(b.t, L, slot, j);
             if (!LEAF) {
-                const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + in_off + 2 * k);
-                c0 = p.x;
-                c1 = p.y;
+                const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + slab_level_offset(b.npad, L - 1) + 2 * k);
+                in0 = g_slot_ptr(b.t, L - 1, p.x, j);
+                in1 = g_slot_ptr(b.t, L - 1, p.y, j);
             }
         } else {
             const size_t t = e - cR - cG;
             col = gdense.c[t / n_L];
             k = t & (n_L - 1);
-            c0 = 2 * k;
-            c1 = 2 * k + 1;
+            out = slab_ptr(b.t, col, L, k);
+            if (!LEAF) {
+                in0 = slab_ptr(b.t, col, L - 1, 2 * k);
+                in1 = in0 + 32;
+            }
         }
-        uint8_t *tr = b.tree + col * b.tree_stride_nodes * 32;
         Digest d;
         if (LEAF) d = sha3_leaf<PAUSE>((uint64_t)(k < b.n_values ? b.vals[col * b.val_stride + k] : 0u));
-        else d = sha3_node<PAUSE>(load_digest(tr, in_off + c0), load_digest(tr, in_off + c1));
-        store_digest_plain(tr, out_off + k, d);
+        else d = sha3_node<PAUSE>(load_digest_at(in0), load_digest_at(in1));
+        store_digest_at(out, d);
     }
 }
 
@@ -554,72 +617,60 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
 
 // ------------------------------------------------------------------ the top of the trees
 // From a level of at most 2 TPB nodes up to the root in ONE launch, one workgroup per column; levels hand over through
-// global memory + a workgroup barrier on the same CU.  Every hash here is a link in a dependent chain run by a few lone
-// waves, so the permutation is the variant without re-arm pauses.
-__global__ __launch_bounds__(TPB) void k_merkle_top(uint8_t *__restrict__ tree, size_t tree_stride_nodes, size_t npad,
-                                                    unsigned first_level, unsigned height, RunMeta meta, int have_meta) {
+// LDS.  Every hash here is a link in a dependent chain run by a few lone waves, so the permutation is the variant without
+// re-arm pauses.  The levels it computes go to TreeRef::upper (a build with lists) or into the slabs.
+__global__ __launch_bounds__(TPB) void k_merkle_top(TreeRef t, unsigned first_level, unsigned height) {
     __shared__ Digest s_d[TPB];  // the level just computed: the next one reads its children here, not from global memory
     const size_t col = blockIdx.y;
-    uint8_t *t = tree + col * tree_stride_nodes * 32;
     for (unsigned l = first_level; l < height; l++) {
-        const size_t n_out = npad >> (l + 1);
-        const size_t in_off = 2 * npad - 2 * (npad >> l), out_off = 2 * npad - 2 * (npad >> (l + 1));
+        const size_t n_out = t.npad >> (l + 1);
         Digest d;
         if (threadIdx.x < n_out) {
             Digest a, c;
             if (l == first_level) {
-                size_t c0 = 2 * threadIdx.x, c1 = c0 + 1;
-                if (have_meta) {
-                    c0 = resolve_node(meta, npad, col, l, c0);
-                    c1 = resolve_node(meta, npad, col, l, c1);
-                }
-                a = load_digest(t, in_off + c0);
-                c = load_digest(t, in_off + c1);
+                a = load_digest_at(node_ptr(t, col, l, 2 * threadIdx.x));
+                c = load_digest_at(node_ptr(t, col, l, 2 * threadIdx.x + 1));
             } else {
                 a = s_d[2 * threadIdx.x];
                 c = s_d[2 * threadIdx.x + 1];
             }
             d = sha3_node<false>(a, c);
-            store_digest_plain(t, out_off + threadIdx.x, d);
+            store_digest_at(t.lists ? upper_ptr(t, col, l + 1, threadIdx.x) : slab_ptr(t, col, l + 1, threadIdx.x), d);
         }
         __syncthreads();  // everybody has read its children
         if (threadIdx.x < n_out) s_d[threadIdx.x] = d;
         __syncthreads();
     }
 }
-void launch_merkle_top(uint8_t *d_tree, size_t tree_stride_nodes, size_t npad, unsigned first_level, unsigned height,
-                       size_t ncols, const RunMeta *meta, hipStream_t s, const KTime *kt) {
-    RunMeta m{};
-    if (meta) m = *meta;
-    ZK_LAUNCH(kt, k_merkle_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, d_tree, tree_stride_nodes, npad, first_level, height, m,
-              meta ? 1 : 0);
+void launch_merkle_top(const TreeRef &t, unsigned first_level, unsigned height, size_t ncols, hipStream_t s, const KTime *kt) {
+    ZK_LAUNCH(kt, k_merkle_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, t, first_level, height);
 }
 
-// ------------------------------------------------------------------ materialising the virtual nodes
-__global__ __launch_bounds__(TPB) void k_runs_fill_level(MerkleBuild b, unsigned L) {
-    const size_t n = b.npad >> L, k = (size_t)blockIdx.x * TPB + threadIdx.x;
+// ------------------------------------------------------------------ materialising whole trees
+// every node of level L of the R / G columns (list levels) and of the levels above them (all columns) into the slabs
+__global__ __launch_bounds__(TPB) void k_fill_level(TreeRef t, unsigned L, ColMap cols) {
+    const size_t n = t.npad >> L, k = (size_t)blockIdx.x * TPB + threadIdx.x;
     if (k >= n) return;
-    const size_t ld = run_leader(b.meta, b.npad, blockIdx.y, L, k);
-    if (ld == k) return;
-    uint8_t *tr = b.tree + (size_t)b.rcols.c[blockIdx.y] * b.tree_stride_nodes * 32;
-    const size_t off = 2 * b.npad - 2 * n;
-    store_digest(tr, off + k, load_digest(tr, off + ld));
-}
-__global__ __launch_bounds__(TPB) void k_cons_fill_level(MerkleBuild b, unsigned L) {
-    if (b.g_ctr[8]) return;
-    const size_t n = b.npad >> L, k = (size_t)blockIdx.x * TPB + threadIdx.x;
-    if (k >= n) return;
-    const size_t off = 2 * b.npad - 2 * n;
-    const uint32_t r = b.g_rep[off + k];
-    if (r == k) return;
-    uint8_t *tr = b.tree + (size_t)b.gcols.c[blockIdx.y] * b.tree_stride_nodes * 32;
-    store_digest(tr, off + k, load_digest(tr, off + r));
+    const size_t col = cols.c[blockIdx.y];
+    const uint8_t *src = node_ptr(t, col, L, k);
+    uint8_t *dst = slab_ptr(t, col, L, k);
+    if (src != dst) store_digest_at(dst, load_digest_at(src));
 }
 void launch_fill_virtual(const MerkleBuild &b, hipStream_t s) {
-    for (unsigned L = 0; b.rcols.n && L <= b.r_lists.top; L++)
-        hipLaunchKernelGGL(k_runs_fill_level, dim3((unsigned)(((b.npad >> L) + TPB - 1) / TPB), b.rcols.n), dim3(TPB), 0, s, b, L);
-    for (unsigned L = 0; b.gcols.n && L <= b.g_lists.top; L++)
-        hipLaunchKernelGGL(k_cons_fill_level, dim3((unsigned)(((b.npad >> L) + TPB - 1) / TPB), b.gcols.n), dim3(TPB), 0, s, b, L);
+    if (!b.t.lists) return;
+    unsigned height = 0;
+    while (((size_t)1 << height) < b.npad) height++;
+    ColMap rg{};  // the columns whose list levels live in the stores
+    for (unsigned c = 0; c < 64; c++)
+        if (b.t.y_of_col[c] >= 0 || b.t.g_j_of_col[c] >= 0) rg.c[rg.n++] = (uint8_t)c;
+    ColMap all{};
+    for (unsigned c = 0; c < 64; c++)
+        if (b.t.slab_of_col[c] >= 0) all.c[all.n++] = (uint8_t)c;
+    for (unsigned L = 0; L <= height; L++) {
+        const ColMap &m = L <= b.t.top ? rg : all;
+        if (m.n == 0) continue;
+        hipLaunchKernelGGL(k_fill_level, dim3((unsigned)(((b.npad >> L) + TPB - 1) / TPB), m.n), dim3(TPB), 0, s, b.t, L, m);
+    }
 }
 
 }  // namespace zk

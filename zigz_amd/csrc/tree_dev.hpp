@@ -46,22 +46,64 @@ __device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, c
     q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
 }
 
-// the node whose digest node k of level l of hinted (R) column y has: itself if it was hashed, else the nearest hashed node
-// before it in its tile (kernels.hpp: RunMeta, run_tile_nodes)
-__device__ __forceinline__ size_t run_leader(const RunMeta &m, size_t npad, unsigned y, unsigned l, size_t k) {
-    const size_t e = run_meta_base(npad, m.ncols, l) + ((size_t)y * (npad >> l) + k) / 64;
+// ---- where a digest lives (kernels.hpp: TreeRef)
+__device__ __host__ __forceinline__ size_t slab_level_offset(size_t npad, unsigned l) { return 2 * npad - 2 * (npad >> l); }
+// the list slot (within level l) that holds the digest of node k of hinted (R) column y: its own if it was hashed, else its
+// leader's -- the nearest hashed node before it in its tile (kernels.hpp: run_tile_nodes)
+__device__ __forceinline__ size_t r_slot(const TreeRef &t, unsigned y, unsigned l, size_t k) {
+    const size_t n_l = t.npad >> l, tile = run_tile_nodes(t.npad, l);
+    const size_t e0 = run_meta_base(t.npad, t.ncols, l) + ((size_t)y * n_l) / 64;
+    size_t e = e0 + k / 64;
     const unsigned q = (unsigned)(k & 63);
-    const unsigned long long mm = m.bitmap[e] & (q == 63 ? ~0ull : ((2ull << q) - 1));
-    if (mm) return (k & ~(size_t)63) + (63 - __builtin_clzll(mm));
-    return (k & ~(run_tile_nodes(npad, l) - 1)) + m.prev[e];
+    unsigned long long m = t.bitmap[e] & (q == 63 ? ~0ull : ((2ull << q) - 1));  // hashed nodes of the chunk at or before k
+    size_t j;
+    if (m) {
+        j = (k & ~(size_t)63) + (63 - __builtin_clzll(m));
+        m &= ~(1ull << (j & 63));  // hashed nodes of the chunk before the leader
+    } else {                       // nothing in this chunk: the last hashed node before it
+        j = (k & ~(tile - 1)) + t.prev[e];
+        e = e0 + j / 64;
+        m = t.bitmap[e] & ((1ull << (j & 63)) - 1);
+    }
+    const size_t u = (size_t)y * (n_l / tile) + j / tile;
+    return (size_t)t.ubase[t.ubase_off[l] + u] + t.woff[e] + (unsigned)__builtin_popcountll(m);
 }
-// where the digest of node k of level l of column col is stored: the node itself unless the level was built from lists
-__device__ __forceinline__ size_t resolve_node(const RunMeta &m, size_t npad, size_t col, unsigned l, size_t k) {
-    if (col >= 64) return k;
-    const int y = m.y_of_col[col];
-    if (y >= 0 && l < m.run_levels) return run_leader(m, npad, (unsigned)y, l, k);
-    if (((m.cons_mask >> col) & 1) && l < m.cons_levels && !*m.cons_dropped) return m.cons_rep[2 * npad - 2 * (npad >> l) + k];
-    return k;
+__device__ __forceinline__ uint8_t *r_slot_ptr(const TreeRef &t, unsigned l, size_t slot) {
+    return t.r_store + (t.r_lists.base[l] + slot) * 32;
+}
+__device__ __forceinline__ uint8_t *g_slot_ptr(const TreeRef &t, unsigned l, size_t slot, unsigned j) {
+    return t.g_store + ((t.g_lists.base[l] + slot) * t.g_ncols + j) * 32;
+}
+__device__ __forceinline__ uint8_t *slab_ptr(const TreeRef &t, size_t col, unsigned l, size_t k) {
+    if (col < 64 && t.slab_of_col[col] < 0)  // a dropped group whose columns have no slabs: the build is flagged and will be
+        return t.upper;                      // repeated; until then nothing may point outside the job's memory
+    const size_t s = col < 64 ? (size_t)t.slab_of_col[col] : col;
+    return t.slab + (s * 2 * t.npad + slab_level_offset(t.npad, l) + k) * 32;
+}
+__device__ __forceinline__ uint8_t *upper_ptr(const TreeRef &t, size_t col, unsigned l, size_t k) {
+    return t.upper + (col * 512 + 512 - 2 * ((size_t)256 >> (l - t.top)) + k) * 32;
+}
+// the address of the digest of node k of level l of column col
+__device__ __forceinline__ uint8_t *node_ptr(const TreeRef &t, size_t col, unsigned l, size_t k) {
+    if (t.lists) {
+        if (l > t.top) return upper_ptr(t, col, l, k);
+        if (col < 64) {
+            const int y = t.y_of_col[col];
+            if (y >= 0) return r_slot_ptr(t, l, r_slot(t, (unsigned)y, l, k));
+            const int j = t.g_j_of_col[col];
+            if (j >= 0 && !*t.g_dropped) return g_slot_ptr(t, l, t.g_rep[slab_level_offset(t.npad, l) + k], (unsigned)j);
+        }
+    }
+    return slab_ptr(t, col, l, k);
+}
+__device__ __forceinline__ Digest load_digest_at(const uint8_t *p) {
+    const ulonglong2 *q = reinterpret_cast<const ulonglong2 *>(p);
+    const ulonglong2 x = q[0], y = q[1];
+    return Digest{{x.x, x.y, y.x, y.y}};
+}
+__device__ __forceinline__ void store_digest_at(uint8_t *p, const Digest &d) {
+    unsigned long long *q = reinterpret_cast<unsigned long long *>(p);
+    q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
 }
 
 }  // namespace zk
