@@ -285,8 +285,8 @@ def main():
     ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
                     "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
                     "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
-                    "bounded by the host cores: 14 lanes, ~480 M steps/s); -1 (default) = half of this rank's CPUs, at most 8 "
-                    "(64 proofs in flight: 218 GiB of HBM), or 0 without AVX-512F")
+                    "bounded by the host cores: 14 lanes, ~480 M steps/s); -1 (default) = 5/8 of this rank's CPUs, at most 12 "
+                    "(10 on a 16-CPU share: 80 proofs in flight, ~50 GiB of HBM), or 0 without AVX-512F")
     ap.add_argument("--mode", choices=["traces", "shard"], default="traces",
                     help="traces (default, the headline): every GPU proves its own traces, no data-path collective, weak "
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
@@ -430,7 +430,10 @@ def main():
     shard = args.mode == "shard"
     servers = args.sponge_servers
     if servers < 0:
-        servers = 0 if shard or not has_avx512f() else max(1, min(8, host_cpus() // max(world, 1) // 2))
+        # a server is one busy core per 8 proofs in flight; the lanes' own threads, the serialiser helpers and the runtime's
+        # event thread need ~2.6 ms of CPU per proof on top: 10 servers on a 16-CPU share leave them 6 cores (11 servers use
+        # 15.9 of the 16 and are 7 % faster when nothing else runs; 12 are over the quota and 15 % slower)
+        servers = 0 if shard or not has_avx512f() else max(1, min(12, host_cpus() // max(world, 1) * 5 // 8))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
@@ -440,8 +443,10 @@ def main():
         probe = zigz_amd.Context(local_rank)
         hbm_free = probe.mem_info()[0]
         probe.close()
-        per_lane = int(3.6 * (1 << 30) * (1 << max(args.nv - 20, 0)))
-        B = max(1, min(B, int(hbm_free * 0.92) // per_lane))
+        # (~0.6 GiB at 2^20 on the bench trace with the digests in list order; a trace that does not loop needs ~2.3 GiB --
+        # slabs for the dropped group, longer lists -- and the legs below run such traces on the same lanes: budget for that)
+        per_lane = int(2.4 * (1 << 30) * (1 << max(args.nv - 20, 0)))
+        B = max(1, min(B, int(hbm_free * 0.9) // per_lane))
     blocking = B + servers + 2 > host_cpus() // max(world, 1)  # more threads than cores: wait for the GPU asleep, not spinning
     if os.environ.get("ZIGZ_BENCH_BLOCKING_SYNC"):
         blocking = os.environ["ZIGZ_BENCH_BLOCKING_SYNC"] == "1"
@@ -552,6 +557,7 @@ def main():
                 out.append(fn(l))
             return out
         sync_all()
+        c0 = time.process_time()
         t0 = time.perf_counter()
         futs = [pool.submit(lane_loop, l) for l in ls]
         for f in futs:
@@ -561,6 +567,7 @@ def main():
                 for k, v in ph.items():
                     phases[k] = phases.get(k, 0.0) + v
         sync_all()
+        acc["process_cpu_s"] = time.process_time() - c0  # all threads of this process (lanes, sponge servers, helpers)
         return time.perf_counter() - t0, acc, phases
 
     run_step()  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
@@ -568,7 +575,18 @@ def main():
         run_step()
     for l in lanes:
         l.ctx.enable_timing(True)
+    if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import thread_cpu
+        snap0 = thread_cpu.snapshot()
     dt, acc, phases = timed(args.steps)          # ---- THE timed region
+    if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
+        rows, by = thread_cpu.diff(snap0, thread_cpu.snapshot())
+        sys.stderr.write("thread CPU over the timed region (%.2f s wall):\n" % dt)
+        for comm, (n, sec) in by:
+            sys.stderr.write("  %-20s threads %3d  cpu %.2f s\n" % (comm, n, sec))
+        allrows, _ = thread_cpu.diff(snap0, thread_cpu.snapshot(), top=10000)
+        sys.stderr.write("  per thread, descending: " + " ".join("%.2f" % r[0] for r in allrows) + "\n")
     nproofs = args.steps * B
     local_steps = float(sum(l.trace.num_steps for l in lanes))
     trace_steps, trace_lookups, prog = lanes[0].trace.num_steps, lanes[0].trace.num_lookups, lanes[0].prog
@@ -694,7 +712,7 @@ def main():
         for nv_s, steps_s in ((16, 10), (22, 3), (24, 2)):
             if nv_s == nv:
                 continue
-            per_lane = int(3.6 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+            per_lane = int(2.4 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
             nl = max(1, min(B, int(free_now * 0.85) // per_lane))
             ls = [Lane(k, nv_s) for k in range(nl)]
             run_step(which=ls)
@@ -859,6 +877,8 @@ def main():
         if kern:
             detail["kernel_leg"] = {k: {"frac": v["frac"], "avg_us": v["avg_us"]} for k, v in kern.items()}
         detail["host_phase_ms_per_proof"] = {k: v / nproofs * 1e3 for k, v in phases.items()}
+        detail["host_cpu_ms_per_proof"] = acc.get("process_cpu_s", 0.0) / nproofs * 1e3  # CPU time of all threads, per proof
+        detail["host_cpus_busy"] = acc.get("process_cpu_s", 0.0) / dt
         detail["host_keccak"] = zigz_amd._ffi.lib.zigz_host_keccak_impl().decode()
         out = {
             "metric": "trace steps/sec proved (BabyBear, 2^%d RV64I trace)" % nv,

@@ -1020,3 +1020,141 @@ def test_ref_polynomial_commit_kats_gpu(ctx, i):
     finally:
         for t in trees:
             t.deinit()
+
+
+def _open_sets(nc, nv, N, seed):
+    rng = np.random.default_rng(seed)
+    special = [0, 1, 63, 64, 4095, 4096, N // 2, N - 2, N - 1]
+    return [np.full(nc, i) for i in special] + [rng.integers(0, N, nc) for _ in range(6)]
+
+
+def test_lists_that_outgrow_their_room_are_rebuilt(ctx):
+    """The lists of the structure-aware levels (and the digests stored in list order) are sized from what the context's earlier
+    builds needed, not for the worst case.  A job whose columns need more -- here: run-aware columns that change at every
+    leaf, after the context has only seen constant ones -- notices on the device, and zigz_commit_roots repeats the build with
+    more room: roots and openings still equal the dense build's, stats.rebuilds says what happened, and the NEXT job of the
+    same kind fits at once."""
+    import zigz_amd
+    nv, nc = 16, 8
+    N = 1 << nv
+    quiet = np.zeros((nc, N), dtype=np.uint64) + 5
+    busy = rnd(8800, nc * N).reshape(nc, N).copy()
+    busy[0, :] = 3
+    sets = _open_sets(nc, nv, N, 5)
+
+    def run(cols, mask):
+        ctx.set_option("run_aware_mask", mask)
+        try:
+            outs = []
+            for idx in sets[:4]:
+                job = zigz_amd.CommitJob(ctx, cols=cols)
+                try:
+                    roots = job.roots().copy()
+                    st = ctx.stats()
+                    pts = rnd(int(idx[0]) + 3, nc * nv).reshape(nc, nv)
+                    pts[:, 0] = idx
+                    outs.append({k: v.copy() for k, v in job.open_all(pts).items()})
+                finally:
+                    job.end()
+        finally:
+            ctx.set_option("run_aware_mask", 0)
+        return roots, outs, st
+
+    r_dense, o_dense, _ = run(busy, 0)
+    r0 = ctx.stats()["rebuilds"]
+    run(quiet, 0xFF)                                   # the context learns: constant columns need next to nothing
+    r1 = ctx.stats()["rebuilds"]
+    r_list, o_list, st = run(busy, 0xFF)               # ... and then meets columns where every node is hashed
+    r2 = ctx.stats()["rebuilds"]
+    assert r1 == r0 and r2 >= r1 + 1, (r0, r1, r2)
+    assert r2 - r1 <= 2                                # one repeat per job at most, and only for the first job(s) of the kind
+    assert np.array_equal(r_dense, r_list)
+    assert st["run_aware_hashed"] > 7 * N              # seven random columns: (almost) every node of every list level
+    for a, b in zip(o_dense, o_list):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+    run(busy, 0xFF)
+    assert ctx.stats()["rebuilds"] == r2               # the room learnt is kept
+
+
+def test_dropped_group_gets_slabs_by_a_rebuild(ctx):
+    """A content-addressed group that does not repeat is dropped ON THE DEVICE; in a commit job its columns then have nowhere to
+    be built densely (no slabs were set aside for them), so the first such job on a context is built twice.  Openings through
+    the dropped group's columns -- small-domain members with virtual leaves included -- equal the dense build's."""
+    import zigz_amd
+    nv, nc = 15, 6
+    N = 1 << nv
+    cols = rnd(9900, nc * N).reshape(nc, N).copy()
+    cols[1, :] = np.arange(N) % 128                    # a small-domain member of the group
+    cols[2, :] = 0
+    sets = _open_sets(nc, nv, N, 9)
+
+    def run(group, sd):
+        ctx.set_option("cons_group_mask", group)
+        ctx.set_option("small_domain_mask", sd)
+        try:
+            outs = []
+            for idx in sets:
+                job = zigz_amd.CommitJob(ctx, cols=cols)
+                try:
+                    roots = job.roots().copy()
+                    st = ctx.stats()
+                    pts = rnd(int(idx[0]) + 1, nc * nv).reshape(nc, nv)
+                    pts[:, 0] = idx
+                    outs.append({k: v.copy() for k, v in job.open_all(pts).items()})
+                finally:
+                    job.end()
+        finally:
+            ctx.set_option("cons_group_mask", 0)
+            ctx.set_option("small_domain_mask", 0)
+        return roots, outs, st
+
+    r0, o0, _ = run(0, 0)
+    before = ctx.stats()["rebuilds"]
+    r1, o1, st = run(0b111, 0b110)                     # columns 0 (random), 1, 2: nothing repeats -> dropped
+    assert st["cons_columns"] == 0 and st["cons_probe_distinct"] > N // 4 and st["small_domain_columns"] == 2
+    assert ctx.stats()["rebuilds"] == before + 1       # once: the context now sets slabs aside for this group
+    assert np.array_equal(r0, r1)
+    for a, b in zip(o0, o1):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
+
+
+def test_commit_begin_does_not_wait_for_the_device(ctx):
+    """zigz_commit_begin_dev enqueues and returns (prover.zig:405-416: the trees do not depend on the transcript, so the host
+    goes on absorbing while they build): the keep / drop decision of the content-addressed group is taken on the device.  On a
+    2^20 x 43 job begin must return in a fraction of the time the build takes."""
+    import time
+    import zigz_amd
+    from zigz_amd import host
+    import programs
+    nv = 20
+    N = 1 << nv
+    tr = host.Trace(programs.add_xor_loop((N - 3) // 4), 0x1000, None, 2 * N)
+    d = ctx.dev_alloc(43 * N * 4)
+    try:
+        tr.witness_to_device(ctx, d, N)
+        ctx.set_option("small_domain_mask", (1 << 1) | (0x3f << 33) | (1 << 42))
+        ctx.set_option("run_aware_mask", (0x7fffffff << 2) | (3 << 40))
+        ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
+        begins, builds = [], []
+        for it in range(6):
+            ctx.synchronize()
+            t0 = time.perf_counter()
+            job = zigz_amd.CommitJob(ctx, d_cols=d, ncols=43, nv=nv, col_stride=N)
+            t1 = time.perf_counter()
+            job.roots()
+            t2 = time.perf_counter()
+            job.end()
+            if it >= 2:  # (the first jobs allocate workspaces and learn the list sizes)
+                begins.append(t1 - t0)
+                builds.append(t2 - t0)
+        st = ctx.stats()
+        assert st["cons_columns"] == 10 and st["run_aware_columns"] == 33
+        print("commit_begin %.3f ms, begin + build %.3f ms (2^20 x 43)" % (min(begins) * 1e3, min(builds) * 1e3))
+        assert min(begins) < 0.6e-3, begins           # ~45 launches enqueued; a build takes ~0.9 ms of device time alone
+        assert min(begins) < 0.5 * min(builds), (begins, builds)
+    finally:
+        for o in ("small_domain_mask", "run_aware_mask", "cons_group_mask"):
+            ctx.set_option(o, 0)
+        ctx.dev_free(d)

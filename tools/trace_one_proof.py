@@ -17,6 +17,8 @@ prog = programs.add_xor_loop((N - 3) // 4)
 tr = host.Trace(prog, 0x1000, None, 2 * N)
 d = ctx.dev_alloc(43 * N * 4)
 tr.witness_to_device(ctx, d, N)
+import json
 for _ in range(3):
     tr.prove(ctx, d, N, want_bytes="borrow")
 ctx.synchronize()
+print(json.dumps({k: v for k, v in ctx.stats().items() if not k.endswith("_us")}))  # what the last build hashed
