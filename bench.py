@@ -618,17 +618,27 @@ def main():
         run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
         self_check = {"lane0_alone_equals_lane0_in_batch": lanes[0].digest == digests[0]}  # single-state code, not the 8-way)
         variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
+        # (a build without the hints keeps node-addressed trees, 2.75 GiB per proof in flight at 2^20: these legs run on as
+        # many of the lanes as fit -- the GPU bounds them long before that -- and give the memory back afterwards)
+        for l in lanes:
+            l.ctx.release_workspaces()
+        vl = lanes[:max(1, min(B, int(lanes[0].ctx.mem_info()[0] * 0.85) // int(3.6 * (1 << 30) * (1 << max(nv - 20, 0)))))]
         for mode in ("cons", "struct", "regs", "all", "tables", "dense"):
             if mode == args.merkle:
                 continue
+            for l in vl:  # (workspaces only grow: what one build kept must not add to what the next one needs)
+                l.ctx.release_workspaces()
             set_merkle_mode(mode)
-            run_step(Lane.prove_and_digest)
+            run_step(Lane.prove_and_digest, which=vl)
             # ... must be byte-identical under every other build (dense hashes every node of every tree)
-            self_check["all_lanes_equal_under_" + mode] = [l.digest for l in lanes] == digests
+            self_check["lanes_equal_under_" + mode] = [l.digest for l in vl] == digests[:len(vl)]
             ks = 3 if mode in ("cons", "struct", "regs", "all") else 2
-            dtv, accv, _ = timed(ks)
-            variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * B)}
+            dtv, accv, _ = timed(ks, which=vl)
+            variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * len(vl)), "lanes": len(vl),
+                              "trace_steps": float(sum(l.trace.num_steps for l in vl))}
         set_merkle_mode(args.merkle)
+        for l in lanes:
+            l.ctx.release_workspaces()
         pcie["variants"] = variants
         pcie["self_check"] = self_check
         if not all(self_check.values()):
@@ -737,6 +747,7 @@ def main():
             pcie["dt"] = allmax(pcie["dt"])
             for vv in pcie.get("variants", {}).values():
                 vv["dt"] = allmax(vv["dt"])
+                vv["trace_steps"] = allsum(vv["trace_steps"])
             for leg in ("worst", "straight", "mixed"):
                 if leg in pcie:
                     pcie[leg]["dt"] = allmax(pcie[leg]["dt"])
@@ -856,10 +867,9 @@ def main():
                 detail["other_traces_keccak_permutations_per_proof"] = {k: pcie[k]["perms"] for k in ("worst", "straight", "mixed")}
             if pcie.get("variants"):
                 if "dense" in pcie["variants"]:
-                    vv = pcie["variants"]["dense"]
-                    cfg["dense_merkle_value"] = total_steps * vv["steps"] / vv["dt"]
+                    cfg["dense_merkle_value"] = rate(pcie["variants"]["dense"])
                 detail["merkle_variants"] = {
-                    m: {"value": total_steps * vv["steps"] / vv["dt"], "keccak_permutations_per_proof": vv["perms"]}
+                    m: {"value": rate(vv), "keccak_permutations_per_proof": vv["perms"], "proofs_in_flight": vv["lanes"]}
                     for m, vv in pcie["variants"].items()}
             if pcie.get("self_check"):
                 cfg["self_check_ok"] = bool(all(pcie["self_check"].values()))

@@ -92,6 +92,10 @@ zigz_status zigz_ctx_synchronize(zigz_ctx *ctx);
 /* Device memory for callers without their own allocator (hipMalloc / hipFree). */
 zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out);
 zigz_status zigz_dev_free(zigz_ctx *ctx, void *d_ptr);
+/* Gives the context's workspaces back to the device (they are grown on demand and otherwise kept for the life of the
+ * context: trees, lists, staging).  For a host that has just put an unusually large job through a context it keeps many of;
+ * what the context learnt about its traces (the room its lists need) stays.  ZIGZ_ERR_BAD_STATE while a commit job is active. */
+zigz_status zigz_ctx_release_workspaces(zigz_ctx *ctx);
 /* free / total HBM of the context's device (hipMemGetInfo): a service sizes its number of proofs in flight from it */
 zigz_status zigz_dev_mem_info(zigz_ctx *ctx, size_t *free_bytes, size_t *total_bytes);
 /* canonical u64 host -> packed u32 device (validates < p), and back */

@@ -94,6 +94,7 @@ SIGNATURES = {
     "zigz_dev_witness_from_steps": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_witness_from_steps_async": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_mem_info": (C.c_int32, [vp, szp, szp]),
+    "zigz_ctx_release_workspaces": (C.c_int32, [vp]),
     "zigz_host_register": (C.c_int32, [vp, vp, C.c_size_t]),
     "zigz_host_unregister": (C.c_int32, [vp, vp]),
     "zigz_dev_mle_bind": (C.c_int32, [vp, vp, C.c_size_t, C.c_uint64, vp]),

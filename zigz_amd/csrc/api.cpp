@@ -286,6 +286,21 @@ extern "C" zigz_status zigz_dev_alloc(zigz_ctx *ctx, size_t bytes, void **d_out)
     HIPCHK(ctx, hipMalloc(d_out, bytes ? bytes : 16));
     return ZIGZ_OK;
 }
+extern "C" zigz_status zigz_ctx_release_workspaces(zigz_ctx *ctx) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;  // the job's trees live in them
+    HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < WS_SLOTS; i++)
+        if (ctx->ws[i]) {
+            (void)hipFree(ctx->ws[i]);
+            ctx->ws[i] = nullptr;
+            ctx->ws_bytes[i] = 0;
+        }
+    ctx->cons_table = nullptr;  // (the content-addressing table went with them: the next build clears its new one)
+    ctx->cons_table_bytes = 0;
+    return ZIGZ_OK;
+}
 extern "C" zigz_status zigz_dev_mem_info(zigz_ctx *ctx, size_t *free_bytes, size_t *total_bytes) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !free_bytes || !total_bytes) return ZIGZ_ERR_INVALID_ARGUMENT;

@@ -124,6 +124,10 @@ class Context:
     def set_option(self, name, value):
         self.check(lib.zigz_ctx_set_option(self.h, name.encode(), int(value)))
 
+    def release_workspaces(self):
+        """give the context's workspaces back to the device (they regrow on demand)"""
+        self.check(lib.zigz_ctx_release_workspaces(self.h))
+
     def mem_info(self):
         """(free, total) bytes of HBM on this context's device"""
         f, t = C.c_size_t(), C.c_size_t()
