@@ -498,59 +498,75 @@ __global__ __launch_bounds__(TPB) void k_steps_summary(const TraceStep *__restri
     if (lane == 0) sum_has[chunk] = (uint32_t)has;
 }
 
-// One workgroup per register.  The chunks are taken in rounds of TPB consecutive chunks (coalesced reads and writes);
-// inside a round an inclusive "last defined value" scan runs over the 256 lanes (shuffles inside a wave, LDS across the
-// four waves), and the value after the round is carried into the next.  carry[r][chunk] = value of r BEFORE the chunk.
-__global__ __launch_bounds__(TPB) void k_steps_scan(const uint32_t *__restrict__ sum_val, const uint32_t *__restrict__ sum_has,
-                                                    size_t nchunks, Regs32 init, uint32_t *__restrict__ carry) {
+// Fill-forward over the chunks in two levels.  A GROUP is TPB consecutive chunks (16 Ki steps).
+//   k_steps_scan_local   one workgroup per (group, register): an inclusive "last defined value" scan over the group's 256
+//                        chunk summaries (shuffles inside a wave, LDS across the four waves) -> per chunk the value of the
+//                        register BEFORE the chunk if it was written earlier in the group, else UNDEF; per group the last value
+//                        written in it (or UNDEF)
+//   k_steps_scan_groups  one wave per register: the same scan over the group summaries, seeded with the initial register
+//                        file -> the value before each group
+// k_steps_expand reads the chunk's entry and falls back to its group's.  (One workgroup per register walking all chunks in
+// 64 dependent rounds took 60-70 us at 2^20 steps; this takes two launches of a few microseconds.)
+constexpr uint32_t STEPS_UNDEF = 0xffffffffu;  // (values are < p < 2^31)
+__global__ __launch_bounds__(TPB) void k_steps_scan_local(const uint32_t *__restrict__ sum_val, const uint32_t *__restrict__ sum_has,
+                                                          size_t nchunks, uint32_t *__restrict__ carry, uint32_t *__restrict__ gsum,
+                                                          size_t ngroups) {
     __shared__ uint32_t w_val[TPB / 64], w_has[TPB / 64];
-    __shared__ uint32_t round_carry;
-    const unsigned r = blockIdx.x + 1;
+    const unsigned r = blockIdx.y + 1;
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const uint32_t *sv = sum_val + (size_t)r * nchunks;
-    uint32_t *cr = carry + (size_t)r * nchunks;
-    if (threadIdx.x == 0) round_carry = init.v[r];
-    __syncthreads();
-    for (size_t base = 0; base < nchunks; base += TPB) {
-        const size_t c = base + threadIdx.x;
-        const bool live = c < nchunks;
-        uint32_t h = live ? (sum_has[c] >> r) & 1u : 0u;
-        uint32_t v = h ? sv[c] : 0u;
-        const uint32_t own_h = h, own_v = v;
-        // inclusive scan inside the wave: (h, v) <- the nearest defined entry at or before this lane
+    const size_t c = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const bool live = c < nchunks;
+    uint32_t h = live ? (sum_has[c] >> r) & 1u : 0u;
+    uint32_t v = h ? sum_val[(size_t)r * nchunks + c] : 0u;
+    // inclusive scan inside the wave: (h, v) <- the nearest defined entry at or before this lane
 #pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const uint32_t ph = __shfl_up(h, off, 64), pv = __shfl_up(v, off, 64);
-            if (lane >= (unsigned)off && !h) { h = ph; v = pv; }
+    for (int off = 1; off < 64; off <<= 1) {
+        const uint32_t ph = __shfl_up(h, off, 64), pv = __shfl_up(v, off, 64);
+        if (lane >= (unsigned)off && !h) { h = ph; v = pv; }
+    }
+    if (lane == 63) { w_has[wave] = h; w_val[wave] = v; }
+    __syncthreads();
+    // value before this lane's chunk: the previous lane's inclusive result, else the previous waves', else undefined here
+    uint32_t ph = __shfl_up(h, 1, 64), pv = __shfl_up(v, 1, 64);
+    if (lane == 0) { ph = 0; pv = 0; }
+    uint32_t before = STEPS_UNDEF;
+    bool found = false;
+    if (ph) { before = pv; found = true; }
+    for (int w = (int)wave - 1; w >= 0 && !found; w--)
+        if (w_has[w]) { before = w_val[w]; found = true; }
+    if (live) carry[(size_t)r * nchunks + c] = before;
+    if (threadIdx.x == TPB - 1) {  // the last value written in this group
+        uint32_t nv = STEPS_UNDEF;
+        bool f = false;
+        if (h) { nv = v; f = true; }
+        for (int w = (int)wave - 1; w >= 0 && !f; w--)
+            if (w_has[w]) { nv = w_val[w]; f = true; }
+        gsum[(size_t)r * ngroups + blockIdx.x] = nv;
+    }
+}
+__global__ __launch_bounds__(64) void k_steps_scan_groups(uint32_t *__restrict__ gsum /* in: summaries, out: value before the group */,
+                                                          size_t ngroups, Regs32 init) {
+    const unsigned r = blockIdx.x + 1, lane = threadIdx.x;
+    uint32_t run = init.v[r];  // the value before the current block of 64 groups (wave-uniform)
+    for (size_t base = 0; base < ngroups; base += 64) {
+        const size_t g = base + lane;
+        uint32_t v = g < ngroups ? gsum[(size_t)r * ngroups + g] : STEPS_UNDEF;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {  // inclusive: the nearest defined summary at or before this lane
+            const uint32_t pv = __shfl_up(v, off, 64);
+            if (lane >= (unsigned)off && v == STEPS_UNDEF) v = pv;
         }
-        if (lane == 63) { w_has[wave] = h; w_val[wave] = v; }
-        __syncthreads();
-        // value before this lane's chunk: the previous lane's inclusive result, else the previous waves', else the carry
-        uint32_t ph = __shfl_up(h, 1, 64), pv = __shfl_up(v, 1, 64);
-        if (lane == 0) { ph = 0; pv = 0; }
-        uint32_t before = round_carry;
-        bool found = false;
-        if (ph) { before = pv; found = true; }
-        for (int w = (int)wave - 1; w >= 0 && !found; w--)
-            if (w_has[w]) { before = w_val[w]; found = true; }
-        if (live) cr[c] = before;
-        __syncthreads();
-        if (threadIdx.x == TPB - 1) {  // the value after this round
-            uint32_t nv = round_carry;
-            bool f = false;
-            if (h) { nv = v; f = true; }
-            for (int w = (int)wave - 1; w >= 0 && !f; w--)
-                if (w_has[w]) { nv = w_val[w]; f = true; }
-            round_carry = nv;
-        }
-        (void)own_h; (void)own_v;
-        __syncthreads();
+        uint32_t before = __shfl_up(v, 1, 64);
+        if (lane == 0 || before == STEPS_UNDEF) before = run;
+        const uint32_t last = __shfl(v, 63, 64);
+        if (g < ngroups) gsum[(size_t)r * ngroups + g] = before;
+        if (last != STEPS_UNDEF) run = last;
     }
 }
 
 __global__ __launch_bounds__(TPB) void k_steps_expand(const TraceStep *__restrict__ steps, size_t num_steps, size_t npad,
-                                                      const uint32_t *__restrict__ carry, size_t nchunks,
-                                                      uint32_t *__restrict__ cols, size_t stride) {
+                                                      const uint32_t *__restrict__ carry, const uint32_t *__restrict__ gcarry,
+                                                      size_t nchunks, size_t ngroups, uint32_t *__restrict__ cols, size_t stride) {
     const size_t chunk = (size_t)blockIdx.x * (TPB / 64) + (threadIdx.x >> 6);
     if (chunk >= nchunks) return;  // wave-uniform
     const unsigned lane = threadIdx.x & 63;
@@ -579,7 +595,11 @@ __global__ __launch_bounds__(TPB) void k_steps_expand(const TraceStep *__restric
         const unsigned long long m = __ballot(wr == r) & le;
         const int src = m ? 63 - __builtin_clzll(m) : 0;
         const uint32_t w = __shfl(val, src, 64);
-        const uint32_t v = m ? w : carry[(size_t)r * nchunks + chunk];
+        uint32_t v = w;
+        if (!m) {  // not written in this chunk so far: what it held before the chunk (else before the chunk's group)
+            v = carry[(size_t)r * nchunks + chunk];
+            if (v == STEPS_UNDEF) v = gcarry[(size_t)r * ngroups + chunk / TPB];
+        }
         if (store) cols[(size_t)(1 + r) * stride + i] = v;  // registers repeat their last value in the padding (:116-123)
     }
 }
@@ -588,11 +608,13 @@ void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npa
                           uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand) {
     if (num_steps == 0) return;
     const size_t nchunks = (npad + 63) / 64;
-    uint32_t *sum_val = d_ws, *carry = d_ws + 32 * nchunks, *sum_has = d_ws + 64 * nchunks;
+    const size_t ngroups = (nchunks + TPB - 1) / TPB;
+    uint32_t *sum_val = d_ws, *carry = d_ws + 32 * nchunks, *sum_has = d_ws + 64 * nchunks, *gsum = d_ws + 65 * nchunks + 64;
     const dim3 grid((unsigned)((nchunks + TPB / 64 - 1) / (TPB / 64)));
     hipLaunchKernelGGL(k_steps_summary, grid, dim3(TPB), 0, s, d_steps, num_steps, nchunks, sum_val, sum_has);
-    hipLaunchKernelGGL(k_steps_scan, dim3(31), dim3(TPB), 0, s, sum_val, sum_has, nchunks, init, carry);
-    ZK_LAUNCH(kt_expand, k_steps_expand, grid, dim3(TPB), 0, s, d_steps, num_steps, npad, carry, nchunks, d_cols, stride);
+    hipLaunchKernelGGL(k_steps_scan_local, dim3((unsigned)ngroups, 31), dim3(TPB), 0, s, sum_val, sum_has, nchunks, carry, gsum, ngroups);
+    hipLaunchKernelGGL(k_steps_scan_groups, dim3(31), dim3(64), 0, s, gsum, ngroups, init);
+    ZK_LAUNCH(kt_expand, k_steps_expand, grid, dim3(TPB), 0, s, d_steps, num_steps, npad, carry, gsum, nchunks, ngroups, d_cols, stride);
 }
 
 static unsigned stream_grid(size_t n) {

@@ -30,8 +30,8 @@ void launch_witness_rows(const uint64_t *d_rows, size_t num_steps, size_t npad, 
                          hipStream_t s);
 void launch_widen_u32(const uint32_t *d_in, uint64_t *d_out, size_t n, hipStream_t s);
 // K8 from the compact trace (include/zigz_hip.h: zigz_trace_step, 48 B per step; TraceStep is its device mirror).
-// Three launches: per-64-step summaries of the register writes, a fill-forward scan over the chunks per register, the
-// expansion into the 43 padded columns.  ws: (65 * nchunks + 64) u32 of scratch, nchunks = ceil(npad / 64).
+// Four launches: per-64-step summaries of the register writes, a two-level fill-forward scan over the chunks per register, the
+// expansion into the 43 padded columns.  ws: witness_steps_ws_words(npad) u32 of scratch.
 struct TraceStep {
     uint64_t pc, rd_value, mem_addr, mem_value;
     int64_t imm;
@@ -41,7 +41,10 @@ static_assert(sizeof(TraceStep) == 48, "TraceStep must mirror zigz_trace_step (4
 struct Regs32 {
     uint32_t v[32];  // initial register values mod p (x0 = 0)
 };
-inline size_t witness_steps_ws_words(size_t npad) { return 65 * ((npad + 63) / 64) + 64; }
+inline size_t witness_steps_ws_words(size_t npad) {
+    const size_t nchunks = (npad + 63) / 64;
+    return 65 * nchunks + 64 + 32 * ((nchunks + 255) / 256) + 64;  // summaries | carries | flags | per-group carries
+}
 void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
                           uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand = nullptr);
 
