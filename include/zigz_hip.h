@@ -437,6 +437,8 @@ zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
  *   virtual like run-aware copies.  The leaf level is probed first (one table pass + a read-back of the number of distinct
  *   leaves, ~0.1 ms during which zigz_commit_begin* waits for the device): a group that does not repeat -- more than a quarter
  *   of its leaves distinct -- is built like any other columns (the other hints then apply to them).
+ *   A context whose last two jobs dropped the group does not try it in its next 15 jobs (their columns are then built like
+ *   any others from the start); "cons_always" = 1 tries in every job.
  * "merkle_dedup" = 1 / 0 is shorthand for run_aware_mask = all ones / 0;
  * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
  *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the

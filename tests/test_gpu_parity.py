@@ -1111,9 +1111,19 @@ def test_dropped_group_gets_slabs_by_a_rebuild(ctx):
 
     r0, o0, _ = run(0, 0)
     before = ctx.stats()["rebuilds"]
-    r1, o1, st = run(0b111, 0b110)                     # columns 0 (random), 1, 2: nothing repeats -> dropped
+    ctx.set_option("cons_always", 1)                   # (a context stops trying after two drops in a row: not here)
+    try:
+        r1, o1, st = run(0b111, 0b110)                 # columns 0 (random), 1, 2: nothing repeats -> dropped
+    finally:
+        ctx.set_option("cons_always", 0)
     assert st["cons_columns"] == 0 and st["cons_probe_distinct"] > N // 4 and st["small_domain_columns"] == 2
     assert ctx.stats()["rebuilds"] == before + 1       # once: the context now sets slabs aside for this group
+    r2, o2, st2 = run(0b111, 0b110)                    # the default: after two drops in a row the group is not even tried
+    assert st2["cons_probe_distinct"] == 0 and st2["cons_columns"] == 0 and st2["small_domain_columns"] == 2
+    assert np.array_equal(r0, r2)
+    for a, b in zip(o0, o2):
+        for k in a:
+            assert np.array_equal(a[k], b[k]), k
     assert np.array_equal(r0, r1)
     for a, b in zip(o0, o1):
         for k in a:

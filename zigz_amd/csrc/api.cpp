@@ -28,6 +28,7 @@ struct ListCaps {
     unsigned rn, gn;
     unsigned r[RUN_MAX_LEVELS], g[RUN_MAX_LEVELS];  // entries per sub-list and level
     bool g_slabs;  // this context's traces made the group be dropped: give its columns slabs up front
+    unsigned g_drops, g_skip;  // consecutive builds that dropped the group; builds left that do not even try it
 };
 struct zigz_ctx {
     int device;
@@ -48,6 +49,7 @@ struct zigz_ctx {
     uint64_t cons_group_mask;    // option: columns (bit c) that repeat in the same places -> content-addressed levels
     unsigned long long *d_cons_count;
     bool run_aware_materialize;  // option (tests): write the copies of every run-aware level (no virtual copies)
+    bool cons_always;            // option (tests): try the content-addressed group in every job, however often it was dropped
     uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
                               // are copied, not hashed); "merkle_dedup" = 1 is all columns
     unsigned long long *d_run_count;  // nodes hashed by the run-aware launches of the last build
@@ -329,6 +331,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "run_aware_mask") == 0) { ctx->run_aware_mask = (uint64_t)value; return ZIGZ_OK; }
     if (strcmp(name, "run_aware_materialize") == 0) { ctx->run_aware_materialize = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "cons_group_mask") == 0) { ctx->cons_group_mask = (uint64_t)value; return ZIGZ_OK; }
+    if (strcmp(name, "cons_always") == 0) { ctx->cons_always = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -339,6 +342,7 @@ extern "C" zigz_status zigz_ctx_get_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "run_aware_mask") == 0) { *value = (int64_t)ctx->run_aware_mask; return ZIGZ_OK; }
     if (strcmp(name, "run_aware_materialize") == 0) { *value = ctx->run_aware_materialize; return ZIGZ_OK; }
     if (strcmp(name, "cons_group_mask") == 0) { *value = (int64_t)ctx->cons_group_mask; return ZIGZ_OK; }
+    if (strcmp(name, "cons_always") == 0) { *value = ctx->cons_always; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { *value = (int64_t)ctx->small_domain_mask; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1222,6 +1226,7 @@ static void caps_for(zigz_ctx *ctx, size_t npad, unsigned rn, unsigned gn) {
     c.rn = rn;
     c.gn = gn;
     c.g_slabs = false;
+    c.g_drops = c.g_skip = 0;
     const LevelLists rw = runs_lists(npad, rn ? rn : 1), gw = cons_lists(npad);
     for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) {
         c.r[l] = l <= rw.top ? (rw.cap[l] / 8 > 256 ? rw.cap[l] / 8 : 256) : 0;  // an eighth of "every node hashed"
@@ -1276,7 +1281,23 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     const bool big = npad >= RUN_MIN_LEAVES && npad <= RUN_MAX_LEAVES && ncols <= 64;
     const bool sd_ok = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
     const bool run_ok = ctx->run_aware_mask && big;
-    const bool cons_ok = ctx->cons_group_mask && big;
+    bool cons_ok = ctx->cons_group_mask && big;
+    unsigned gn_hinted = 0;  // (what the context learnt is filed under the hints, not under whether this build tries the group)
+    for (size_t c = 0; cons_ok && c < ncols; c++) gn_hinted += (unsigned)((ctx->cons_group_mask >> c) & 1);
+    if (run_ok || cons_ok) {
+        unsigned rn_hinted = 0;
+        for (size_t c = 0; run_ok && c < ncols; c++)
+            rn_hinted += (unsigned)(((ctx->run_aware_mask >> c) & 1) && !(cons_ok && ((ctx->cons_group_mask >> c) & 1)) &&
+                                    !(sd_ok && ((ctx->small_domain_mask >> c) & 1)));
+        caps_for(ctx, npad, rn_hinted, gn_hinted);
+    }
+    // A context whose last two jobs dropped the group (its traces do not loop) stops trying for a while: the group's columns
+    // are then H / D from the start -- no table passes that find nothing, and the tuned dense kernels instead of the list
+    // kernel's dense branch -- and every 16th job looks again.
+    if (cons_ok && ref && !ctx->cons_always && ctx->caps.npad == npad && ctx->caps.g_skip) {
+        ctx->caps.g_skip--;
+        cons_ok = false;
+    }
     auto kind = [&](size_t c) -> int {  // 0 D, 1 H, 2 R, 3 G
         if (cons_ok && ((ctx->cons_group_mask >> c) & 1)) return 3;
         if (sd_ok && ((ctx->small_domain_mask >> c) & 1)) return 1;
@@ -1293,7 +1314,6 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     const bool lists = R.n || G.n;
     const bool whole = ref == nullptr || ctx->run_aware_materialize;  // every digest into node-addressed slabs
     const bool virt = !whole;  // copies / non-representatives / table leaves never written
-    if (lists) caps_for(ctx, npad, R.n, G.n);
     // ---- where the digests go
     TreeRef t{};
     t.npad = npad;
@@ -1787,6 +1807,10 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
                     c.g[l] = (unsigned)(gu + gu / 4 + 64);
             }
             if (dropped) c.g_slabs = true;  // this context's traces do not repeat: give the group's columns slabs from now on
+            if (job->cons_hinted) {
+                c.g_drops = dropped ? c.g_drops + 1 : 0;
+                if (c.g_drops >= 2) c.g_skip = 15;  // ... and after the second drop in a row, skip the attempt for 15 jobs
+            }
             again = r_over || (g_over && !dropped) || g_noslab;
         }
         if (!again) break;

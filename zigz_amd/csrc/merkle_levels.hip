@@ -559,8 +559,10 @@ __global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, C
             k = ent & ((1u << RUN_NODE_BITS) - 1);
             out = r_slot_ptr(b.t, L, slot);
             if (!LEAF) {
-                in0 = r_slot_ptr(b.t, L - 1, r_slot(b.t, y, L - 1, 2 * k));
-                in1 = r_slot_ptr(b.t, L - 1, r_slot(b.t, y, L - 1, 2 * k + 1));
+                size_t c0, c1;
+                r_slot_pair(b.t, y, L - 1, 2 * k, &c0, &c1);
+                in0 = r_slot_ptr(b.t, L - 1, c0);
+                in1 = r_slot_ptr(b.t, L - 1, c1);
             }
         } else if (e < cR + cG) {
             const size_t t = e - cR, ei = t / b.gcols.n;

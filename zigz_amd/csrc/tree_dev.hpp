@@ -68,6 +68,15 @@ __device__ __forceinline__ size_t r_slot(const TreeRef &t, unsigned y, unsigned 
     const size_t u = (size_t)y * (n_l / tile) + j / tile;
     return (size_t)t.ubase[t.ubase_off[l] + u] + t.woff[e] + (unsigned)__builtin_popcountll(m);
 }
+// the slots of the two children 2 k2, 2 k2 + 1 of a node: they share a 64-node chunk, and list order is node order, so the
+// odd child's digest sits right behind the even child's if the odd child was hashed itself -- and in the SAME slot if it is a
+// copy (its leader is the even child or the even child's leader).  One leader search instead of two.
+__device__ __forceinline__ void r_slot_pair(const TreeRef &t, unsigned y, unsigned l, size_t k_even, size_t *s0, size_t *s1) {
+    const size_t n_l = t.npad >> l;
+    const unsigned long long w = t.bitmap[run_meta_base(t.npad, t.ncols, l) + ((size_t)y * n_l + k_even) / 64];
+    *s0 = r_slot(t, y, l, k_even);
+    *s1 = *s0 + (unsigned)((w >> ((k_even & 63) + 1)) & 1);
+}
 __device__ __forceinline__ uint8_t *r_slot_ptr(const TreeRef &t, unsigned l, size_t slot) {
     return t.r_store + (t.r_lists.base[l] + slot) * 32;
 }
