@@ -149,7 +149,8 @@ zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols,
 /* device-resident columns (packed u32 canonical); the buffer must stay valid until zigz_commit_end */
 zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
                                   size_t nv, zigz_commit_job **out);
-/* waits for the Merkle builds; roots: ncols*32 bytes (prover.zig:405-410).
+/* zigz_commit_begin* ENQUEUES the Merkle builds and returns (nothing on that path is read back by the host: ~0.15 ms for the
+ * ~45 launches of a 2^20 x 43 job); zigz_commit_roots waits for them; roots: ncols*32 bytes (prover.zig:405-410).
  * One job per context at a time (a second begin returns ZIGZ_ERR_BAD_STATE).  Other calls on the same context
  * between begin and end are allowed -- e.g. a Zig host evaluating one MLE while the trees build: they queue behind
  * the builds on the context's stream, and the job's roots travel through a pinned buffer of their own, so they
@@ -162,8 +163,9 @@ zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t *points, u
                                  uint64_t *indices, uint64_t *leaves, uint8_t *siblings, uint8_t *dirs);
 /* diagnostic (tests): device address of the job's trees once built -- per column `bytes_per_column` = 2 * 2^nv nodes x 32 B
  * in the kernels' internal node form (level l at node offset 2N - 2(N >> l)); valid until zigz_commit_end.  Lets a test
- * compare two builds of the same columns node for node (dense vs table / run-aware levels; set "run_aware_materialize"
- * for the latter, otherwise the copies of the run-aware levels are not in the tree). */
+ * compare two builds of the same columns node for node (dense vs table / run-aware / content-addressed levels).  Whole
+ * node-addressed trees exist only when no column is list-built or the job was begun with "run_aware_materialize" = 1:
+ * ZIGZ_ERR_BAD_STATE otherwise. */
 zigz_status zigz_commit_job_tree(zigz_commit_job *job, const void **d_tree, size_t *bytes_per_column);
 void zigz_commit_end(zigz_commit_job *job);
 
@@ -358,9 +360,9 @@ typedef struct zigz_kernel_stats {
     uint64_t bind_vec_launches;
     uint64_t bind_vec_bytes;
     /* run-aware Merkle levels (option "run_aware_mask") of the last batched commit: columns built that way, the nodes
-     * of the levels they covered (what a dense build hashes there), how many of those were hashed rather than copied
-     * from the left neighbour, and the kernel time of those launches (timing mode).  0 when the option is off or the
-     * trees have fewer than 2^15 leaves. */
+     * of the levels they covered (levels 0 .. v - 8: what a dense build hashes there), how many of those were hashed rather
+     * than copied from the left neighbour, and the kernel time of the structure + hashing launches (timing mode).  0 when the
+     * option is off or the trees have fewer than 2^15 leaves. */
     uint64_t run_aware_columns;
     uint64_t run_aware_dense_nodes;
     uint64_t run_aware_hashed;
@@ -370,7 +372,7 @@ typedef struct zigz_kernel_stats {
     uint64_t cons_columns;
     uint64_t cons_dense_nodes;
     uint64_t cons_hashed;
-    uint64_t cons_probe_distinct; /* distinct leaves (tuples) of the group found by the probe; > 1/4 of the leaves: cons_columns = 0 */
+    uint64_t cons_probe_distinct; /* distinct leaves (tuples) of the group; > 1/4 of the leaves: dropped, cons_columns = 0 (0 when the group was not tried) */
     /* Keccak launches of the last batched commit by class, each launch timed with its own begin / end timestamps
      * (kernel time as rocprofv3 --kernel-trace reports it; the gaps between launches are in merkle_build_us only):
      * k_keccak_leaves; k_keccak_level<4> (the large levels); k_keccak_level<1> (the small levels); hashes = permutations */
@@ -419,26 +421,29 @@ zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
  * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;
  * "run_aware_mask" = bit c set: column c of the following batched commits (<= 64 columns, 2^15 .. 2^26 rows) is expected to be
  *   piecewise constant -- in the witness of prover.zig:376-390 the registers: every RV64IM step writes at most one of them
- *   (state.zig writeReg), so the 31 columns x1..x31 together change at most once per step.  On the levels with >= 16384
- *   nodes a node whose subtree and its left neighbour's are uniform with the same value takes the neighbour's digest
- *   instead of being hashed.  Decided from the VALUES on the device, never from the hint: identical trees for ANY input;
- *   with c change points in a column a level costs <= min(nodes, 2 c + nodes / 4096) hashes.
- *   In a commit job the copies of all but the top run-aware level are VIRTUAL: their 32 bytes are never written; the next
- *   level's hashes and zigz_commit_open_all read a copy through a per-level bitmap of hashed nodes (2 GB less HBM traffic per
- *   2^20 x 43 build).  "run_aware_materialize" = 1 writes them all (tests that compare whole trees); single trees
- *   (zigz_merkle_commit) always hold every digest.
+ *   (state.zig writeReg), so the 31 columns x1..x31 together change at most once per step.  On the levels 0 .. v - 8 (down to
+ *   256 nodes per column) a node whose subtree and its left neighbour's are uniform with the same value takes the
+ *   neighbour's digest instead of being hashed.  Decided from the VALUES on the device, never from the hint: identical trees
+ *   for ANY input; with c change points in a column a level costs <= min(nodes, 2 c + one per tile) hashes (a tile is what one
+ *   4096-leaf segment covers at that level).
+ *   In a commit job only the hashed nodes have a digest at all, stored in LIST ORDER; the next level's hashes and
+ *   zigz_commit_open_all find a copy's digest through a per-level bitmap of hashed nodes.  The room for those lists is what the
+ *   context's earlier jobs needed (+ 25 %), not the worst case: a job that runs out notices on the device and
+ *   zigz_commit_roots repeats its build with more (kernel_stats.rebuilds) -- typically once, the first time a context meets
+ *   a new kind of trace.  "run_aware_materialize" = 1 writes every digest of every tree into node-addressed trees (tests that
+ *   compare whole trees); single trees (zigz_merkle_commit) always do.
  * "cons_group_mask" = bit c set: the columns of this set repeat in the same places -- in the witness of prover.zig:376-390
  *   the ten columns that are functions of the instruction at pc (pc, x0, opcode, rd, rs1, rs2, funct3, funct7, imm, is_read):
  *   wherever the program loops, the same nodes recur in all of them, at most P distinct ones per level for a loop of P steps.
- *   On the levels with >= 16384 nodes a device hash table finds for every node the first node of its level with the same
- *   content in ALL columns of the group (leaves: the tuple of values, fingerprinted and verified; above: the pair of the
- *   children's representatives -- the identity of the hash input itself), and only representatives are hashed, once per
- *   column.  Takes precedence over the two hints above; identical trees for ANY input; in a commit job the other nodes are
- *   virtual like run-aware copies.  The leaf level is probed first (one table pass + a read-back of the number of distinct
- *   leaves, ~0.1 ms during which zigz_commit_begin* waits for the device): a group that does not repeat -- more than a quarter
- *   of its leaves distinct -- is built like any other columns (the other hints then apply to them).
- *   A context whose last two jobs dropped the group does not try it in its next 15 jobs (their columns are then built like
- *   any others from the start); "cons_always" = 1 tries in every job.
+ *   On the levels 0 .. v - 8 a device hash table finds for every node the first node of its level with the same content in
+ *   ALL columns of the group (leaves: the tuple of values, fingerprinted and verified; above: the pair of the children's
+ *   representatives -- the identity of the hash input itself), and only representatives are hashed, once per column.  Takes
+ *   precedence over the two other hints; identical trees for ANY input; the other nodes are virtual like run-aware copies.
+ *   A group that does not repeat -- more than a quarter of its leaves distinct -- is DROPPED: its columns are built like any
+ *   others (the other hints then apply to them).  That decision is taken on the device after the leaf level's table pass and
+ *   read by the later launches from device memory: zigz_commit_begin* never waits for it.  (The first job of a context that
+ *   drops its group is built twice -- the columns had no node-addressed trees to be built into; a context whose last two
+ *   jobs dropped the group does not try it in its next 15 jobs; "cons_always" = 1 tries in every job.)
  * "merkle_dedup" = 1 / 0 is shorthand for run_aware_mask = all ones / 0;
  * "small_domain_mask" = bit c set: column c of the following batched commits (<= 64 columns, >= 1024 rows) holds values
  *   < 128 BY CONSTRUCTION -- in the witness of prover.zig:376-390 that is x0 (always 0, registers.zig:38-48), the
