@@ -662,9 +662,10 @@ def main():
             return {"dt": dtl, "steps": steps_l, "perms": accl["keccak_permutations"] / (steps_l * B),
                     "trace_steps": float(sum(l.trace.num_steps for l in lanes))}
         pcie["worst"] = other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3)
+        pcie["mixed"] = other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3)
+        # (last: a context whose group was dropped twice in a row stops trying it for its next 15 jobs)
         base = programs.straight_line_program(1000 + rank, int(0.95 * N))  # one program per rank, a different prefix per lane
         pcie["straight"] = other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], 3)
-        pcie["mixed"] = other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3)
 
     # ---- N > 1, traces mode: also ONE proof per step sharded by column over the N ranks (the strong-scaling variant of
     # --mode shard), reported in the same line.  Exchanges go through the shared-memory hook (host-resident payloads of a

@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """One-off GPU soak (not collected by pytest): random LOOPING RV64IM programs with ragged step counts up to 2^17, proved
-through every build variant of the HIP path -- packed rows / compact device trace; Merkle build dense, with the
-small-domain tables, with run-aware register columns, with every column run-aware -- and compared byte for byte with the oracle's literal proof.
+(every fifth case: a straight-line program that never loops) through every build variant of the HIP path -- packed rows /
+compact device trace; Merkle build dense, with the small-domain tables, with run-aware register columns, with every column
+run-aware, with the content-addressed group -- ALL ON ONE CONTEXT, so the room it has learnt for its lists, its repeated builds
+and its dropped groups carry over from case to case -- and compared byte for byte with the oracle's literal proof.
 
     python tests/stress_gpu.py [--cases 12] [--seed 7] [--max-log 17]
 
@@ -60,7 +62,9 @@ def main():
     for case in range(args.cases):
         lg = int(rng.integers(8, args.max_log + 1)) if case % 3 else args.max_log
         target = int(rng.integers((1 << (lg - 1)) + 1, (1 << lg) + 1))
-        prog = looping_program(rng, target)
+        # every fifth case never loops (the content-addressed group is dropped on the device, its columns rebuilt with slabs,
+        # and after two such jobs the context stops trying the group for a while): the same context then meets loops again
+        prog = programs.straight_line_program(int(rng.integers(1 << 30)), target) if case % 5 == 4 else looping_program(rng, target)
         iregs = None if case % 2 else [0] + [int(x) for x in rng.integers(0, 2**63, size=int(rng.integers(1, 31)), dtype=np.int64)]
         t0 = time.time()
         oproof, ons = O.prove(P, prog, 0x1000, iregs, 1 << 20)
