@@ -4,31 +4,35 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nv 20] [--mode traces|shard]
                     [--no-cpu-baseline] [--kernels]
 
-A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces
-(default: 8 per sponge-server thread, 6 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness columns each are already
-resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of Prover.prove
-(public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v
-challenges, OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and
-the ZIGZ v1 serialisation of the proof.  Nothing is skipped or cached between steps.
+A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces (default: 8 per
+sponge-server thread, 10 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness
+columns each are already resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of
+Prover.prove (public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v challenges,
+OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and the ZIGZ v1 serialisation of
+the proof.  Nothing is skipped or cached between steps.
 
-Why a batch: one proof is bounded by its own sequential SHA3 transcript on ONE host core (19 bytes absorbed per
-lookup step, ~27 ms at 2^20) while its GPU work takes ~0.9 ms, so a proving service keeps the GPU busy by
-running many proofs per GPU concurrently (one host thread + one HIP stream each), and advances their transcripts
-8 per host thread in lock step (zigz_host_sponge_servers: 8-way AVX-512 Keccak-f, same bytes absorbed) so that
-the host cores do not become the limit.  The same JSON line also
-carries `single_proof_ms` (one proof at a time), `pcie_inclusive_value` (trace upload + witness kernels inside
-the timed loop), `merkle_variants` (the same batch under the other Merkle builds of --merkle) and
-`register_worst_case_value` (the trace that is worst for the default build) and `self_check` (SHA-256 of every lane's
-proof: identical under every Merkle build and transcript path), measured right after the timed region.
+Why a batch: one proof is bounded by its own sequential SHA3 transcript on ONE host core (19 bytes absorbed per lookup step,
+~27 ms at 2^20) while its GPU work takes ~0.55 ms, so a proving service keeps the GPU busy by running many proofs per GPU
+concurrently (one host thread + one HIP stream each), and advances their transcripts 8 per host thread in lock step
+(zigz_host_sponge_servers: 8-way AVX-512 Keccak-f, same bytes absorbed) so that the host cores carry them.
 
-N > 1: `python bench.py --gpus N` starts the N ranks itself (child `python -m torch.distributed.run`, before this
-process touches torch or HIP) and relays rank 0's JSON line; when a launcher has already set WORLD_SIZE the
-process is a rank.  One rank per GPU, backend nccl (= RCCL); the path shards by independent traces (one batch of
-proofs per rank, no data-path collective): "scaling": "weak", value = all ranks' trace steps / max-over-ranks
-time.  `--mode shard` (one proof per step, its 43 columns sharded over the ranks) is the strong-scaling variant.
+The JSON line: metric / value / ... as the contract says; `roofline` = the kernel class that dominates the TIMED REGION
+(k_level_hash: permutations x VALU instructions per hash / the sum of its launches' own durations / the int-VALU issue peak;
+flat keys, the named ones first); `config` = the workload plus, measured right after the timed region in the same process,
+single_proof_ms, pcie_inclusive_value (trace upload + witness kernels inside the loop), the same batch on three other traces
+(register_worst_case_value, config4_mixed_value, straight_line_value), under the dense Merkle build (dense_merkle_value) and at
+the other trace sizes of the north-star (value_nv16 / _nv22 / _nv24); `cpu_baseline`; nested records under `detail`
+(merkle_variants, self_check: SHA-256 of every lane's proof identical under every Merkle build and transcript path; host
+phases; per-class kernel time).  DESIGN.md s6 says what each number is.
 
-`--kernels` runs only the per-kernel leg (cold-HBM launches of the MLE and Keccak kernels with kernel
-timestamps) and prints its own JSON line; that is the command profiles/r02_kernels_* were taken from.
+N > 1: `python bench.py --gpus N` starts the N ranks itself (child `python -m torch.distributed.run`, before this process
+touches torch or HIP) and relays rank 0's JSON line; when a launcher has already set WORLD_SIZE the process is a rank.  One
+rank per GPU, backend nccl (= RCCL), each rank pinned to the cores of its GPU's NUMA node; the path shards by independent
+traces (one batch of proofs per rank, no data-path collective): "scaling": "weak", value = all ranks' trace steps /
+max-over-ranks time.  `--mode shard` (one proof per step, its 43 columns sharded over the ranks) is the strong-scaling variant.
+
+`--kernels` runs only the per-kernel leg (cold-HBM launches of the MLE and Keccak kernels with kernel timestamps) and prints
+its own JSON line; that is the command profiles/r03_kernels_* were taken from.
 """
 import argparse
 import hashlib
@@ -277,11 +281,11 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: 8 per "
-                    "sponge server; without the service this rank's share of the host CPUs minus 2, at most 14).  One proof alone "
-                    "is bound by its sequential host transcript (~27 ms on one core) against ~2.6 ms of GPU work with the default "
-                    "Merkle build, so a proving service keeps many proofs in flight, one host thread + one HIP stream each: with "
-                    "6 sponge servers x 8 lanes ~1.0 G steps/s (each more server adds ~150 M until the GPU's 0.86 ms per proof is "
-                    "reached at 8 x 8, 235 GB of HBM); with one core per transcript 14 lanes fit a 16-CPU share of the host (~480 M)")
+                    "sponge server, bounded by free HBM; without the service this rank's share of the host CPUs minus 2, at most "
+                    "14).  One proof alone is bound by its sequential host transcript (~27 ms on one core) against ~0.55 ms of GPU "
+                    "work with the default Merkle build, so a proving service keeps many proofs in flight, one host thread + one "
+                    "HIP stream each: 10 sponge servers x 8 lanes ~1.6-1.8 G steps/s on a 16-CPU share; with one core per "
+                    "transcript 14 lanes fit (~0.5 G)")
     ap.add_argument("--sponge-servers", type=int, default=-1, help="host threads of the sponge service (zigz_host_sponge_servers): each "
                     "advances up to 8 proofs' transcripts in lock step with one 8-way AVX-512 permutation per block while the "
                     "proofs' own threads sleep.  0 = every proof absorbs its transcript on its own thread (the lane count is then "
@@ -723,14 +727,24 @@ def main():
         for nv_s, steps_s in ((16, 10), (22, 3), (24, 2)):
             if nv_s == nv:
                 continue
-            per_lane = int(2.4 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
-            nl = max(1, min(B, int(free_now * 0.85) // per_lane))
-            ls = [Lane(k, nv_s) for k in range(nl)]
-            run_step(which=ls)
-            dts_, _, _ = timed(steps_s, which=ls)
-            sweep[nv_s] = {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
+            # (the bench trace needs ~0.6 GiB per proof in flight at 2^20 -- 0.9 with the room a first build may ask for --
+            # and proportionally more above; below 2^20 the fixed workspaces dominate)
+            per_lane = int(0.9 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+            nl = max(1, min(B, int(free_now * 0.8) // per_lane))
+            ls = []
+            try:
+                ls = [Lane(k, nv_s) for k in range(nl)]
+                run_step(which=ls)
+                run_step(which=ls)
+                dts_, _, _ = timed(steps_s, which=ls)
+                sweep[nv_s] = {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
+            except zigz_amd.ZigzError as e:  # (out of HBM at this size: the line goes out without this entry)
+                sys.stderr.write("bench.py: sweep at 2^%d skipped: %r\n" % (nv_s, e))
             for l in ls:
-                l.close()
+                try:
+                    l.close()
+                except Exception:
+                    pass
     else:
         lanes_main = lanes
 
@@ -753,9 +767,17 @@ def main():
                 if leg in pcie:
                     pcie[leg]["dt"] = allmax(pcie[leg]["dt"])
                     pcie[leg]["trace_steps"] = allsum(pcie[leg]["trace_steps"])
-        for sv in sweep.values():
-            sv["dt"] = allmax(sv["dt"])
-            sv["trace_steps"] = allsum(sv["trace_steps"])
+        for nv_s in (16, 22, 24):  # (every rank takes part for every size, whether its own leg succeeded or not)
+            if nv_s == nv or not extras:
+                continue
+            sv = sweep.get(nv_s)
+            ok = -allmax(-1.0 if sv else 0.0)  # 1.0 only if every rank has the entry
+            dtm = allmax(sv["dt"] if sv else 0.0)
+            tsm = allsum(sv["trace_steps"] if sv else 0.0)
+            if ok == 1.0:
+                sv["dt"], sv["trace_steps"] = dtm, tsm
+            else:
+                sweep.pop(nv_s, None)
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace

@@ -312,10 +312,19 @@ __device__ __forceinline__ unsigned long long cons_mix(unsigned long long x) {  
     x ^= x >> 27; x *= 0x94d049bb133111ebull;
     return x ^ (x >> 31);
 }
-__device__ __forceinline__ unsigned long long cons_leaf_payload(const MerkleBuild &b, size_t k) {
+constexpr unsigned CONS_TUP = 16;  // a leaf's tuple is kept in registers up to this many columns (the witness group has ten)
+__device__ __forceinline__ unsigned long long cons_leaf_payload(const MerkleBuild &b, size_t k, uint32_t *tup = nullptr) {
     unsigned long long h = 0x243f6a8885a308d3ull;
-    for (unsigned j = 0; j < b.gcols.n; j++)
-        h = cons_mix(h ^ (k < b.n_values ? b.vals[(size_t)b.gcols.c[j] * b.val_stride + k] : 0u));  // padding leaves hold 0
+    if (tup && b.gcols.n <= CONS_TUP) {
+#pragma unroll
+        for (unsigned j = 0; j < CONS_TUP; j++) {
+            tup[j] = (j < b.gcols.n && k < b.n_values) ? b.vals[(size_t)b.gcols.c[j] * b.val_stride + k] : 0u;  // padding leaves hold 0
+            if (j < b.gcols.n) h = cons_mix(h ^ tup[j]);
+        }
+    } else {
+        for (unsigned j = 0; j < b.gcols.n; j++)
+            h = cons_mix(h ^ (k < b.n_values ? b.vals[(size_t)b.gcols.c[j] * b.val_stride + k] : 0u));
+    }
     return h & ((1ull << CONS_GEN_SHIFT) - 1);
 }
 // Lanes of a wave that hold the same key elect the lowest of them: in a loop-dominated trace the 64 nodes of a wave share a
@@ -442,8 +451,9 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
     const size_t off = 2 * b.npad - 2 * n;                            // first node of level lr in g_rep
     const size_t off_in = LEAF ? 0 : 2 * b.npad - 2 * (b.npad >> (lr - 1));  // ... of level lr - 1
     unsigned long long key = (unsigned long long)g_r << CONS_GEN_SHIFT;
+    uint32_t tup[CONS_TUP];  // (leaves) this leaf's tuple: compared with the representative's below without reading it again
     if (valid) {
-        if (LEAF) key |= cons_leaf_payload(b, c);
+        if (LEAF) key |= cons_leaf_payload(b, c, tup);
         else {
             const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + off_in + 2 * c);
             key |= ((unsigned long long)p.x << RUN_NODE_BITS) | p.y;
@@ -456,11 +466,18 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
     bool alone = false;  // (leaves only) equal fingerprints are not yet equal tuples: verify against the representative's tuple,
     if (LEAF && valid && r != 0xffffffffu) {  // else this leaf stands for itself, in a list slot of its own
         const size_t rn = b.g_list[b.t.g_lists.base[0] + r];
-        if (rn != c)
-            for (unsigned j = 0; j < b.gcols.n; j++) {
-                const uint32_t *v = b.vals + (size_t)b.gcols.c[j] * b.val_stride;
-                if ((c < b.n_values ? v[c] : 0u) != (rn < b.n_values ? v[rn] : 0u)) { alone = true; break; }
+        if (rn != c) {
+            if (b.gcols.n <= CONS_TUP) {
+#pragma unroll
+                for (unsigned j = 0; j < CONS_TUP; j++)
+                    if (j < b.gcols.n && tup[j] != (rn < b.n_values ? b.vals[(size_t)b.gcols.c[j] * b.val_stride + rn] : 0u)) alone = true;
+            } else {
+                for (unsigned j = 0; j < b.gcols.n; j++) {
+                    const uint32_t *v = b.vals + (size_t)b.gcols.c[j] * b.val_stride;
+                    if ((c < b.n_values ? v[c] : 0u) != (rn < b.n_values ? v[rn] : 0u)) { alone = true; break; }
+                }
             }
+        }
     }
     if (valid && r == 0xffffffffu) alone = true;  // (cannot happen)
     const unsigned own = cons_take_slot(b, lr, alone, lane, c / 64);
