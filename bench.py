@@ -89,16 +89,35 @@ MERKLE_BUILDS = {  # --merkle: what config.merkle_build says
 }
 
 
-def host_cpus():
-    """CPUs this process may use: the cgroup quota (cpu.max) if there is one, else the affinity mask."""
-    n = len(os.sched_getaffinity(0))
+def cgroup_cpu_quota():
+    """CPUs the cgroup grants this process tree (cpu.max), or None."""
     try:
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
         if quota != "max":
-            n = min(n, max(1, int(quota) // int(period)))
+            return max(1, int(quota) // int(period))
     except (OSError, ValueError):
         pass
-    return n
+    return None
+
+
+def host_cpus():
+    """CPUs this process may use: the cgroup quota (cpu.max) if there is one, else the affinity mask."""
+    n = len(os.sched_getaffinity(0))
+    q = cgroup_cpu_quota()
+    return min(n, q) if q else n
+
+
+def rank_cpus(world, pinned):
+    """CPUs ONE rank may count on.  A rank that has pinned itself (zigz_amd/placement.py) already holds its slice of the
+    cores in its affinity mask -- dividing that by the world size again would leave an 8-GPU run two sponge servers per GPU;
+    an unpinned rank takes its share of the common mask.  A cgroup quota is shared by all ranks of the launch."""
+    n = len(os.sched_getaffinity(0))
+    if not pinned:
+        n //= max(world, 1)
+    q = cgroup_cpu_quota()
+    if q:
+        n = min(n, q // max(world, 1))
+    return max(1, n)
 
 
 def has_avx512f():
@@ -108,10 +127,10 @@ def has_avx512f():
         return False
 
 
-def default_batch(world):
+def default_batch(ncpu):
     """Lanes per GPU: every lane keeps one host core busy with its proof's sequential SHA3 sponge; two cores per rank are
     left for the helper threads (serialisation, Lasso commitments) and this interpreter (used without the sponge service)."""
-    return max(1, min(14, host_cpus() // max(world, 1) - 2))
+    return max(1, min(14, ncpu - 2))
 
 
 def launch_ranks(n, argv):
@@ -432,16 +451,17 @@ def main():
         return 0
 
     shard = args.mode == "shard"
+    ncpu = rank_cpus(world, pin.get("pinned", 0))  # what this rank sizes its threads for
     servers = args.sponge_servers
     if servers < 0:
         # a server is one busy core per 8 proofs in flight; the lanes' own threads, the serialiser helpers and the runtime's
         # event thread need ~2.6 ms of CPU per proof on top: 10 servers on a 16-CPU share leave them 6 cores (11 servers use
         # 15.9 of the 16 and are 7 % faster when nothing else runs; 12 are over the quota and 15 % slower)
-        servers = 0 if shard or not has_avx512f() else max(1, min(12, host_cpus() // max(world, 1) * 5 // 8))
+        servers = 0 if shard or not has_avx512f() else max(1, min(12, ncpu * 5 // 8))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
-    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers if servers else default_batch(world)))
+    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers if servers else default_batch(ncpu)))
     hbm_free = None
     if not shard and args.batch <= 0:  # a proof in flight holds ~3.5 GiB of HBM at 2^20 (trees, lists, witness): stay inside it
         probe = zigz_amd.Context(local_rank)
@@ -451,7 +471,7 @@ def main():
         # slabs for the dropped group, longer lists -- and the legs below run such traces on the same lanes: budget for that)
         per_lane = int(2.4 * (1 << 30) * (1 << max(args.nv - 20, 0)))
         B = max(1, min(B, int(hbm_free * 0.9) // per_lane))
-    blocking = B + servers + 2 > host_cpus() // max(world, 1)  # more threads than cores: wait for the GPU asleep, not spinning
+    blocking = B + servers + 2 > ncpu  # more threads than cores: wait for the GPU asleep, not spinning
     if os.environ.get("ZIGZ_BENCH_BLOCKING_SYNC"):
         blocking = os.environ["ZIGZ_BENCH_BLOCKING_SYNC"] == "1"
     if blocking:
@@ -856,7 +876,7 @@ def main():
             "trace_steps": trace_steps, "traces_per_step_per_gpu": B, "sponge_servers": servers,
             "merkle_build": args.merkle, "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
             "ms_per_proof_per_gpu": dt / nproofs * 1e3,
-            "host_cpus_available": host_cpus(), "cpus_pinned": pin.get("pinned", 0),
+            "host_cpus_available": ncpu, "cpus_pinned": pin.get("pinned", 0),
             "parallelism": ("1 proof/step, columns sharded over %d GPUs (strong)" % world) if shard else
                            ("independent traces: %d GPU(s) x %d proofs in flight, no data-path collective" % (world, B)),
             "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",

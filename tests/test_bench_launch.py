@@ -61,12 +61,21 @@ def test_single_rank_dry_run():
 
 
 def test_default_lane_count_follows_the_cpu_share(monkeypatch):
-    """--batch 0 (the default): one lane per host CPU of this rank's share, two left for the helper threads, at most 14."""
+    """What a rank sizes its threads for: its own slice of the cores when it has pinned itself (NOT divided by the world size
+    again), its share of the common mask otherwise, never more than its share of a cgroup quota; without the sponge service one
+    lane per CPU, two left for the helper threads, at most 14."""
     import importlib.util
     spec = importlib.util.spec_from_file_location("bench_mod", BENCH)
     b = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(b)
     assert 1 <= b.host_cpus() <= len(os.sched_getaffinity(0))
-    for cpus, world, want in ((16, 1, 14), (128, 8, 14), (256, 8, 14), (8, 1, 6), (16, 8, 1), (2, 1, 1)):
-        monkeypatch.setattr(b, "host_cpus", lambda c=cpus: c)
-        assert b.default_batch(world) == want, (cpus, world)
+    for cpus, want in ((16, 14), (32, 14), (8, 6), (3, 1), (2, 1)):
+        assert b.default_batch(cpus) == want, cpus
+    for mask, quota, world, pinned, want in ((256, None, 8, 0, 32),    # eight unpinned ranks share 256 CPUs
+                                             (32, None, 8, 32, 32),    # a pinned rank keeps its 32-core slice ...
+                                             (32, 128, 8, 32, 16),     # ... unless the launch's cgroup grants less
+                                             (128, 16, 1, 128, 16),    # this pool's 1-GPU boxes: one socket pinned, 16-CPU quota
+                                             (4, None, 8, 0, 1)):
+        monkeypatch.setattr(b.os, "sched_getaffinity", lambda _pid, m=mask: set(range(m)))
+        monkeypatch.setattr(b, "cgroup_cpu_quota", lambda q=quota: q)
+        assert b.rank_cpus(world, pinned) == want, (mask, quota, world, pinned)

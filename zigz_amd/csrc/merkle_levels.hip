@@ -530,9 +530,16 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
 // lane busy whatever mix of constant and busy columns produced the lists.  A list entry's digest is stored at ITS LIST SLOT;
 // children are read where their digests are: an R child at its leader's slot, a G child at its representative's.
 // PAUSE = false for the small levels, whose few waves run alone on their SIMDs (keccak.hpp).
+#ifndef ZK_LEVEL_HASH_MIN_WAVES
+#define ZK_LEVEL_HASH_MIN_WAVES 1  // (A/B: waves per SIMD the compiler must leave room for)
+#endif
 template <bool LEAF, bool PAUSE>
-__global__ __launch_bounds__(TPB) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
+__global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
     __shared__ unsigned long long s_r[RUN_SUBS + 1], s_g[RUN_SUBS + 1];  // exclusive prefixes of the sub-list lengths
+#ifdef ZK_LEVEL_HASH_LDS_PAD  // (A/B: unused LDS per workgroup caps the workgroups per CU)
+    __shared__ unsigned s_pad[ZK_LEVEL_HASH_LDS_PAD / 4];
+    if (b.npad == 3) s_pad[threadIdx.x] = L;  // (never true: keeps the array)
+#endif
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
     if (wave < 2) {
