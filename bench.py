@@ -315,6 +315,11 @@ def main():
                     "scaling = independent-trace throughput.  shard: ONE proof per step, its 43 columns sharded over the "
                     "GPUs (two all-gathers of 43 x 32 B and 43 x (24 + 33 v) B per proof), strong scaling; bounded by the "
                     "sequential host transcript that every rank replays (DESIGN.md s7)")
+    ap.add_argument("--exchange", choices=["shm", "rccl"], default="shm",
+                    help="transport of the sharded paths (--mode shard, and the one-proof-over-all-ranks leg when N > 1): shm = the "
+                    "shared-memory mailbox (zigz_shm_comm: 2-5 us per exchange between the ranks of one node); rccl = RCCL bound "
+                    "natively (zigz_rccl_comm, no torch in the loop: ~60 us per exchange of <= 8 KiB, for ranks on several nodes).  "
+                    "rccl needs one GPU per rank")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--merkle", choices=["cons", "struct", "regs", "all", "tables", "dense"], default="cons",
                     help="Merkle build of the 43 columns (identical trees and proofs in every mode).  cons (the product's default): "
@@ -544,14 +549,30 @@ def main():
 
     # --mode shard: the two exchanges of a column-sharded proof are host-resident and a few KiB -> the shared-memory hook
     # (one node); ZIGZ_BENCH_SHARD_HOOK=torch binds torch.distributed (RCCL / gloo) instead
+    def make_comm(tag, timeout_s):
+        """The exchange transport of a sharded path: every rank calls this (creation is a collective)."""
+        if args.exchange == "rccl":
+            if backend != "nccl":
+                raise RuntimeError("--exchange rccl needs one GPU per rank (this launch runs over %s)" % backend)
+            from zigz_amd.shard import RcclComm
+            uid = torch.zeros(128, dtype=torch.uint8, device=tdev)
+            if rank == 0:
+                uid = torch.frombuffer(bytearray(RcclComm.unique_id()), dtype=torch.uint8).to(tdev)
+            dist.broadcast(uid, src=0)
+            return RcclComm(local_rank, bytes(uid.cpu().numpy().tobytes()), rank, world, max_bytes=1 << 16)
+        from zigz_amd.shard import ShmComm
+        # the name carries a nonce agreed on by the ranks of THIS launch: ports and job ids get reused
+        nonce = torch.tensor([float(int.from_bytes(os.urandom(6), "little"))], dtype=torch.float64, device=tdev)
+        dist.all_reduce(nonce, op=dist.ReduceOp.MAX)
+        return ShmComm("zigz_bench_%s_%s_%x" % (tag, os.environ.get("MASTER_PORT", "0"), int(nonce.item())), rank, world,
+                       max_bytes=1 << 16, timeout_s=timeout_s)
+
     allgather_hook = None
     if shard and dist is not None:
         if os.environ.get("ZIGZ_BENCH_SHARD_HOOK") == "torch":
             allgather_hook = host.make_allgather(dist)
         else:
-            from zigz_amd.shard import ShmComm
-            allgather_hook = ShmComm("zigz_bench_shard_%s" % os.environ.get("MASTER_PORT", "0"), rank, world, max_bytes=1 << 16,
-                                     timeout_s=120.0)
+            allgather_hook = make_comm("shard", 120.0)
     lanes = [Lane(k) for k in range(B)]
     pool = ThreadPoolExecutor(max_workers=B)
 
@@ -699,14 +720,17 @@ def main():
         comm = None
         sd = None
         ok = 1.0
-        try:  # set-up: nothing collective in here, so a rank that fails cannot desynchronise the others
-            from zigz_amd.shard import ShmComm
+        try:  # set-up: a rank that fails before the transport exists is noticed by the others as a timeout of its creation
             sctx = lanes[0].ctx
             sprog = programs.add_xor_loop((N - 3) // 4)  # the same trace on every rank
             strace = host.Trace(sprog, 0x1000, None, 2 * N)
             sd = sctx.dev_alloc(43 * N * 4)
             strace.witness_to_device(sctx, sd, N)
-            comm = ShmComm("zigz_bench_%s" % os.environ.get("MASTER_PORT", "0"), rank, world, max_bytes=1 << 16, timeout_s=60.0)
+        except Exception as e:
+            ok = 0.0
+            shard_leg = {"error": repr(e)[:300]}
+        try:
+            comm = make_comm("leg", 60.0)  # (collective: every rank gets here, whatever happened above)
         except Exception as e:
             ok = 0.0
             shard_leg = {"error": repr(e)[:300]}
@@ -720,7 +744,7 @@ def main():
                 for _ in range(ks):
                     sp = strace.prove_sharded(sctx, sd, N, None, comm)  # the exchanges inside synchronise the ranks
                 sdt = time.perf_counter() - t0
-                shard_leg = {"ms_per_proof": sdt / ks * 1e3, "steps_per_s": strace.num_steps * ks / sdt, "proofs": ks,
+                shard_leg = {"exchange": args.exchange, "ms_per_proof": sdt / ks * 1e3, "steps_per_s": strace.num_steps * ks / sdt, "proofs": ks,
                              "proof_bytes": len(sp), "accepts": host.verify(sp.tobytes(), sprog) == "Accept" if rank == 0 else None}
             except Exception as e:  # a peer died: the shared-memory waits time out on every rank alike
                 shard_leg = {"error": repr(e)[:300]}
