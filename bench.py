@@ -637,68 +637,102 @@ def main():
     trace_steps, trace_lookups, prog = lanes[0].trace.num_steps, lanes[0].trace.num_lookups, lanes[0].prog
     proof = lanes[0].proof.tobytes()  # (the legs below reuse the borrowed buffers and, at the end, the lanes' traces)
 
-    # ---- legs outside the timed region (same run, same resident data)
+    # ---- legs outside the timed region (same run, same resident data).  Each runs under a guard: a leg that fails (out of
+    # HBM on an unusual box, say) is recorded in detail.leg_errors and left out; the line with `value` goes out regardless.
     extras = not args.no_extras and not shard
-    solo = pcie = kern = None
+    solo = kern = None
+    legs = {}         # name -> {"dt", "steps", "trace_steps", ...}: what is reduced over the ranks below
+    leg_errors = {}
+    self_check = {}
+
+    def guard(name, fn):
+        try:
+            return fn()
+        except SystemExit:
+            raise
+        except Exception as e:  # noqa: BLE001
+            leg_errors[name] = repr(e)[:200]
+            sys.stderr.write("bench.py: leg %s failed: %r\n" % (name, e))
+            try:
+                for l in lanes:
+                    l.ctx.synchronize()
+                    l.ctx.release_workspaces()
+            except Exception:
+                pass
+            return None
+
     if extras:
-        ksolo = max(3, min(args.steps, 8))
-        run_step(which=lanes[:1])
-        dts, accs, _ = timed(ksolo, which=lanes[:1])           # one proof at a time on the GPU
-        solo = {"dt": dts, "n": ksolo, "acc": accs}
-        if rank == 0:  # Prover.prove from program bytes: VM + compact trace upload + witness kernels + proof + serialisation
-            host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
-            t0 = time.perf_counter()
-            for _ in range(2):
+        def leg_solo():
+            ksolo = max(3, min(args.steps, 8))
+            run_step(which=lanes[:1])
+            dts, accs, _ = timed(ksolo, which=lanes[:1])           # one proof at a time on the GPU
+            r = {"dt": dts, "n": ksolo, "acc": accs}
+            if rank == 0:  # Prover.prove from program bytes: VM + compact trace upload + witness kernels + proof + serialisation
                 host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
-            solo["from_program_ms"] = (time.perf_counter() - t0) / 2 * 1e3
-            t0 = time.perf_counter()
-            host.Trace(lanes[0].prog, 0x1000, None, 2 * N)
-            solo["vm_ms"] = (time.perf_counter() - t0) * 1e3
-        run_step(Lane.upload_and_prove)
-        dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
-        pcie = {"dt": dtp}
-        # self-check, untimed: every lane's proof under this build ...
-        run_step(Lane.prove_and_digest)
-        digests = [l.digest for l in lanes]
-        run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
-        self_check = {"lane0_alone_equals_lane0_in_batch": lanes[0].digest == digests[0]}  # single-state code, not the 8-way)
-        variants = {}  # the same batch under the other Merkle builds (identical proofs), for the record
-        # (a build without the hints keeps node-addressed trees, 2.75 GiB per proof in flight at 2^20: these legs run on as
-        # many of the lanes as fit -- the GPU bounds them long before that -- and give the memory back afterwards)
-        for l in lanes:
-            l.ctx.release_workspaces()
-        vl = lanes[:max(1, min(B, int(lanes[0].ctx.mem_info()[0] * 0.85) // int(3.6 * (1 << 30) * (1 << max(nv - 20, 0)))))]
-        for mode in ("cons", "struct", "regs", "all", "tables", "dense"):
-            if mode == args.merkle:
-                continue
-            for l in vl:  # (workspaces only grow: what one build kept must not add to what the next one needs)
+                t0 = time.perf_counter()
+                for _ in range(2):
+                    host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
+                r["from_program_ms"] = (time.perf_counter() - t0) / 2 * 1e3
+                t0 = time.perf_counter()
+                host.Trace(lanes[0].prog, 0x1000, None, 2 * N)
+                r["vm_ms"] = (time.perf_counter() - t0) * 1e3
+            return r
+        solo = guard("single_proof", leg_solo)
+
+        def leg_pcie():
+            run_step(Lane.upload_and_prove)
+            dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
+            return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
+        legs["pcie"] = guard("pcie_inclusive", leg_pcie)
+
+        digests = []
+
+        def leg_self_check():  # untimed: every lane's proof under this build ...
+            run_step(Lane.prove_and_digest)
+            digests.extend(l.digest for l in lanes)
+            run_step(Lane.prove_and_digest, which=lanes[:1])  # ... lane 0 once more ALONE (its transcript then runs through the
+            self_check["lane0_alone_equals_lane0_in_batch"] = lanes[0].digest == digests[0]  # single-state code, not the 8-way)
+            return True
+        have_digests = guard("self_check", leg_self_check)
+
+        # the same batch under the other Merkle builds (identical proofs), for the record.  A build without the hints keeps
+        # node-addressed trees, 2.75 GiB per proof in flight at 2^20: these legs run on as many of the lanes as fit -- the GPU
+        # bounds them long before that -- and give the memory back afterwards
+        def variant_lanes():
+            for l in lanes:
                 l.ctx.release_workspaces()
-            set_merkle_mode(mode)
-            run_step(Lane.prove_and_digest, which=vl)
-            # ... must be byte-identical under every other build (dense hashes every node of every tree)
-            self_check["lanes_equal_under_" + mode] = [l.digest for l in vl] == digests[:len(vl)]
-            ks = 3 if mode in ("cons", "struct", "regs", "all") else 2
-            dtv, accv, _ = timed(ks, which=vl)
-            variants[mode] = {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * len(vl)), "lanes": len(vl),
-                              "trace_steps": float(sum(l.trace.num_steps for l in vl))}
-        set_merkle_mode(args.merkle)
-        for l in lanes:
-            l.ctx.release_workspaces()
-        pcie["variants"] = variants
-        pcie["self_check"] = self_check
+            return lanes[:max(1, min(B, int(lanes[0].ctx.mem_info()[0] * 0.85) // int(3.6 * (1 << 30) * (1 << max(nv - 20, 0)))))]
+        vl = guard("merkle_variants", variant_lanes) if have_digests else None
+        for mode in ("cons", "struct", "regs", "all", "tables", "dense"):
+            if mode == args.merkle or not vl:
+                continue
+
+            def leg_variant(mode=mode):
+                for l in vl:  # (workspaces only grow: what one build kept must not add to what the next one needs)
+                    l.ctx.release_workspaces()
+                set_merkle_mode(mode)
+                run_step(Lane.prove_and_digest, which=vl)
+                # ... must be byte-identical under every other build (dense hashes every node of every tree)
+                self_check["lanes_equal_under_" + mode] = [l.digest for l in vl] == digests[:len(vl)]
+                ks = 3 if mode in ("cons", "struct", "regs", "all") else 2
+                dtv, accv, _ = timed(ks, which=vl)
+                return {"dt": dtv, "steps": ks, "perms": accv["keccak_permutations"] / (ks * len(vl)), "lanes": len(vl),
+                        "trace_steps": float(sum(l.trace.num_steps for l in vl))}
+            legs["variant:" + mode] = guard("merkle_variant_" + mode, leg_variant)
+            set_merkle_mode(args.merkle)
+        guard("release", lambda: [l.ctx.release_workspaces() for l in lanes])
         if not all(self_check.values()):
             raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
-            kern = kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)), big_nv=24 if nv <= 22 else 0)
+            kern = guard("kernel_leg", lambda: kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)),
+                                                          big_nv=24 if nv <= 22 else 0))
         # The structure-aware levels make the GPU time depend on the trace, so the same batch also runs on three other traces
         # (same lanes, same everything else; the lanes' witness buffers are overwritten: these are the last legs on them):
         #   worst     the worst case BY CONSTRUCTION for the run-aware register levels: a loop that writes 30 different
         #             registers in turn, so the <= N change points of the 31 register columns are spread evenly over all of them
+        #   mixed     BASELINE config 4's RV64IM mix (MUL / DIVU / REM / LD / SD / *W in a 12-step loop) at this size
         #   straight  a program that never loops (~2^20 different instructions, each executed once): the content-addressed group
         #             finds nothing and is dropped on the device, its columns are built from the tables / densely
-        #   mixed     BASELINE config 4's RV64IM mix (MUL / DIVU / REM / LD / SD / *W in a 12-step loop) at this size
-        import numpy as np
-
         def other_trace(make_prog, steps_l):
             for k, l in enumerate(lanes):
                 l.retrace(make_prog(rank * B + k))
@@ -706,11 +740,13 @@ def main():
             dtl, accl, _ = timed(steps_l)
             return {"dt": dtl, "steps": steps_l, "perms": accl["keccak_permutations"] / (steps_l * B),
                     "trace_steps": float(sum(l.trace.num_steps for l in lanes))}
-        pcie["worst"] = other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3)
-        pcie["mixed"] = other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3)
-        # (last: a context whose group was dropped twice in a row stops trying it for its next 15 jobs)
-        base = programs.straight_line_program(1000 + rank, int(0.95 * N))  # one program per rank, a different prefix per lane
-        pcie["straight"] = other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], 3)
+        legs["worst"] = guard("register_worst_case", lambda: other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3))
+        legs["mixed"] = guard("config4_mixed", lambda: other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3))
+
+        def leg_straight():  # (last: a context whose group was dropped twice in a row stops trying it for its next 15 jobs)
+            base = programs.straight_line_program(1000 + rank, int(0.95 * N))  # one program per rank, a prefix per lane
+            return other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], 3)
+        legs["straight"] = guard("straight_line", leg_straight)
 
     # ---- N > 1, traces mode: also ONE proof per step sharded by column over the N ranks (the strong-scaling variant of
     # --mode shard), reported in the same line.  Exchanges go through the shared-memory hook (host-resident payloads of a
@@ -760,10 +796,12 @@ def main():
 
     # ---- the other trace sizes of the north-star (2^16 .. 2^24), same bench trace, same build: small step counts, after the
     # main lanes have given their HBM back (a 2^24 proof in flight holds ~55 GiB)
-    sweep = {}
     if extras:
         for l in lanes:
-            l.close()
+            try:
+                l.close()
+            except Exception:
+                pass
         lanes_main, lanes = lanes, []
         probe = zigz_amd.Context(local_rank)
         free_now = probe.mem_info()[0]
@@ -776,14 +814,14 @@ def main():
             per_lane = int(0.9 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
             nl = max(1, min(B, int(free_now * 0.8) // per_lane))
             ls = []
-            try:
-                ls = [Lane(k, nv_s) for k in range(nl)]
+
+            def leg_size(nv_s=nv_s, steps_s=steps_s, nl=nl, ls=ls):
+                ls.extend(Lane(k, nv_s) for k in range(nl))
                 run_step(which=ls)
                 run_step(which=ls)
                 dts_, _, _ = timed(steps_s, which=ls)
-                sweep[nv_s] = {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
-            except zigz_amd.ZigzError as e:  # (out of HBM at this size: the line goes out without this entry)
-                sys.stderr.write("bench.py: sweep at 2^%d skipped: %r\n" % (nv_s, e))
+                return {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
+            legs["nv%d" % nv_s] = guard("value_nv%d" % nv_s, leg_size)
             for l in ls:
                 try:
                     l.close()
@@ -792,6 +830,10 @@ def main():
     else:
         lanes_main = lanes
 
+    # every leg of the fixed list is reduced by EVERY rank whether its own attempt succeeded or not (the number of collectives
+    # must not depend on what failed where); a leg that failed on any rank is dropped everywhere
+    leg_names = ["pcie"] + ["variant:" + m for m in ("cons", "struct", "regs", "all", "tables", "dense")] + \
+                ["worst", "mixed", "straight", "nv16", "nv22", "nv24"]
     if torch is not None:
         def allmax(x):
             t = torch.tensor([x], dtype=torch.float64, device=tdev)
@@ -802,26 +844,16 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.SUM)
             return float(t.item())
         dt = allmax(dt)
-        if pcie:
-            pcie["dt"] = allmax(pcie["dt"])
-            for vv in pcie.get("variants", {}).values():
-                vv["dt"] = allmax(vv["dt"])
-                vv["trace_steps"] = allsum(vv["trace_steps"])
-            for leg in ("worst", "straight", "mixed"):
-                if leg in pcie:
-                    pcie[leg]["dt"] = allmax(pcie[leg]["dt"])
-                    pcie[leg]["trace_steps"] = allsum(pcie[leg]["trace_steps"])
-        for nv_s in (16, 22, 24):  # (every rank takes part for every size, whether its own leg succeeded or not)
-            if nv_s == nv or not extras:
-                continue
-            sv = sweep.get(nv_s)
-            ok = -allmax(-1.0 if sv else 0.0)  # 1.0 only if every rank has the entry
-            dtm = allmax(sv["dt"] if sv else 0.0)
-            tsm = allsum(sv["trace_steps"] if sv else 0.0)
-            if ok == 1.0:
-                sv["dt"], sv["trace_steps"] = dtm, tsm
-            else:
-                sweep.pop(nv_s, None)
+        if extras:
+            for name in leg_names:
+                rec = legs.get(name)
+                everyone = -allmax(0.0 if rec else 1.0) == 0.0  # nobody missing
+                dtm = allmax(rec["dt"] if rec else 0.0)
+                tsm = allsum(rec["trace_steps"] if rec else 0.0)
+                if rec and everyone:
+                    rec["dt"], rec["trace_steps"] = dtm, tsm
+                else:
+                    legs[name] = None
         s = torch.tensor([local_steps], dtype=torch.float64, device=tdev)
         dist.all_reduce(s, op=dist.ReduceOp.SUM)
         total_steps = local_steps if shard else float(s.item())  # shard: all ranks worked on the same trace
@@ -877,11 +909,15 @@ def main():
         roof["structure_share"] = share["structure"]
         roof["top_share"] = share["top"]
         roof["eval_share"] = share["eval"]
-        roof["top_frac"] = valu_frac(acc.get("top_perms", 0), ic["top"], classes["top"])
+        # the structure passes are HBM-side work: their algorithmic bytes (4 B per leaf of the 33 run-aware columns; the group's
+        # ten columns twice + 12 B per node of its levels) over their time with ONE proof on the GPU at a time
+        struct_bytes = {"cons": 224.0, "struct": 132.0, "regs": 124.0, "all": 140.0}.get(args.merkle, 0.0) * N
         roof["eval_hbm_frac"] = ((acc["bind_vec_bytes"] / 1e9) / (acc["bind_vec_us"] / 1e6) / HBM_PEAK_GBS) if acc.get("bind_vec_us") else None
         if solo:  # the same class with one proof on the GPU at a time (no overlap between proofs)
             a = solo["acc"]
             roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
+            if a.get("structure_us") and struct_bytes:
+                roof["structure_in_proof_hbm_frac"] = struct_bytes * solo["n"] / 1e9 / (a["structure_us"] / 1e6) / HBM_PEAK_GBS
         # all Keccak work of the region over its wall time: a lower bound on what the chip sustained while the bench ran
         roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * ic["level_hash"] / dt / 1e12 / VALU_PEAK_TOPS
         kl = kern.get("k_keccak_leaves[43x2^%d]" % nv) if kern else None
@@ -925,27 +961,31 @@ def main():
             if "from_program_ms" in solo:
                 cfg["from_program_bytes_ms"] = solo["from_program_ms"]  # one Prover.prove incl. VM execution
                 detail["single_proof"]["vm_ms"] = solo["vm_ms"]
-        if pcie:
-            cfg["pcie_inclusive_value"] = total_steps * args.steps / pcie["dt"]  # trace upload + witness kernels inside the loop
-            if "worst" in pcie:
-                cfg["register_worst_case_value"] = rate(pcie["worst"])
-                cfg["straight_line_value"] = rate(pcie["straight"])
-                cfg["config4_mixed_value"] = rate(pcie["mixed"])
-                detail["other_traces_keccak_permutations_per_proof"] = {k: pcie[k]["perms"] for k in ("worst", "straight", "mixed")}
-            if pcie.get("variants"):
-                if "dense" in pcie["variants"]:
-                    cfg["dense_merkle_value"] = rate(pcie["variants"]["dense"])
-                detail["merkle_variants"] = {
-                    m: {"value": rate(vv), "keccak_permutations_per_proof": vv["perms"], "proofs_in_flight": vv["lanes"]}
-                    for m, vv in pcie["variants"].items()}
-            if pcie.get("self_check"):
-                cfg["self_check_ok"] = bool(all(pcie["self_check"].values()))
-                detail["self_check"] = dict(pcie["self_check"], note="SHA-256 of every lane's 2^%d proof: identical under every "
-                                            "Merkle build, and lane 0 alone (single-state transcript code) vs in the batch "
-                                            "(sponge service)" % nv)
-        for nv_s, sv in sorted(sweep.items()):
-            cfg["value_nv%d" % nv_s] = rate(sv)
-            detail["value_nv%d_lanes" % nv_s] = sv["lanes"]
+        if legs.get("pcie"):  # trace upload + witness kernels inside the loop
+            cfg["pcie_inclusive_value"] = rate(legs["pcie"])
+        for key, name in (("worst", "register_worst_case_value"), ("mixed", "config4_mixed_value"), ("straight", "straight_line_value")):
+            if legs.get(key):
+                cfg[name] = rate(legs[key])
+                detail.setdefault("other_traces_keccak_permutations_per_proof", {})[key] = legs[key]["perms"]
+        variants = {k.split(":", 1)[1]: v for k, v in legs.items() if k.startswith("variant:") and v}
+        if variants:
+            if "dense" in variants:
+                cfg["dense_merkle_value"] = rate(variants["dense"])
+            detail["merkle_variants"] = {
+                m: {"value": rate(vv), "keccak_permutations_per_proof": vv["perms"], "proofs_in_flight": vv["lanes"]}
+                for m, vv in variants.items()}
+        if self_check:
+            cfg["self_check_ok"] = bool(all(self_check.values()))
+            detail["self_check"] = dict(self_check, note="SHA-256 of every lane's 2^%d proof: identical under every "
+                                        "Merkle build, and lane 0 alone (single-state transcript code) vs in the batch "
+                                        "(sponge service)" % nv)
+        for nv_s in (16, 22, 24):
+            sv = legs.get("nv%d" % nv_s)
+            if sv:
+                cfg["value_nv%d" % nv_s] = rate(sv)
+                detail["value_nv%d_lanes" % nv_s] = sv["lanes"]
+        if leg_errors:
+            detail["leg_errors"] = leg_errors
         if shard_leg:
             for k, v in shard_leg.items():
                 detail["one_proof_over_all_gpus_" + k] = v
