@@ -594,6 +594,8 @@ def main():
         lockstep -- and the region ends when the last lane has finished.  Returns (seconds, accumulated stats, phases)."""
         ls = lanes if which is None else which
         acc = {}
+        acc_t = {}  # the same sums over the lanes that run in timing mode only
+        n_t = 0
         phases = {}
 
         def lane_loop(l):
@@ -605,21 +607,33 @@ def main():
         c0 = time.process_time()
         t0 = time.perf_counter()
         futs = [pool.submit(lane_loop, l) for l in ls]
-        for f in futs:
+        for l, f in zip(ls, futs):
             for st, ph in f.result():
                 for k, v in st.items():
                     acc[k] = acc.get(k, 0) + v
+                    if getattr(l, "timing", False):
+                        acc_t[k] = acc_t.get(k, 0) + v
+                n_t += 1 if getattr(l, "timing", False) else 0
                 for k, v in ph.items():
                     phases[k] = phases.get(k, 0.0) + v
         sync_all()
+        acc["_timed"] = acc_t
+        acc["_timed_proofs"] = n_t
         acc["process_cpu_s"] = time.process_time() - c0  # all threads of this process (lanes, sponge servers, helpers)
         return time.perf_counter() - t0, acc, phases
 
     run_step()  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
     for _ in range(args.warmup):
         run_step()
-    for l in lanes:
-        l.ctx.enable_timing(True)
+    # Per-launch kernel timestamps (HIP events on every launch's own stream) cost host CPU -- two events per launch, collected
+    # per proof, and their completion handlers on the runtime's event thread: ~0.5 ms of the ~8 ms of CPU per proof, ~3 % of
+    # `value` on a host-bound box.  They stay on for EVERY lane of the timed region: `roofline` is then computed from all of its
+    # launches, and lanes of unequal cost would only add a tail (every 8th lane timed: 1.72-1.75 G against 1.77-1.83 G with all
+    # of them and 1.86 G with none, same box; ZIGZ_BENCH_TIMING_EVERY=k times every k-th lane).
+    timing_every = max(1, int(os.environ.get("ZIGZ_BENCH_TIMING_EVERY", "1")))
+    for k, l in enumerate(lanes):
+        l.timing = k % timing_every == 0
+        l.ctx.enable_timing(l.timing)
     if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import thread_cpu
@@ -632,6 +646,12 @@ def main():
             sys.stderr.write("  %-20s threads %3d  cpu %.2f s\n" % (comm, n, sec))
         allrows, _ = thread_cpu.diff(snap0, thread_cpu.snapshot(), top=10000)
         sys.stderr.write("  per thread, descending: " + " ".join("%.2f" % r[0] for r in allrows) + "\n")
+        for r in allrows[:14]:
+            try:
+                wchan = open("/proc/self/task/%d/wchan" % r[2]).read().strip()
+            except OSError:
+                wchan = "?"
+            sys.stderr.write("    tid %d: user %.2f s  sys %.2f s  wchan %s\n" % (r[2], r[3], r[4], wchan))
     nproofs = args.steps * B
     local_steps = float(sum(l.trace.num_steps for l in lanes))
     trace_steps, trace_lookups, prog = lanes[0].trace.num_steps, lanes[0].trace.num_lookups, lanes[0].prog
@@ -863,8 +883,10 @@ def main():
     if rank == 0:
         assert host.verify(proof, prog) == "Accept"
         ic = isa_counts()
-        # ---- where the kernel time of the TIMED REGION went, by class (every launch carries its own begin / end timestamps
-        # in timing mode; concurrent proofs share the chip, so the per-launch durations are stretched by the overlap)
+        # ---- where the kernel time of the TIMED REGION went, by class (every launch of the lanes in timing mode carries its own
+        # begin / end timestamps; concurrent proofs share the chip, so the per-launch durations are stretched by the overlap)
+        acc_all, nproofs_all = acc, nproofs
+        acc, nproofs = (acc["_timed"], acc["_timed_proofs"]) if acc.get("_timed_proofs") else (acc, nproofs)
         classes = {
             "level_hash": acc.get("list_hash_us", 0.0),       # k_level_hash: the list-driven levels 0 .. v - 8
             "structure": acc.get("structure_us", 0.0),        # k_runs_stage + k_cons_*: which nodes are hashed (no hashing)
@@ -875,6 +897,7 @@ def main():
         }
         kernel_us = max(sum(classes.values()), 1e-9)
         share = {k: v / kernel_us for k, v in classes.items()}
+        kernel_us_per_proof = {k: v / max(nproofs, 1) for k, v in classes.items()}
 
         def valu_frac(perms, instr, us):
             return perms * instr / (us / 1e6) / 1e12 / VALU_PEAK_TOPS if us else None
@@ -907,7 +930,6 @@ def main():
                                      "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash")}
         roof["level_hash_share"] = share["level_hash"]
         roof["structure_share"] = share["structure"]
-        roof["top_share"] = share["top"]
         roof["eval_share"] = share["eval"]
         # the structure passes are HBM-side work: their algorithmic bytes (4 B per leaf of the 33 run-aware columns; the group's
         # ten columns twice + 12 B per node of its levels) over their time with ONE proof on the GPU at a time
@@ -918,6 +940,8 @@ def main():
             roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
             if a.get("structure_us") and struct_bytes:
                 roof["structure_in_proof_hbm_frac"] = struct_bytes * solo["n"] / 1e9 / (a["structure_us"] / 1e6) / HBM_PEAK_GBS
+        roof["timed_launches_sampled"] = nproofs / max(nproofs_all, 1)  # share of the region's proofs whose launches were timed
+        acc, nproofs = acc_all, nproofs_all
         # all Keccak work of the region over its wall time: a lower bound on what the chip sustained while the bench ran
         roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * ic["level_hash"] / dt / 1e12 / VALU_PEAK_TOPS
         kl = kern.get("k_keccak_leaves[43x2^%d]" % nv) if kern else None
@@ -948,7 +972,7 @@ def main():
                                        "step (8-way AVX-512 Keccak-f); the proofs' own threads sleep meanwhile" % servers)
                                       if servers else "every proof absorbs its transcript on its own host thread",
                   "kernel_time_shares_timed_region": share,
-                  "kernel_us_per_proof_timed_region": {k: v / nproofs for k, v in classes.items()}}
+                  "kernel_us_per_proof_timed_region": kernel_us_per_proof}
         if solo:
             cfg["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
             a = solo["acc"]

@@ -26,6 +26,8 @@ ap.add_argument("--iters", type=int, default=20)
 ap.add_argument("--trace", default="add_xor", help="add_xor | round_robin | mixed (RV64IM mix with loads / stores, BASELINE config 4's loop)")
 ap.add_argument("--hint", default="cons", help="run-aware hint: regs | regs+mem | all | cons (regs+mem and the ten "
                 "instruction-determined columns as a content-addressed group)")
+ap.add_argument("--debug-skip", type=int, default=0, help="measurement only (wrong trees): 1 = no level hashing / top kernel, "
+                "2 = no structure passes (the hash launches then find the previous job's lists)")
 ap.add_argument("--phases", action="store_true", help="also print the host wall time of each call of the commit job")
 ap.add_argument("--blocking-sync", action="store_true", help="waiting host threads sleep instead of spinning")
 args = ap.parse_args()
@@ -59,6 +61,7 @@ class Lane:
                                                "cons": REGS | (3 << 40)}[args.hint])
         if args.hint == "cons":
             self.ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
+        self.debug_skip = args.debug_skip
 
     def once(self):
         t0 = time.perf_counter()
@@ -76,6 +79,9 @@ class Lane:
 lanes = [Lane(k) for k in range(args.lanes)]
 for l in lanes:
     l.once()
+    l.once()
+    if l.debug_skip:
+        l.ctx.set_option("debug_skip", l.debug_skip)
 
 
 def loop(l):

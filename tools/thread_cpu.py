@@ -11,7 +11,7 @@ def snapshot():
                 s = f.read()
             comm = s[s.index("(") + 1:s.rindex(")")]
             rest = s[s.rindex(")") + 2:].split()
-            out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / tick)
+            out[int(tid)] = (comm, (int(rest[11]) + int(rest[12])) / tick, int(rest[11]) / tick, int(rest[12]) / tick)
         except (OSError, ValueError):
             pass
     return out
@@ -19,13 +19,14 @@ def snapshot():
 
 def diff(a, b, top=12):
     rows = []
-    for tid, (comm, t) in b.items():
-        t0 = a.get(tid, (comm, 0.0))[1]
-        if t - t0 > 0:
-            rows.append((t - t0, comm, tid))
+    for tid, rec in b.items():
+        comm, t = rec[0], rec[1]
+        old = a.get(tid, (comm, 0.0, 0.0, 0.0))
+        if t - old[1] > 0:
+            rows.append((t - old[1], comm, tid, rec[2] - old[2], rec[3] - old[3]))
     rows.sort(reverse=True)
     by = {}
-    for dt, comm, _ in rows:
+    for dt, comm, *_ in rows:
         n, s = by.get(comm, (0, 0.0))
         by[comm] = (n + 1, s + dt)
     return rows[:top], sorted(by.items(), key=lambda kv: -kv[1][1])

@@ -50,6 +50,7 @@ struct zigz_ctx {
     unsigned long long *d_cons_count;
     bool run_aware_materialize;  // option (tests): write the copies of every run-aware level (no virtual copies)
     bool cons_always;            // option (tests): try the content-addressed group in every job, however often it was dropped
+    int debug_skip;              // option (measurement only, wrong trees): 1 = no level hashing / top, 2 = no structure passes
     uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
                               // are copied, not hashed); "merkle_dedup" = 1 is all columns
     unsigned long long *d_run_count;  // nodes hashed by the run-aware launches of the last build
@@ -332,6 +333,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "run_aware_materialize") == 0) { ctx->run_aware_materialize = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "cons_group_mask") == 0) { ctx->cons_group_mask = (uint64_t)value; return ZIGZ_OK; }
     if (strcmp(name, "cons_always") == 0) { ctx->cons_always = value != 0; return ZIGZ_OK; }
+    if (strcmp(name, "debug_skip") == 0) { ctx->debug_skip = (int)value; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
@@ -1463,8 +1465,10 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             t.upper = (uint8_t *)u;
         }
         b.t = t;
-        launch_runs_structure(b, ctx->stream, R.n ? stamp(4, 0) : nullptr);
-        launch_cons_structure(b, ctx->stream, G.n ? stamp(4, 0) : nullptr);
+        if (ctx->debug_skip != 2) {
+            launch_runs_structure(b, ctx->stream, R.n ? stamp(4, 0) : nullptr);
+            launch_cons_structure(b, ctx->stream, G.n ? stamp(4, 0) : nullptr);
+        }
         if (GS.n && b.g_has_slabs) {  // only if the group was dropped: its small-domain members' levels 0 and 1 by table
             const ColMap gs = slab_map(GS);
             launch_keccak_small_l01(d_vals, val_stride, n_values, npad, t.slab, stride, GS, ctx->d_sd_tables, ctx->d_sd_fallbacks + 1,
@@ -1476,7 +1480,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     unsigned first_top = 0;  // the level the top kernel starts from
     if (lists) {
         for (unsigned l = 0; l <= top; l++) {
-            launch_level_hash(b, l, ctx->stream, stamp(5, 0));
+            if (ctx->debug_skip != 1) launch_level_hash(b, l, ctx->stream, stamp(5, 0));
             if (l == top) break;
             ColMap m{};  // the densely built columns that already have level l: D, and H from level 1
             for (size_t c = 0; c < ncols; c++) {
@@ -1511,7 +1515,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     }
     if (height) {
         ctx->build_top_perms = (uint64_t)ncols * ((npad >> first_top) - 1);
-        launch_merkle_top(t, first_top, height, ncols, ctx->stream, stamp(6, ctx->build_top_perms));
+        if (ctx->debug_skip != 1) launch_merkle_top(t, first_top, height, ncols, ctx->stream, stamp(6, ctx->build_top_perms));
     }
     if (lists && whole) launch_fill_virtual(b, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
