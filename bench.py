@@ -756,9 +756,18 @@ def main():
         def other_trace(make_prog, steps_l):
             for k, l in enumerate(lanes):
                 l.retrace(make_prog(rank * B + k))
+            # two untimed steps: a context that meets a new kind of trace learns the room its lists need (a build repeated in
+            # zigz_commit_roots) and, where the group finds nothing twice in a row, stops trying it; what is timed is the
+            # service's steady state on that trace, and `rebuilds` says how many builds were repeated inside the timed steps
+            def repeated():  # (a context counts the builds it had to repeat since it was created)
+                return sum(l.ctx.stats()["rebuilds"] for l in lanes)
+            r0 = repeated()
             run_step()
+            run_step()
+            r1 = repeated()
             dtl, accl, _ = timed(steps_l)
             return {"dt": dtl, "steps": steps_l, "perms": accl["keccak_permutations"] / (steps_l * B),
+                    "rebuilds": (repeated() - r1) / (steps_l * B), "rebuilds_while_learning": (r1 - r0) / (2.0 * B),
                     "trace_steps": float(sum(l.trace.num_steps for l in lanes))}
         legs["worst"] = guard("register_worst_case", lambda: other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3))
         legs["mixed"] = guard("config4_mixed", lambda: other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3))
@@ -991,6 +1000,7 @@ def main():
             if legs.get(key):
                 cfg[name] = rate(legs[key])
                 detail.setdefault("other_traces_keccak_permutations_per_proof", {})[key] = legs[key]["perms"]
+                detail.setdefault("other_traces_rebuilds_per_proof", {})[key] = [legs[key]["rebuilds_while_learning"], legs[key]["rebuilds"]]
         variants = {k.split(":", 1)[1]: v for k, v in legs.items() if k.startswith("variant:") and v}
         if variants:
             if "dense" in variants:

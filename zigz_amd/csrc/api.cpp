@@ -642,16 +642,16 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
             if (r >= P) return ZIGZ_ERR_NOT_CANONICAL;
             rt[c * nv + j] = host_to_mont(r);
         }
-    void *d_rt;
-    CHK(ws_get(ctx, WS_MISC, nv * ncols * 4 + 64, &d_rt));
-    HIPCHK(ctx, hipMemcpyAsync(d_rt, rt, nv * ncols * 4, hipMemcpyHostToDevice, ctx->stream));
+    // zero-copy: k_eq_weights reads the few KB of points from the pinned buffer (both callers wait for the stream before they
+    // return, so the buffer is not rewritten under it)
+    const uint32_t *d_rt = rt;
     // workspace: part[ncols][groups][m] u64 | W1[ncols][nb] u32 | W2[ncols][m] u32 | T1[ncols][m] u32
     void *ws;
     CHK(ws_get(ctx, WS_FOLD, ncols * (groups * m * 8 + nb * 4 + m * 4 + m * 4) + 256, &ws));
     unsigned long long *d_part = (unsigned long long *)ws;
     uint32_t *d_w1 = (uint32_t *)(d_part + ncols * groups * m), *d_w2 = d_w1 + ncols * nb, *d_t1 = d_w2 + ncols * m;
-    launch_eq_weights((const uint32_t *)d_rt, nv, k1, d_w1, nb, ncols, ctx->stream);
-    launch_eq_weights((const uint32_t *)d_rt + k1, nv, k2, d_w2, m, ncols, ctx->stream);
+    launch_eq_weights(d_rt, nv, k1, d_w1, nb, ncols, ctx->stream);
+    launch_eq_weights(d_rt + k1, nv, k2, d_w2, m, ncols, ctx->stream);
     bind_pool_reset(ctx);
     const bool rec = ctx->timing;
     // the one pass over the data; in timing mode the events carry the dispatch's own begin/end timestamps
@@ -1359,9 +1359,12 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             HIPCHK(ctx, hipMalloc((void **)&ctx->d_sd_fallbacks, 64));
             launch_sd_tables(ctx->d_sd_tables, ctx->stream);
         }
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_sd_fallbacks, 0, 16, ctx->stream));
         CHK(ws_get(ctx, WS_DEDUP, (sd_todo_words(npad, H.n) + sd_todo_words(npad, GS.n)) * 4, &sd_todo));
     }
+    // every counter this build's kernels add to, zeroed by ONE launch (three memsets are three commands in the stream)
+    if (H.n || GS.n || R.n || G.n)
+        launch_zero_counters((H.n || GS.n) ? ctx->d_sd_fallbacks : nullptr, R.n ? ctx->d_run_count : nullptr,
+                             G.n ? ctx->d_cons_count : nullptr, ctx->stream);
     if (H.n) {
         // in a commit job the leaf digests of these columns are left out (virtual): only an opening reads one, and it
         // hashes that value itself
@@ -1417,7 +1420,6 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             t.ncols = R.n;
             for (unsigned y = 0; y < R.n; y++) t.y_of_col[R.c[y]] = (signed char)y;
             b.r_ctr = ctx->d_run_count;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_run_count, 0, RUN_CTRS * 8, ctx->stream));
             ctx->stats.run_aware_columns = R.n;
             ctx->stats.run_aware_dense_nodes = (uint64_t)R.n * level_nodes;
         }
@@ -1449,7 +1451,6 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             ctx->cons_gen += top + 1;
             b.g_ctr = ctx->d_cons_count;
             b.g_has_slabs = whole || ctx->caps.g_slabs;
-            HIPCHK(ctx, hipMemsetAsync(ctx->d_cons_count, 0, RUN_CTRS * 8, ctx->stream));
             t.g_ncols = G.n;
             t.g_dropped = ctx->d_cons_count + 8;
             for (unsigned k = 0; k < G.n; k++) t.g_j_of_col[G.c[k]] = (signed char)k;
@@ -1703,13 +1704,12 @@ static zigz_status job_build(zigz_commit_job *job) {
     }
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     // roots + the counters of the build -> contiguous device buffer -> pinned staging (async), then the "built" event
-    void *d_roots;
-    CHK(ws_get(ctx, WS_MISC, ncols * 32 + JOB_SUMMARY_WORDS * 8 + nv * ncols * 4 + 128, &d_roots));
-    launch_job_summary(job->tree, (unsigned)nv, (uint8_t *)d_roots, ncols, ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
+    // zero-copy: the summary kernel stores the roots and counters into the pinned host buffer itself (no copy command)
+    launch_job_summary(job->tree, (unsigned)nv, ctx->h_roots, ncols,
+                       ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
                        (ctx->stats.small_domain_columns || ctx->build_cons_sd) ? ctx->d_sd_fallbacks : nullptr,
                        ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream);
     HIPCHK(ctx, hipGetLastError());
-    HIPCHK(ctx, hipMemcpyAsync(ctx->h_roots, d_roots, ncols * 32 + JOB_SUMMARY_WORDS * 8, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
     // hinted columns take levels 0 and 1 (N + N/2 digests) from the tables (waves that had to hash are counted in
     // small_domain_fallback_waves, read in zigz_commit_roots; they are not added back here)
@@ -1874,6 +1874,39 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
     if (job->state != 1) return ZIGZ_ERR_BAD_STATE;
     const size_t nv = job->nv, ncols = job->ncols;
     if (nv && (!points || !siblings || !dirs)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    // What a proof needs back -- 43 evaluations, leaves, sibling digests, directions: ~30 KB -- is written by the kernels
+    // straight into the pinned staging buffer, and the indices are read from it: no copy command at all, one wait (0.51 vs
+    // 0.52 ms of GPU per proof with 14 lanes; ONE packed copy through the same buffer was slower than the five small copies
+    // to pageable memory of the fallback below: 0.56 ms).
+    const size_t sib_b = ncols * nv * 32, leaf_b = ncols * 4, val_b = ncols * 4, dir_b = ncols * nv;
+    const size_t out_b = sib_b + leaf_b + val_b + dir_b;
+    if (out_b <= PIN_WORDS * 8 / 2 && nv * ncols * 4 + ncols * 8 <= PIN_WORDS * 8 / 2) {
+        uint8_t *h = (uint8_t *)ctx->h_pin;
+        uint8_t *z_sib = h;
+        uint32_t *z_leaf = (uint32_t *)(h + sib_b), *z_val = z_leaf + ncols;
+        uint8_t *z_dirs = (uint8_t *)(z_val + ncols);
+        uint64_t *h_idx = ctx->h_pin + PIN_WORDS - ncols;
+        for (size_t c = 0; c < ncols; c++) {
+            h_idx[c] = nv == 0 ? 0 : points[c * nv] % ((uint64_t)1 << nv);  // pointToIndex
+            indices[c] = h_idx[c];
+        }
+        CHK(timed_begin(ctx, 4));
+        CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val));
+        CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
+        launch_paths(job->tree, job->tree.npad, (unsigned)nv, job->d_cols, job->col_stride, h_idx, z_sib, z_dirs, z_leaf, ncols,
+                     ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (sib_b) memcpy(siblings, z_sib, sib_b);
+        for (size_t c = 0; c < ncols; c++) {
+            leaves[c] = z_leaf[c];
+            values[c] = z_val[c];
+        }
+        if (dir_b) memcpy(dirs, z_dirs, dir_b);
+        CHK(bind_pool_collect(ctx));
+        job->state = 2;
+        return ZIGZ_OK;
+    }
     void *dv;
     CHK(ws_get(ctx, WS_SCRATCH, ncols * 4 + 64, &dv));
     CHK(timed_begin(ctx, 4));

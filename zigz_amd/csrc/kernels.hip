@@ -938,6 +938,17 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
         cnt[8 + threadIdx.x] = mx;
     }
 }
+__global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g) {
+    const unsigned i = blockIdx.x * TPB + threadIdx.x;
+    if (i < RUN_CTRS) {
+        if (r) r[i] = 0;
+        if (g) g[i] = 0;
+    }
+    if (sd && i < 2) sd[i] = 0;
+}
+void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s) {
+    hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTRS + TPB - 1) / TPB), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr);
+}
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s) {
     hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr, d_sd_ctr,

@@ -278,6 +278,9 @@ void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t
 //   (its distinct leaves), [6] d_r_ctr[10] | d_g_ctr[10] << 8 (out of room / slabs missing), then per level l < RUN_MAX_LEVELS
 //   the longest sub-list of the R lists [8 + l] and of the G lists [8 + RUN_MAX_LEVELS + l]; null pointers read as 0
 constexpr unsigned JOB_SUMMARY_WORDS = 8 + 2 * RUN_MAX_LEVELS;
+// the counters a build's kernels add to (2 words of small-domain fall-backs, RUN_CTRS words each of the R and G lists; null =
+// not used by this build), zeroed by one launch
+void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s);
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s);
 // gather element 0 of each column of a strided table
