@@ -502,6 +502,10 @@ def main():
             self.proof = None
             self.up_ctx = None
             self.d_next = None
+            self.k = k
+            self.timing = False     # per-launch timestamps on the next proof?
+            self.timing_every = 0   # 0: leave the context's timing mode alone
+            self.proofs_done = 0
 
         def retrace(self, prog):  # the same lane on another program of the same size (overwrites the resident witness)
             self.prog = prog
@@ -522,11 +526,19 @@ def main():
                 self.ctx = None
 
         def prove(self):
+            if self.timing_every:  # per-launch timestamps on every timing_every-th proof of this lane (see the timed region)
+                self.proofs_done += 1
+                on = (self.proofs_done + self.k) % self.timing_every == 0
+                if on != self.timing:
+                    self.timing = on
+                    self.ctx.enable_timing(on)
             if shard and dist is not None:
                 self.proof = self.trace.prove_sharded(self.ctx, self.d_cols, self.N, dist, allgather_hook)
             else:
                 self.proof = self.trace.prove(self.ctx, self.d_cols, self.N, want_bytes="borrow")
-            return self.ctx.stats(), host.last_timings()
+            st = self.ctx.stats()
+            st["_timed"] = 1 if self.timing else 0
+            return st, host.last_timings()
 
         def prove_and_digest(self):  # self-check steps (untimed): SHA-256 of the proof, taken on the proving thread while
             # the borrowed buffer is still this proof's
@@ -611,9 +623,9 @@ def main():
             for st, ph in f.result():
                 for k, v in st.items():
                     acc[k] = acc.get(k, 0) + v
-                    if getattr(l, "timing", False):
+                    if st.get("_timed"):
                         acc_t[k] = acc_t.get(k, 0) + v
-                n_t += 1 if getattr(l, "timing", False) else 0
+                n_t += 1 if st.get("_timed") else 0
                 for k, v in ph.items():
                     phases[k] = phases.get(k, 0.0) + v
         sync_all()
@@ -626,13 +638,16 @@ def main():
     for _ in range(args.warmup):
         run_step()
     # Per-launch kernel timestamps (HIP events on every launch's own stream) cost host CPU -- two events per launch, collected
-    # per proof, and their completion handlers on the runtime's event thread: ~0.5 ms of the ~8 ms of CPU per proof, ~3 % of
-    # `value` on a host-bound box.  They stay on for EVERY lane of the timed region: `roofline` is then computed from all of its
-    # launches, and lanes of unequal cost would only add a tail (every 8th lane timed: 1.72-1.75 G against 1.77-1.83 G with all
-    # of them and 1.86 G with none, same box; ZIGZ_BENCH_TIMING_EVERY=k times every k-th lane).
-    timing_every = max(1, int(os.environ.get("ZIGZ_BENCH_TIMING_EVERY", "1")))
+    # per proof, and their completion handlers on the runtime's event thread: ~0.5 ms of the ~8 ms of CPU per proof on a
+    # host-bound box.  In the timed region every lane therefore carries them on every 4th of its proofs, the lanes taking
+    # turns (lane k on proofs k, k + 4, ...: at any moment a quarter of the proofs in flight are timed, and all lanes cost the
+    # same -- timing every 8th LANE instead made lanes of unequal cost and a tail: 1.72-1.75 G against 1.77-1.83 G with all
+    # lanes timed).  `roofline` is computed from those launches (`timed_launches_sampled`); ZIGZ_BENCH_TIMING_EVERY=1 times
+    # every proof, a large value none.
+    timing_every = max(1, int(os.environ.get("ZIGZ_BENCH_TIMING_EVERY", "4")))
     for k, l in enumerate(lanes):
-        l.timing = k % timing_every == 0
+        l.timing_every = timing_every
+        l.timing = timing_every == 1
         l.ctx.enable_timing(l.timing)
     if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
@@ -753,6 +768,9 @@ def main():
         #   mixed     BASELINE config 4's RV64IM mix (MUL / DIVU / REM / LD / SD / *W in a 12-step loop) at this size
         #   straight  a program that never loops (~2^20 different instructions, each executed once): the content-addressed group
         #             finds nothing and is dropped on the device, its columns are built from the tables / densely
+        # (8 timed steps: the lanes leave the two learning steps in lockstep -- all on the GPU, then all in their transcripts --
+        # and need a step or two to spread out again, which is the state a service runs in)
+        OTHER_STEPS = 8
         def other_trace(make_prog, steps_l):
             for k, l in enumerate(lanes):
                 l.retrace(make_prog(rank * B + k))
@@ -769,12 +787,12 @@ def main():
             return {"dt": dtl, "steps": steps_l, "perms": accl["keccak_permutations"] / (steps_l * B),
                     "rebuilds": (repeated() - r1) / (steps_l * B), "rebuilds_while_learning": (r1 - r0) / (2.0 * B),
                     "trace_steps": float(sum(l.trace.num_steps for l in lanes))}
-        legs["worst"] = guard("register_worst_case", lambda: other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), 3))
-        legs["mixed"] = guard("config4_mixed", lambda: other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), 3))
+        legs["worst"] = guard("register_worst_case", lambda: other_trace(lambda i: programs.register_round_robin((N - 2) // 31 - i), OTHER_STEPS))
+        legs["mixed"] = guard("config4_mixed", lambda: other_trace(lambda i: programs.mixed_loop((N - 8) // 12 - i), OTHER_STEPS))
 
         def leg_straight():  # (last: a context whose group was dropped twice in a row stops trying it for its next 15 jobs)
             base = programs.straight_line_program(1000 + rank, int(0.95 * N))  # one program per rank, a prefix per lane
-            return other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], 3)
+            return other_trace(lambda i: base[:4 * (int(0.95 * N) - (i - rank * B))], OTHER_STEPS)
         legs["straight"] = guard("straight_line", leg_straight)
 
     # ---- N > 1, traces mode: also ONE proof per step sharded by column over the N ranks (the strong-scaling variant of
@@ -835,7 +853,7 @@ def main():
         probe = zigz_amd.Context(local_rank)
         free_now = probe.mem_info()[0]
         probe.close()
-        for nv_s, steps_s in ((16, 10), (22, 3), (24, 2)):
+        for nv_s, steps_s in ((16, 10), (22, 5), (24, 2)):
             if nv_s == nv:
                 continue
             # (the bench trace needs ~0.6 GiB per proof in flight at 2^20 -- 0.9 with the room a first build may ask for --

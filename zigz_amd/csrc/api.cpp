@@ -8,7 +8,9 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
+#include <atomic>
 #include <new>
 #include <thread>
 #include <vector>
@@ -43,6 +45,7 @@ struct zigz_ctx {
     uint64_t h_sums[2048];  // host copy of padded / replicated half sums (dev_half_sums)
     uint8_t *h_roots;  // pinned, ROOTS_MAX_COLS * 32 B: the active commit job's roots travel through this buffer ONLY, so any
                        // other call on the context between zigz_commit_begin* and zigz_commit_roots leaves them intact
+    uint64_t done_seq;  // last sequence number handed to a launch that signals its completion in pinned memory (DoneFlag)
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
     bool fold_eval;           // force eval by v successive binds instead of the one-pass radix form
@@ -196,10 +199,35 @@ extern "C" zigz_status zigz_device_count(int *count) {
     return n > 0 ? ZIGZ_OK : ZIGZ_ERR_NO_DEVICE;
 }
 
+// Waiting host threads sleep (zigz_device_set_blocking_sync): the runtime's own interrupt wait costs 0.2-0.5 ms of CPU per
+// wait once tens of threads of a process wait at the same time (measured with CLOCK_THREAD_CPUTIME_ID around the calls:
+// 0.46 ms in the hipStreamSynchronize of zigz_commit_open_all, 0.15-0.23 ms in the event wait of zigz_commit_roots, with 80
+// proving threads), so the two waits of a proof's commit path poll a completion word that the last kernel stores into pinned
+// memory (DoneFlag, kernels.hpp), sleeping 30 -> 150 us between looks.
+static std::atomic<int> g_sleep_wait{0};
+static bool sleep_wait(const unsigned long long *flag, unsigned long long seq) {
+    long ns = 30000;
+    for (int i = 0; i < 20000; i++) {  // ~3 s, then the caller asks the runtime (which also reports a fault)
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+        timespec ts{0, ns};
+        nanosleep(&ts, nullptr);
+        if (ns < 150000) ns += ns / 2;
+    }
+    return false;
+}
+static DoneFlag done_flag(zigz_ctx *ctx, int which) {  // which: 0 = the roots of a commit job, 1 = its openings
+    DoneFlag d;
+    d.count = ctx->d_flag + 4;
+    d.flag = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8) + which;
+    d.seq = ++ctx->done_seq;
+    return d;
+}
+
 extern "C" zigz_status zigz_device_set_blocking_sync(int device, int on) {
     int n = 0;
     if (zigz_device_count(&n) != ZIGZ_OK || device < 0 || device >= n) return ZIGZ_ERR_NO_DEVICE;
     if (hipSetDevice(device) != hipSuccess) return ZIGZ_ERR_HIP;
+    g_sleep_wait.store(on ? 1 : 0);
     return hipSetDeviceFlags(on ? hipDeviceScheduleBlockingSync : hipDeviceScheduleAuto) == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP;
 }
 
@@ -223,6 +251,8 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
+    if (st == ZIGZ_OK && fail(hipMemset(ctx->d_flag, 0, 64))) st = ZIGZ_ERR_HIP;  // (word 4: the DoneFlag counter, zero between launches)
+    if (st == ZIGZ_OK) memset(ctx->h_roots + ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8, 0, 64);
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 128; i++)
@@ -1673,6 +1703,7 @@ struct zigz_commit_job {
     const uint32_t *d_cols;
     int state;  // 0 begun, 1 roots read, 2 opened
     hipEvent_t built;
+    uint64_t roots_seq;  // the DoneFlag sequence number of the (last) build's summary launch
     TreeRef tree;  // where the digests are (the context's WS_TREE / WS_RUNMETA / WS_CONSMETA workspaces)
     bool whole;    // built with every digest in node-addressed slabs (option run_aware_materialize)
     // the hints the job was begun with (a repeated build -- zigz_commit_roots, when a list ran out of room -- uses the same) and
@@ -1705,10 +1736,12 @@ static zigz_status job_build(zigz_commit_job *job) {
     if (ctx->timing) HIPCHK(ctx, hipEventRecord(ctx->ev[3], ctx->stream));
     // roots + the counters of the build -> contiguous device buffer -> pinned staging (async), then the "built" event
     // zero-copy: the summary kernel stores the roots and counters into the pinned host buffer itself (no copy command)
+    const DoneFlag done = done_flag(ctx, 0);
+    job->roots_seq = done.seq;
     launch_job_summary(job->tree, (unsigned)nv, ctx->h_roots, ncols,
                        ctx->stats.run_aware_columns ? ctx->d_run_count : nullptr,
                        (ctx->stats.small_domain_columns || ctx->build_cons_sd) ? ctx->d_sd_fallbacks : nullptr,
-                       ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream);
+                       ctx->build_cons_hinted ? ctx->d_cons_count : nullptr, ctx->stream, done);
     HIPCHK(ctx, hipGetLastError());
     HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
     // hinted columns take levels 0 and 1 (N + N/2 digests) from the tables (waves that had to hash are counted in
@@ -1793,7 +1826,9 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     if (job->state != 0) return ZIGZ_ERR_BAD_STATE;
     const unsigned long long *h_cnt = (const unsigned long long *)(ctx->h_roots + job->ncols * 32);
     for (int attempt = 0;; attempt++) {
-        HIPCHK(ctx, hipEventSynchronize(job->built));
+        const unsigned long long *h_done = (const unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8);
+        if (!(g_sleep_wait.load() && !ctx->timing && sleep_wait(h_done, job->roots_seq)))
+            HIPCHK(ctx, hipEventSynchronize(job->built));
         // What the lists of the structure-aware levels needed: the context remembers it for its next builds, and a build that
         // ran out of room (or found its group dropped with nowhere to build the columns densely) is repeated here with more.
         // This is the one place where a proof may pay for a second build: the first time a context meets a new kind of trace.
@@ -1893,10 +1928,12 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         CHK(timed_begin(ctx, 4));
         CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val));
         CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
+        const DoneFlag done = done_flag(ctx, 1);
         launch_paths(job->tree, job->tree.npad, (unsigned)nv, job->d_cols, job->col_stride, h_idx, z_sib, z_dirs, z_leaf, ncols,
-                     ctx->stream);
+                     ctx->stream, done);
         HIPCHK(ctx, hipGetLastError());
-        HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+        if (!(g_sleep_wait.load() && !ctx->timing && sleep_wait(done.flag, done.seq)))
+            HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
         if (sib_b) memcpy(siblings, z_sib, sib_b);
         for (size_t c = 0; c < ncols; c++) {
             leaves[c] = z_leaf[c];

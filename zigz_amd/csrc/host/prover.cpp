@@ -3,10 +3,14 @@
 // Merkle/eval/open work runs on the GPU through the zigz_commit_* job of the C ABI and overlaps the
 // sequential O(L) transcript absorption of the Lasso placeholders.
 #include <chrono>
+#include <condition_variable>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <exception>
+#include <functional>
 #include <memory>
+#include <mutex>
 #include <thread>
 
 #include "zigz_host.hpp"
@@ -19,6 +23,66 @@ namespace zigz {
 static double now_s() {
     return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
 }
+
+// One helper thread per proving thread, started on first use and kept: it runs the closure a proof hands it (the early
+// sections of the serialised proof, underneath the transcript), so that a proof does not create and destroy a thread -- with
+// 80 proving threads in one process that is 2 000 clone / 8 MB stack map / unmap cycles per second on the shared address space.
+namespace {
+class Helper {
+  public:
+    void run(std::function<void()> f) {
+        std::unique_lock<std::mutex> lk(m_);
+        if (!th_.joinable()) th_ = std::thread([this] { loop(); });
+        job_ = std::move(f);
+        state_ = 1;
+        err_ = nullptr;
+        cv_.notify_all();
+    }
+    void wait() {  // returns when the closure has run; rethrows what it threw
+        std::unique_lock<std::mutex> lk(m_);
+        cv_.wait(lk, [this] { return state_ == 0; });
+        if (err_) {
+            std::exception_ptr e = err_;
+            err_ = nullptr;
+            std::rethrow_exception(e);
+        }
+    }
+    ~Helper() {
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            quit_ = true;
+        }
+        cv_.notify_all();
+        if (th_.joinable()) th_.join();
+    }
+
+  private:
+    void loop() {
+        std::unique_lock<std::mutex> lk(m_);
+        for (;;) {
+            cv_.wait(lk, [this] { return quit_ || state_ == 1; });
+            if (state_ != 1) return;  // quit
+            std::function<void()> f = std::move(job_);
+            state_ = 2;
+            lk.unlock();
+            std::exception_ptr e;
+            try { f(); } catch (...) { e = std::current_exception(); }
+            lk.lock();
+            err_ = e;
+            state_ = 0;
+            cv_.notify_all();
+        }
+    }
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::function<void()> job_;
+    std::exception_ptr err_;
+    int state_ = 0;  // 0 idle, 1 handed over, 2 running
+    bool quit_ = false;
+    std::thread th_;
+};
+thread_local Helper t_helper;
+}  // namespace
 
 static size_t log2_int_ceil(size_t n) {  // std.math.log2_int_ceil; n may come from an untrusted proof header
     size_t l = 0;
@@ -300,7 +364,7 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     if (initial_regs) proof.public_io.initial_regs = *initial_regs;
     else proof.public_io.initial_regs.reset();
     proof.lookup_placeholders = num_lookups;  // final before the writer thread exists
-    std::thread writer;
+    bool writing = false;
     try {
         t0 = now_s();
         generateSumcheckProof(proof, num_steps, num_vars);  // [4/6]
@@ -311,21 +375,22 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
             if (bytes_out->size() != total) bytes_out->resize(total);
             uint8_t *buf = bytes_out->data();
             const Proof *pp = &proof;
-            writer = std::thread([pp, buf] { BinarySerializer::writePrefix(*pp, buf); });
+            t_helper.run([pp, buf] { BinarySerializer::writePrefix(*pp, buf); });
+            writing = true;
         }
         t0 = now_s();
         generateLassoProofs(proof, num_lookups);            // [5/6]
         timings[2] = now_s() - t0;
         generateCommitments(proof, guard.job, num_vars);    // [6/6]
     } catch (...) {
-        if (writer.joinable()) writer.join();
+        if (writing) try { t_helper.wait(); } catch (...) {}  // (the helper reads `proof`: it must be done before the unwind)
         throw;
     }
     zigz_commit_end(guard.job);
     guard.job = nullptr;
     if (bytes_out) {
         t0 = now_s();
-        writer.join();
+        t_helper.wait();
         BinarySerializer::writeCommitments(proof, bytes_out->data() + BinarySerializer::prefixSize(proof));
         timings[7] = now_s() - t0;
     }

@@ -856,32 +856,50 @@ void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n
 }
 
 // ------------------------------------------------------------------ K7: authentication paths
+// The last workgroup of a launch that wrote its results into pinned host memory says so there: every workgroup makes its
+// stores visible system-wide, then counts itself; the one that completes the count stores the sequence number the host polls
+// for (and leaves the counter at zero for the next launch).  A workgroup here is one wave.
+__device__ __forceinline__ void signal_done(const DoneFlag &done, unsigned n_groups) {
+    if (!done.flag) return;
+    __threadfence_system();
+    if (threadIdx.x == 0) {
+        const unsigned prev = atomicAdd(done.count, 1u);
+        if (prev == n_groups - 1) {
+            *done.count = 0;
+            __hip_atomic_store(done.flag, done.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+}
+
 __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsigned height, const uint32_t *__restrict__ vals,
                                               size_t val_stride, const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
-                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf) {
+                                              uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, DoneFlag done) {
     const size_t col = blockIdx.x;
     const size_t index = idx[col];
     const unsigned l = threadIdx.x;
     if (l == 0) leaf[col] = vals[col * val_stride + index];
-    if (l >= height) return;
-    const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
-    const size_t node = ci ^ 1;    // the sibling: a copy / non-representative resolves to where its digest is stored (node_ptr)
-    bool virt_leaf = l == 0 && col < 64 && ((t.virtual_leaves >> col) & 1);  // leaf digests of this column were never written
-    if (l == 0 && col < 64 && ((t.g_sd_mask >> col) & 1) && *t.g_dropped) virt_leaf = true;
-    Digest d;
-    if (virt_leaf) d = sha3_leaf<false>(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
-    else d = load_digest_at(node_ptr(t, col, l, node));
-    d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
-    ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
-    q[0] = make_ulonglong2(d.w[0], d.w[1]);
-    q[1] = make_ulonglong2(d.w[2], d.w[3]);
-    dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
+    if (l < height) {
+        const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
+        const size_t node = ci ^ 1;    // the sibling: a copy / non-representative resolves to where its digest is stored (node_ptr)
+        bool virt_leaf = l == 0 && col < 64 && ((t.virtual_leaves >> col) & 1);  // leaf digests of this column were never written
+        if (l == 0 && col < 64 && ((t.g_sd_mask >> col) & 1) && *t.g_dropped) virt_leaf = true;
+        Digest d;
+        if (virt_leaf) d = sha3_leaf<false>(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
+        else d = load_digest_at(node_ptr(t, col, l, node));
+        d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
+        q[0] = make_ulonglong2(d.w[0], d.w[1]);
+        q[1] = make_ulonglong2(d.w[2], d.w[3]);
+        dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
+    }
+    signal_done(done, gridDim.x);
 }
 
 void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
-                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s) {
+                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s,
+                  DoneFlag done) {
     hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx, d_sib, d_dirs,
-                       d_leaf);
+                       d_leaf, done);
 }
 TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad) {
     TreeRef t{};
@@ -907,7 +925,7 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
 // roots of a commit job + the build's counters behind them (kernels.hpp: JOB_SUMMARY_WORDS u64; a null pointer reads as 0): ONE
 // buffer, one copy
 __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ out, size_t ncols, const unsigned long long *r_ctr,
-                              const unsigned long long *sd_ctr, const unsigned long long *g_ctr) {
+                              const unsigned long long *sd_ctr, const unsigned long long *g_ctr, DoneFlag done) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (c < ncols) {
         const Digest d = canonical_digest(load_digest_at(node_ptr(t, c, height, 0)));  // tree form -> SHA3 bytes
@@ -937,6 +955,7 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
             }
         cnt[8 + threadIdx.x] = mx;
     }
+    signal_done(done, gridDim.x);
 }
 __global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g) {
     const unsigned i = blockIdx.x * TPB + threadIdx.x;
@@ -950,9 +969,9 @@ void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_
     hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTRS + TPB - 1) / TPB), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr);
 }
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
-                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s) {
+                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s, DoneFlag done) {
     hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr, d_sd_ctr,
-                       d_g_ctr);
+                       d_g_ctr, done);
 }
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s) {

@@ -265,8 +265,17 @@ void launch_keccak_small_l01(const uint32_t *d_vals, size_t val_stride, size_t n
 bool keccak_level_is_wide(size_t n_out, size_t ncols);
 // K7: authentication paths.  For column c: index d_idx[c]; siblings -> d_sib[c][l][32], dirs -> d_dirs[c][l],
 // leaf value -> d_leaf[c].
+// Completion flag of a launch whose results go straight into pinned host memory: `count` is a device word that is zero
+// between launches, `flag` a pinned host word that receives `seq` once every workgroup's stores are visible to the host
+// (flag == nullptr: no signalling).  The host then waits by polling `flag` with short sleeps instead of a runtime wait.
+struct DoneFlag {
+    unsigned *count = nullptr;
+    unsigned long long *flag = nullptr;
+    unsigned long long seq = 0;
+};
 void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
-                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s);
+                  const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s,
+                  DoneFlag done = DoneFlag());
 // a TreeRef for plain node-addressed trees (column c -> slab c)
 TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad);
 // copies node `node` of every column's tree into d_out[c][32]
@@ -282,7 +291,8 @@ constexpr unsigned JOB_SUMMARY_WORDS = 8 + 2 * RUN_MAX_LEVELS;
 // not used by this build), zeroed by one launch
 void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s);
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
-                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s);
+                        const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s,
+                        DoneFlag done = DoneFlag());
 // gather element 0 of each column of a strided table
 void launch_gather_first(const uint32_t *d_in, size_t stride, uint32_t *d_out, size_t ncols, hipStream_t s);
 // K9: Lasso fingerprints (src/lookups/lasso_prover.zig:208-239): rows x width canonical u32 -> u32
