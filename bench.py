@@ -596,9 +596,22 @@ def main():
                 torch.cuda.synchronize()
             dist.barrier()
 
+    def gather(futs):
+        """Results of all futures; if some failed, the first failure -- but only after EVERY lane has finished, so that what
+        handles it (guard) finds no lane in the middle of a proof."""
+        out, first = [], None
+        for f in futs:
+            try:
+                out.append(f.result())
+            except BaseException as e:  # noqa: BLE001
+                first = first or e
+        if first is not None:
+            raise first
+        return out
+
     def run_step(fn=Lane.prove, which=None):
         ls = lanes if which is None else which
-        return [f.result() for f in [pool.submit(fn, l) for l in ls]]
+        return gather([pool.submit(fn, l) for l in ls])
 
     def timed(steps, fn=Lane.prove, which=None):
         """Exactly `steps` steps (= steps x len(lanes) proofs) between barrier + synchronize brackets.  Every lane proves its
@@ -618,9 +631,8 @@ def main():
         sync_all()
         c0 = time.process_time()
         t0 = time.perf_counter()
-        futs = [pool.submit(lane_loop, l) for l in ls]
-        for l, f in zip(ls, futs):
-            for st, ph in f.result():
+        for l, res in zip(ls, gather([pool.submit(lane_loop, l) for l in ls])):
+            for st, ph in res:
                 for k, v in st.items():
                     acc[k] = acc.get(k, 0) + v
                     if st.get("_timed"):
@@ -681,13 +693,27 @@ def main():
     self_check = {}
 
     def guard(name, fn):
+        t_leg = time.perf_counter()
         try:
-            return fn()
+            r = fn()
+            if rank == 0:  # (one progress line per leg on stderr: a long default run is not silent)
+                try:
+                    free_gib = lanes[0].ctx.mem_info()[0] / 2.0**30 if lanes and lanes[0].ctx is not None else float("nan")
+                except Exception:
+                    free_gib = float("nan")
+                sys.stderr.write("bench.py: leg %s: %.1f s, %.0f GiB of HBM free\n" % (name, time.perf_counter() - t_leg, free_gib))
+                sys.stderr.flush()
+            return r
         except SystemExit:
             raise
         except Exception as e:  # noqa: BLE001
             leg_errors[name] = repr(e)[:200]
             sys.stderr.write("bench.py: leg %s failed: %r\n" % (name, e))
+            try:  # what the backend recorded (the failing HIP call, if any)
+                msgs = {zigz_amd._ffi.lib.zigz_last_error(l.ctx.h).decode(errors="replace") for l in lanes if l.ctx is not None}
+                sys.stderr.write("bench.py:   backend: %s\n" % "; ".join(sorted(m for m in msgs if m))[:600])
+            except Exception:
+                pass
             try:
                 for l in lanes:
                     l.ctx.synchronize()
@@ -745,6 +771,8 @@ def main():
             def leg_variant(mode=mode):
                 for l in vl:  # (workspaces only grow: what one build kept must not add to what the next one needs)
                     l.ctx.release_workspaces()
+                if rank == 0:
+                    sys.stderr.write("bench.py: %s on %d lanes, %.0f GiB of HBM free\n" % (mode, len(vl), vl[0].ctx.mem_info()[0] / 2.0**30))
                 set_merkle_mode(mode)
                 run_step(Lane.prove_and_digest, which=vl)
                 # ... must be byte-identical under every other build (dense hashes every node of every tree)

@@ -45,6 +45,7 @@ struct zigz_ctx {
     uint64_t h_sums[2048];  // host copy of padded / replicated half sums (dev_half_sums)
     uint8_t *h_roots;  // pinned, ROOTS_MAX_COLS * 32 B: the active commit job's roots travel through this buffer ONLY, so any
                        // other call on the context between zigz_commit_begin* and zigz_commit_roots leaves them intact
+    bool events_recorded;  // timing mode has been on: the context's events may still refer to launches (and so to their buffers)
     uint64_t done_seq;  // last sequence number handed to a launch that signals its completion in pinned memory (DoneFlag)
     bool timing;
     bool per_round_sumcheck;  // force the one-launch-per-round form (tests, A/B timing)
@@ -148,7 +149,13 @@ static zigz_status ws_get(zigz_ctx *ctx, int slot, size_t bytes, void **out) {
         if (e != hipSuccess) {
             (void)hipGetLastError();
             want = (bytes + 255) & ~(size_t)255;
-            HIPCHK(ctx, hipMalloc(&ctx->ws[slot], want));
+            e = hipMalloc(&ctx->ws[slot], want);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();  // (not left behind for the next launch check on this thread to find)
+                ctx->ws[slot] = nullptr;
+                set_err(ctx, "workspace %d: hipMalloc(%zu bytes) failed: %s", slot, want, hipGetErrorString(e));
+                return e == hipErrorOutOfMemory ? ZIGZ_ERR_OUT_OF_MEMORY : ZIGZ_ERR_HIP;
+            }
         }
         ctx->ws_bytes[slot] = want;
     }
@@ -251,7 +258,10 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
-    if (st == ZIGZ_OK && fail(hipMemset(ctx->d_flag, 0, 64))) st = ZIGZ_ERR_HIP;  // (word 4: the DoneFlag counter, zero between launches)
+    // (word 4 of d_flag: the DoneFlag counter, zero between launches.  Zeroed on the context's own stream: a plain hipMemset
+    // would bring the legacy null stream into the process, and with it implicit synchronisation against every other stream)
+    if (st == ZIGZ_OK && (fail(hipMemsetAsync(ctx->d_flag, 0, 64, ctx->own_stream)) || fail(hipStreamSynchronize(ctx->own_stream))))
+        st = ZIGZ_ERR_HIP;
     if (st == ZIGZ_OK) memset(ctx->h_roots + ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8, 0, 64);
     for (int i = 0; st == ZIGZ_OK && i < 6; i++)
         if (fail(hipEventCreate(&ctx->ev[i]))) st = ZIGZ_ERR_HIP;
@@ -324,6 +334,29 @@ extern "C" zigz_status zigz_ctx_release_workspaces(zigz_ctx *ctx) {
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;  // the job's trees live in them
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    // An event recorded around a launch (timing mode) keeps that launch's command alive, and the command the buffers it used:
+    // hipFree of such a buffer returns, but the memory does not come back until the event is recorded again or destroyed
+    // (measured: a context whose last timed proof used a 3 GiB tree kept those 3 GiB through this call).  So the events go too.
+    if (ctx->events_recorded) {
+        for (int i = 0; i < 6; i++) {
+            (void)hipEventDestroy(ctx->ev[i]);
+            ctx->ev[i] = nullptr;
+            HIPCHK(ctx, hipEventCreate(&ctx->ev[i]));
+        }
+        for (int i = 0; i < 128; i++) {
+            (void)hipEventDestroy(ctx->pool[i]);
+            ctx->pool[i] = nullptr;
+            HIPCHK(ctx, hipEventCreate(&ctx->pool[i]));
+        }
+        for (int i = 0; i < 2 * KEV_MAX; i++) {
+            (void)hipEventDestroy(ctx->kev[i]);
+            ctx->kev[i] = nullptr;
+            HIPCHK(ctx, hipEventCreate(&ctx->kev[i]));
+        }
+        ctx->events_recorded = ctx->timing;
+        ctx->pool_used = 0;
+        ctx->kev_n = 0;
+    }
     for (int i = 0; i < WS_SLOTS; i++)
         if (ctx->ws[i]) {
             (void)hipFree(ctx->ws[i]);
@@ -352,6 +385,7 @@ extern "C" zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable) {
     ZIGZ_ENTER(ctx);
     if (!ctx) return ZIGZ_ERR_INVALID_ARGUMENT;
     ctx->timing = enable != 0;
+    if (enable) ctx->events_recorded = true;
     return ZIGZ_OK;
 }
 extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int64_t value) {
