@@ -73,6 +73,20 @@ def test_product_never_imports_oracle():
                     assert "oracle_lib" not in txt and "zigz_oracle" not in txt and "orc_" not in txt, os.path.join(d, f)
 
 
+def test_product_stays_off_the_null_stream():
+    """Every copy, fill and launch of the backend goes to a stream of its own.  One synchronous hipMemset (= the legacy null
+    stream) at context creation was enough to make a later hipFree wait for ever in a process with 80 proving threads
+    (round 3): the calls that imply the null stream do not appear in the sources."""
+    import re
+    bad = re.compile(r"\bhip(Memset|Memcpy|MemcpyHtoD|MemcpyDtoH|MemcpyDtoD|DeviceSynchronize|Memset2D|Memcpy2D)\s*\(")
+    for d, _, fs in os.walk(os.path.join(ROOT, "zigz_amd", "csrc")):
+        for f in fs:
+            if f.endswith((".cpp", ".hpp", ".hip")):
+                for n, line in enumerate(open(os.path.join(d, f), errors="replace"), 1):
+                    code = line.split("//")[0]
+                    assert not bad.search(code), "%s:%d: %s" % (os.path.join(d, f), n, line.strip())
+
+
 def test_isa_counts_match_the_built_kernels():
     """bench.py prices Keccak permutations/s with the VALU instruction count per hash read from
     profiles/isa_counts.json: re-derive it from the gfx950 assembly of the current kernels.hip."""

@@ -1168,3 +1168,51 @@ def test_commit_begin_does_not_wait_for_the_device(ctx):
         for o in ("small_domain_mask", "run_aware_mask", "cons_group_mask"):
             ctx.set_option(o, 0)
         ctx.dev_free(d)
+
+
+@pytest.mark.gpu
+def test_commit_job_with_sleeping_waits(ctx):
+    """zigz_device_set_blocking_sync(on): the two waits of a commit job poll the completion word the last kernel stores in pinned
+    memory (DoneFlag, csrc/kernels.hpp) instead of asking the runtime.  Same roots, values, leaves, paths as with the runtime's
+    waits, job after job on one context (the word carries a sequence number), with and without timing mode (which keeps the
+    runtime's waits), for two shapes."""
+    import numpy as np
+    import zigz_amd
+    rng = np.random.default_rng(77)
+    lib = zigz_amd._ffi.lib
+
+    def run(c, cols, pts):
+        out = []
+        for _ in range(3):
+            job = zigz_amd.CommitJob(c, cols)
+            roots = job.roots()
+            opened = job.open_all(pts)
+            job.end()
+            out.append((bytes(roots), [np.asarray(opened[k]).tobytes() for k in sorted(opened)]))
+        assert out[0] == out[1] == out[2]
+        return out[0]
+
+    for ncols, nv in ((43, 15), (5, 9)):
+        cols = rng.integers(0, 2013265921, size=(ncols, 1 << nv), dtype=np.uint64)
+        cols[3 % ncols] = 7  # (a constant column and a piecewise-constant one for the run-aware levels)
+        cols[2 % ncols] = np.repeat(rng.integers(0, 2013265921, size=(1 << nv) // 64, dtype=np.uint64), 64)
+        pts = rng.integers(0, 2013265921, size=(ncols, nv), dtype=np.uint64)
+        ctx.set_option("run_aware_mask", 0b1100 if nv >= 15 else 0)
+        try:
+            want = run(ctx, cols, pts)
+            lib.zigz_device_set_blocking_sync(0, 1)  # (the device flag itself may be refused on an active device: the waits switch regardless)
+            try:
+                c2 = zigz_amd.Context(0)
+                try:
+                    c2.set_option("run_aware_mask", 0b1100 if nv >= 15 else 0)
+                    assert run(c2, cols, pts) == want
+                    c2.enable_timing(True)
+                    assert run(c2, cols, pts) == want
+                    c2.enable_timing(False)
+                    assert run(c2, cols, pts) == want
+                finally:
+                    c2.close()
+            finally:
+                lib.zigz_device_set_blocking_sync(0, 0)
+        finally:
+            ctx.set_option("run_aware_mask", 0)
