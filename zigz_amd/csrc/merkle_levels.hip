@@ -559,13 +559,25 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
         if (lane == RUN_SUBS - 1) dst[RUN_SUBS] = incl;
     }
     __syncthreads();
-    const size_t n_L = b.npad >> L;
-    const size_t cR = s_r[RUN_SUBS], cG = s_g[RUN_SUBS] * b.gcols.n, cD = (dropped && b.g_has_slabs) ? (size_t)gdense.n * n_L : 0;
+    // Everything that depends on the level only -- list lengths (out of LDS, i.e. in vector registers), capacities and bases
+    // (indexed by L in the kernel arguments), the R metadata of the children's level -- as wave-uniform scalars, fetched once:
+    // what the loop keeps in vector registers through a permutation is its index and where the result goes, nothing else.
+    // No 64-bit division inside the loop either (its magic numbers are loop invariants in vector registers too).
+    const size_t n_L = uniform64(b.npad >> L);
+    const unsigned n_L_log2 = (unsigned)__builtin_ctzll(n_L);  // (a power of two)
+    const unsigned gn = b.gcols.n;
+    const size_t cR = uniform64(s_r[RUN_SUBS]), cG = uniform64(s_g[RUN_SUBS]) * gn,
+                 cD = (dropped && b.g_has_slabs) ? (size_t)gdense.n * n_L : 0;
     if (blockIdx.x == 0 && threadIdx.x == 0) {  // nodes hashed by the whole build
         if (cR) atomicAdd(&b.r_ctr[0], (unsigned long long)cR);
         if (cG) atomicAdd(&b.g_ctr[0], (unsigned long long)cG);
     }
     const size_t total = cR + cG + cD;
+    const RLevel rl = r_level(b.t, L, true), rc = r_level(b.t, LEAF ? 0 : L - 1, true);
+    const size_t r_cap = uniform64(b.t.r_lists.cap[L]), g_cap = uniform64(b.t.g_lists.cap[L]);
+    const size_t g_base = uniform64(b.t.g_lists.base[L]), g_base_c = uniform64(b.t.g_lists.base[LEAF ? 0 : L - 1]);
+    const size_t g_rep_c = slab_level_offset(b.npad, LEAF ? 0 : L - 1);
+    const unsigned g_magic = gn ? (unsigned)(0x100000000ull / gn) : 0;  // floor(2^32 / group size)
 #pragma unroll 1
     for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * TPB) {
         size_t col, k;
@@ -576,37 +588,43 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
 #pragma unroll
             for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
                 if (s_r[sub + step] <= e) sub += step;
-            const size_t slot = (size_t)sub * b.t.r_lists.cap[L] + (e - s_r[sub]);
-            const uint32_t ent = b.r_list[b.t.r_lists.base[L] + slot];
+            const size_t slot = (size_t)sub * r_cap + (e - s_r[sub]);
+            const uint32_t ent = b.r_list[rl.list_base + slot];
             const unsigned y = ent >> RUN_NODE_BITS;
             col = b.rcols.c[y];
             k = ent & ((1u << RUN_NODE_BITS) - 1);
-            out = r_slot_ptr(b.t, L, slot);
+            out = r_slot_ptr(b.t, rl, slot);
             if (!LEAF) {
                 size_t c0, c1;
-                r_slot_pair(b.t, y, L - 1, 2 * k, &c0, &c1);
-                in0 = r_slot_ptr(b.t, L - 1, c0);
-                in1 = r_slot_ptr(b.t, L - 1, c1);
+                r_slot_pair(b.t, rc, y, 2 * k, &c0, &c1);
+                in0 = r_slot_ptr(b.t, rc, c0);
+                in1 = r_slot_ptr(b.t, rc, c1);
             }
         } else if (e < cR + cG) {
-            const size_t t = e - cR, ei = t / b.gcols.n;
-            const unsigned j = (unsigned)(t % b.gcols.n);
+            // (entry, column) = divmod(t, group size): t < 2^32 (launch_level_hash), so the multiply-high with
+            // floor(2^32 / n) is the quotient or one short of it
+            const unsigned t32 = (unsigned)(e - cR);
+            unsigned ei = __umulhi(t32, g_magic), j = t32 - ei * gn;
+            if (j >= gn) {
+                ei++;
+                j -= gn;
+            }
             col = b.gcols.c[j];
             unsigned sub = 0;
 #pragma unroll
             for (unsigned step = RUN_SUBS / 2; step; step >>= 1)
                 if (s_g[sub + step] <= ei) sub += step;
-            const size_t slot = (size_t)sub * b.t.g_lists.cap[L] + (ei - s_g[sub]);
-            k = b.g_list[b.t.g_lists.base[L] + slot];
-            out = g_slot_ptr(b.t, L, slot, j);
+            const size_t slot = (size_t)sub * g_cap + (ei - s_g[sub]);
+            k = b.g_list[g_base + slot];
+            out = b.t.g_store + ((g_base + slot) * gn + j) * 32;
             if (!LEAF) {
-                const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + slab_level_offset(b.npad, L - 1) + 2 * k);
-                in0 = g_slot_ptr(b.t, L - 1, p.x, j);
-                in1 = g_slot_ptr(b.t, L - 1, p.y, j);
+                const uint2 p = *reinterpret_cast<const uint2 *>(b.g_rep + g_rep_c + 2 * k);
+                in0 = b.t.g_store + ((g_base_c + p.x) * gn + j) * 32;
+                in1 = b.t.g_store + ((g_base_c + p.y) * gn + j) * 32;
             }
         } else {
             const size_t t = e - cR - cG;
-            col = gdense.c[t / n_L];
+            col = gdense.c[t >> n_L_log2];
             k = t & (n_L - 1);
             out = slab_ptr(b.t, col, L, k);
             if (!LEAF) {

@@ -48,11 +48,26 @@ __device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, c
 
 // ---- where a digest lives (kernels.hpp: TreeRef)
 __device__ __host__ __forceinline__ size_t slab_level_offset(size_t npad, unsigned l) { return 2 * npad - 2 * (npad >> l); }
+// What r_slot needs to know about level l of the R columns -- all of it the same for every thread of a launch.  A kernel that
+// resolves many nodes of ONE level (k_level_hash) builds it once with `uniform` = true: the values then sit in scalar
+// registers instead of being recomputed, or kept in vector registers, by every lane through every permutation.
+struct RLevel {
+    size_t n_l, tile, meta_base, ubase_off, list_base;
+};
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {  // a value every lane holds -> scalar registers
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ RLevel r_level(const TreeRef &t, unsigned l, bool uniform = false) {
+    RLevel v{t.npad >> l, run_tile_nodes(t.npad, l), run_meta_base(t.npad, t.ncols, l), t.ubase_off[l], t.r_lists.base[l]};
+    if (uniform) v = RLevel{uniform64(v.n_l), uniform64(v.tile), uniform64(v.meta_base), uniform64(v.ubase_off), uniform64(v.list_base)};
+    return v;
+}
 // the list slot (within level l) that holds the digest of node k of hinted (R) column y: its own if it was hashed, else its
 // leader's -- the nearest hashed node before it in its tile (kernels.hpp: run_tile_nodes)
-__device__ __forceinline__ size_t r_slot(const TreeRef &t, unsigned y, unsigned l, size_t k) {
-    const size_t n_l = t.npad >> l, tile = run_tile_nodes(t.npad, l);
-    const size_t e0 = run_meta_base(t.npad, t.ncols, l) + ((size_t)y * n_l) / 64;
+__device__ __forceinline__ size_t r_slot(const TreeRef &t, const RLevel &v, unsigned y, size_t k) {
+    const size_t n_l = v.n_l, tile = v.tile;
+    const size_t e0 = v.meta_base + ((size_t)y * n_l) / 64;
     size_t e = e0 + k / 64;
     const unsigned q = (unsigned)(k & 63);
     unsigned long long m = t.bitmap[e] & (q == 63 ? ~0ull : ((2ull << q) - 1));  // hashed nodes of the chunk at or before k
@@ -66,17 +81,18 @@ __device__ __forceinline__ size_t r_slot(const TreeRef &t, unsigned y, unsigned 
         m = t.bitmap[e] & ((1ull << (j & 63)) - 1);
     }
     const size_t u = (size_t)y * (n_l / tile) + j / tile;
-    return (size_t)t.ubase[t.ubase_off[l] + u] + t.woff[e] + (unsigned)__builtin_popcountll(m);
+    return (size_t)t.ubase[v.ubase_off + u] + t.woff[e] + (unsigned)__builtin_popcountll(m);
 }
+__device__ __forceinline__ size_t r_slot(const TreeRef &t, unsigned y, unsigned l, size_t k) { return r_slot(t, r_level(t, l), y, k); }
 // the slots of the two children 2 k2, 2 k2 + 1 of a node: they share a 64-node chunk, and list order is node order, so the
 // odd child's digest sits right behind the even child's if the odd child was hashed itself -- and in the SAME slot if it is a
 // copy (its leader is the even child or the even child's leader).  One leader search instead of two.
-__device__ __forceinline__ void r_slot_pair(const TreeRef &t, unsigned y, unsigned l, size_t k_even, size_t *s0, size_t *s1) {
-    const size_t n_l = t.npad >> l;
-    const unsigned long long w = t.bitmap[run_meta_base(t.npad, t.ncols, l) + ((size_t)y * n_l + k_even) / 64];
-    *s0 = r_slot(t, y, l, k_even);
+__device__ __forceinline__ void r_slot_pair(const TreeRef &t, const RLevel &v, unsigned y, size_t k_even, size_t *s0, size_t *s1) {
+    const unsigned long long w = t.bitmap[v.meta_base + ((size_t)y * v.n_l + k_even) / 64];
+    *s0 = r_slot(t, v, y, k_even);
     *s1 = *s0 + (unsigned)((w >> ((k_even & 63) + 1)) & 1);
 }
+__device__ __forceinline__ uint8_t *r_slot_ptr(const TreeRef &t, const RLevel &v, size_t slot) { return t.r_store + (v.list_base + slot) * 32; }
 __device__ __forceinline__ uint8_t *r_slot_ptr(const TreeRef &t, unsigned l, size_t slot) {
     return t.r_store + (t.r_lists.base[l] + slot) * 32;
 }
