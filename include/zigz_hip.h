@@ -402,6 +402,10 @@ typedef struct zigz_kernel_stats {
     /* builds that zigz_commit_roots had to repeat on this context because a list of the structure-aware levels ran out of the
      * room learnt from earlier builds (or the group was dropped and its columns had no slabs): a running count */
     uint64_t rebuilds;
+    /* hinted (run-aware) columns of the last commit job whose N values are all equal -- established from the values by the
+     * structure pass -- and which zigz_commit_open_all therefore did not read again: the multilinear extension of a constant is
+     * that constant */
+    uint64_t eval_constant_columns;
 } zigz_kernel_stats;
 /* One hot kernel, `iters` (<= 64) launches on a synthetic device-resident table of ncols columns x 2^nv elements, each
  * launch timed by its own begin / end timestamps.  kernel: "k_bind_vec" (partialEval, multilinear.zig:154-180, 6 B per

@@ -1216,3 +1216,46 @@ def test_commit_job_with_sleeping_waits(ctx):
                 lib.zigz_device_set_blocking_sync(0, 0)
         finally:
             ctx.set_option("run_aware_mask", 0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv", [15, 17])
+def test_eval_leaves_out_constant_columns_only(ctx, nv):
+    """zigz_commit_open_all does not read a hinted column again that the run-aware structure pass of the same job found
+    constant (EvalSkip, csrc/kernels.hpp: the extension of a constant is that constant).  Every value must still be the
+    oracle's eval -- for constant columns, for columns that are constant except in ONE place (the last leaf, the first leaf,
+    the first leaf of a later 4096-leaf segment, the leaf before it, one leaf in the middle of a chunk) and for columns the hint
+    does not cover -- and the count of skipped columns must be exactly the constant ones under the hint."""
+    import zigz_amd
+    N = 1 << nv
+    cols = rnd(0xE7A1 + nv, 43 * N).reshape(43, N).copy()
+    const = {2: 0, 3: 5, 4: 2013265920, 20: 77}
+    for c, v in const.items():
+        cols[c, :] = v
+    near = {5: N - 1, 6: 0, 7: 4096 * 3, 8: 4096 * 3 - 1, 9: 64 * 100 + 17, 10: 4096}
+    for c, i in near.items():
+        cols[c, :] = 9
+        cols[c, i] = 10
+    cols[11, :] = 4
+    cols[11, N // 2:] = 6            # two runs
+    cols[40, :] = 0                  # a memory column without accesses (hinted)
+    cols[0, :] = 3                   # constant, but NOT hinted: read like any other column
+    mask = (0x7fffffff << 2) | (3 << 40)
+    pts = rnd(0xE7A2 + nv, 43 * nv).reshape(43, nv)
+    ctx.set_option("run_aware_mask", mask)
+    try:
+        for it in range(2):
+            job = zigz_amd.CommitJob(ctx, cols=cols)
+            job.roots()
+            got = job.open_all(pts)
+            job.end()
+            st = ctx.stats()
+            assert st["run_aware_columns"] == 33
+            assert st["eval_constant_columns"] == len(const) + 1, st["eval_constant_columns"]  # + column 40
+            for c in range(43):
+                want = O.mle_eval(P, cols[c], pts[c])
+                assert int(got["values"][c]) == want, (c, int(got["values"][c]), want)
+            cols[3, 12345 % N] += 1      # second round: a constant column stops being one
+            const.pop(3, None)
+    finally:
+        ctx.set_option("run_aware_mask", 0)

@@ -34,7 +34,8 @@ class KernelStats(C.Structure):
                 ("small_domain_columns", C.c_uint64), ("small_domain_us", C.c_double),
                 ("small_domain_fallback_waves", C.c_uint64),
                 ("structure_us", C.c_double), ("list_hash_us", C.c_double), ("list_hash_perms", C.c_uint64),
-                ("top_us", C.c_double), ("top_perms", C.c_uint64), ("rebuilds", C.c_uint64)]
+                ("top_us", C.c_double), ("top_perms", C.c_uint64), ("rebuilds", C.c_uint64),
+                ("eval_constant_columns", C.c_uint64)]
 
 
 class BenchResult(C.Structure):

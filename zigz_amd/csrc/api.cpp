@@ -254,7 +254,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     auto fail = [&](hipError_t e) { return e != hipSuccess; };
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
-        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTRS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_count, RUN_CTRS * 8)) ||
+        fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTR_WORDS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_count, RUN_CTR_WORDS * 8)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
@@ -694,10 +694,15 @@ extern "C" zigz_status zigz_dev_mle_bind_sums(zigz_ctx *ctx, const uint32_t *d_i
 // leaving 1024 elements per column that a weighted dot product with the eq weights of point[9..0] finishes.
 // HBM traffic 4*N B per column instead of 12*N for v successive binds.  Exact arithmetic => same value.
 static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t col_stride, size_t ncols, size_t nv,
-                                  const uint64_t *points, uint32_t *d_vals) {
+                                  const uint64_t *points, uint32_t *d_vals, const EvalSkip *skip = nullptr) {
     const size_t N = (size_t)1 << nv;
     const unsigned k2 = 10, k1 = (unsigned)nv - k2;
-    const size_t m = (size_t)1 << k2, nb = (size_t)1 << k1, groups = radix_fold_groups(nb);
+    const size_t m = (size_t)1 << k2, nb = (size_t)1 << k1;
+    // a thread folds rloops x 16 rows: fewer when most columns are skipped, so that the launch still fills the chip (13 of 43
+    // columns x 16 groups are 208 workgroups on 256 CUs)
+    const size_t active = skip ? ncols - (size_t)ctx->stats.eval_constant_columns : ncols;
+    const int rloops = active * 2 <= ncols && nb % 16 == 0 ? (active * 4 <= ncols + 3 ? 1 : 2) : 4;
+    const size_t groups = radix_fold_groups(nb, rloops);
     if (nv * ncols * 4 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
     uint32_t *rt = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);  // [col][j], j-th bound variable = point[v-1-j]
     for (size_t c = 0; c < ncols; c++)
@@ -720,13 +725,14 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
     const bool rec = ctx->timing;
     // the one pass over the data; in timing mode the events carry the dispatch's own begin/end timestamps
     launch_radix_fold(d_cols, col_stride, m, nb, d_w1, nb, d_part, groups * m, ncols, ctx->stream, rec ? ctx->pool[0] : nullptr,
-                      rec ? ctx->pool[1] : nullptr);
+                      rec ? ctx->pool[1] : nullptr, skip, rloops);
     if (rec) {
         ctx->pool_used = 1;
-        ctx->pool_bytes = (uint64_t)ncols * (N * 4 + groups * m * 8);  // one read of the tables + the partial sums
+        // one read of the tables (those of the columns that are not skipped) + the partial sums
+        ctx->pool_bytes = (uint64_t)(ncols - (skip ? ctx->stats.eval_constant_columns : 0)) * (N * 4 + groups * m * 8);
     }
-    launch_radix_finalize(d_part, groups * m, groups, d_t1, m, m, 0, nullptr, ncols, ctx->stream);
-    launch_weighted_dot(d_t1, m, d_w2, m, m, d_vals, ncols, ctx->stream);
+    launch_radix_finalize(d_part, groups * m, groups, d_t1, m, m, 0, nullptr, ncols, ctx->stream, skip);
+    launch_weighted_dot(d_t1, m, d_w2, m, m, d_vals, ncols, ctx->stream, skip, d_cols, col_stride);
     HIPCHK(ctx, hipGetLastError());
     return ZIGZ_OK;
 }
@@ -735,7 +741,7 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
 // point reversed (exact arithmetic => the same canonical value as the reference's O(v*2^v) loop).
 // Batched over `ncols` columns, column c using point row c.  Result words land in d_vals[ncols].
 static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t col_stride, size_t ncols, size_t nv,
-                                  const uint64_t *points /*host, ncols*nv*/, uint32_t *d_vals) {
+                                  const uint64_t *points /*host, ncols*nv*/, uint32_t *d_vals, const EvalSkip *skip = nullptr) {
     const size_t N = (size_t)1 << nv;
     if (nv == 0) {
         launch_gather_first(d_cols, col_stride, d_vals, ncols, ctx->stream);
@@ -743,7 +749,7 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
         return ZIGZ_OK;
     }
     if (nv >= 14 && nv <= 24 && col_stride % 4 == 0 && aligned16(d_cols) && !ctx->fold_eval)
-        return dev_eval_radix(ctx, d_cols, col_stride, ncols, nv, points, d_vals);
+        return dev_eval_radix(ctx, d_cols, col_stride, ncols, nv, points, d_vals, skip);
     // r table in Montgomery form, [round][col], staged in the upper half of the pinned buffer so the
     // asynchronous H2D copy never reads freed host memory
     if (nv * ncols * 4 > PIN_WORDS * 8 / 2) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -1737,6 +1743,7 @@ struct zigz_commit_job {
     const uint32_t *d_cols;
     int state;  // 0 begun, 1 roots read, 2 opened
     hipEvent_t built;
+    uint64_t const_cols; // hinted columns the structure pass found constant (summary word 7): not read by the eval
     uint64_t roots_seq;  // the DoneFlag sequence number of the (last) build's summary launch
     TreeRef tree;  // where the digests are (the context's WS_TREE / WS_RUNMETA / WS_CONSMETA workspaces)
     bool whole;    // built with every digest in node-addressed slabs (option run_aware_materialize)
@@ -1902,6 +1909,8 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
     ctx->stats.small_domain_columns = job->sd_cols;
     ctx->stats.keccak_permutations = job->perms0;
     ctx->stats.run_aware_hashed = job->run_cols ? h_cnt[0] : 0;
+    job->const_cols = job->run_cols ? h_cnt[7] : 0;
+    ctx->stats.eval_constant_columns = job->const_cols;
     ctx->stats.keccak_permutations -= ctx->stats.run_aware_dense_nodes - ctx->stats.run_aware_hashed;
     ctx->stats.small_domain_fallback_waves = job->sd_cols ? h_cnt[1] : 0;
     ctx->stats.list_hash_perms = ctx->stats.run_aware_hashed;
@@ -1959,8 +1968,15 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
             h_idx[c] = nv == 0 ? 0 : points[c * nv] % ((uint64_t)1 << nv);  // pointToIndex
             indices[c] = h_idx[c];
         }
+        // columns the run-aware structure pass of THIS job found constant are not read again (EvalSkip, kernels.hpp): of the 43
+        // witness columns of a program that uses a handful of registers, most
+        EvalSkip skip;
+        if (job->tree.lists && job->run_cols && job->col_stride >= job->N) {
+            skip.changed = ctx->d_run_count + RUN_CHANGED;
+            memcpy(skip.y_of_col, job->tree.y_of_col, sizeof(skip.y_of_col));
+        }
         CHK(timed_begin(ctx, 4));
-        CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val));
+        CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val, skip.changed ? &skip : nullptr));
         CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
         const DoneFlag done = done_flag(ctx, 1);
         launch_paths(job->tree, job->tree.npad, (unsigned)nv, job->d_cols, job->col_stride, h_idx, z_sib, z_dirs, z_leaf, ncols,

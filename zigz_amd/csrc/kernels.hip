@@ -267,20 +267,27 @@ constexpr int RLOOPS = 4;  // RB-chunks per thread: accumulators stay in registe
 // FULL: nb is a multiple of RB*RLOOPS (every launch but the late, small sumcheck stages): no row needs a bounds test
 // and the RB loads of a chunk are issued back to back.  Otherwise rows past nb are clamped to a valid row and given
 // weight 0 (per-row branches would make the compiler serialise the loads behind s_waitcnt vmcnt(0)).
+__device__ __forceinline__ bool eval_skips(const EvalSkip &skip, size_t col) {
+    if (!skip.changed || col >= 64) return false;
+    const int y = skip.y_of_col[col];
+    return y >= 0 && skip.changed[y] == 0;
+}
 template <bool FULL>
 __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t in_stride, size_t m, size_t nb,
                                                     const uint32_t *__restrict__ w_m, size_t w_stride,
-                                                    unsigned long long *__restrict__ part, size_t part_col_stride) {
+                                                    unsigned long long *__restrict__ part, size_t part_col_stride, EvalSkip skip,
+                                                    int rloops) {
     const size_t q = (size_t)blockIdx.x * TPB + threadIdx.x;  // uint4 index of the outputs
     if (q * 4 >= m) return;
     const size_t col = blockIdx.z;
+    if (eval_skips(skip, col)) return;  // a constant column: k_weighted_dot writes its value, its partial sums are never used
     const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride) + q;
     const uint32_t *w = w_m + col * w_stride;
     const size_t mq = m / 4;
     unsigned long long lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
 #pragma unroll 1
-    for (int l = 0; l < RLOOPS; l++) {
-        const size_t b0 = ((size_t)blockIdx.y * RLOOPS + l) * RB;
+    for (int l = 0; l < rloops; l++) {
+        const size_t b0 = ((size_t)blockIdx.y * rloops + l) * RB;
         if (!FULL && b0 >= nb) break;
         uint4 v[RB];
 #pragma unroll
@@ -306,25 +313,33 @@ __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__
     o[1] = make_ulonglong2(s[2], s[3]);
 }
 
-size_t radix_fold_groups(size_t nb) { return (nb + RB * RLOOPS - 1) / (RB * RLOOPS); }
+size_t radix_fold_groups(size_t nb, int rloops) {
+    if (rloops <= 0) rloops = RLOOPS;
+    return (nb + (size_t)RB * rloops - 1) / ((size_t)RB * rloops);
+}
 
 void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
                        size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s,
-                       hipEvent_t t_start, hipEvent_t t_stop) {
-    dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)radix_fold_groups(nb), (unsigned)ncols);
-    auto kern = nb % (RB * RLOOPS) == 0 ? k_radix_fold<true> : k_radix_fold<false>;
+                       hipEvent_t t_start, hipEvent_t t_stop, const EvalSkip *skip, int rloops) {
+    if (rloops <= 0) rloops = RLOOPS;
+    dim3 grid((unsigned)((m / 4 + TPB - 1) / TPB), (unsigned)radix_fold_groups(nb, rloops), (unsigned)ncols);
+    auto kern = nb % ((size_t)RB * rloops) == 0 ? k_radix_fold<true> : k_radix_fold<false>;
+    const EvalSkip sk = skip ? *skip : EvalSkip();
     if (t_start && t_stop)  // kernel-exact timing for the roofline figure (an event pair around a launch adds the gaps)
         hipExtLaunchKernelGGL(kern, grid, dim3(TPB), 0, s, t_start, t_stop, 0, d_in, in_stride, m, nb, d_w_m, w_stride,
-                              d_part, part_col_stride);
+                              d_part, part_col_stride, sk, rloops);
     else
-        hipLaunchKernelGGL(kern, grid, dim3(TPB), 0, s, d_in, in_stride, m, nb, d_w_m, w_stride, d_part, part_col_stride);
+        hipLaunchKernelGGL(kern, grid, dim3(TPB), 0, s, d_in, in_stride, m, nb, d_w_m, w_stride, d_part, part_col_stride, sk,
+                           rloops);
 }
 
 __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ part, size_t part_col_stride,
                                                         size_t groups, uint32_t *__restrict__ out, size_t out_stride,
-                                                        size_t m, unsigned log2_m2, unsigned long long *__restrict__ sums) {
+                                                        size_t m, unsigned log2_m2, unsigned long long *__restrict__ sums,
+                                                        EvalSkip skip) {
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     const size_t col = blockIdx.z;
+    if (eval_skips(skip, col)) return;  // (its partial sums were never written)
     uint32_t v = 0;
     if (i < m) {
         const unsigned long long *pp = part + col * part_col_stride + i;
@@ -341,10 +356,10 @@ __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long
 
 void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
                            size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
-                           hipStream_t s) {
+                           hipStream_t s, const EvalSkip *skip) {
     dim3 grid((unsigned)((m + TPB - 1) / TPB), 1, (unsigned)ncols);
     hipLaunchKernelGGL(k_radix_finalize, grid, dim3(TPB), 0, s, d_part, part_col_stride, groups, d_out, out_stride, m, log2_m2,
-                       d_sums);
+                       d_sums, skip ? *skip : EvalSkip());
 }
 
 // eq weights by doubling in LDS, one workgroup per column (all values Montgomery form: mont_mul keeps the form)
@@ -383,9 +398,14 @@ void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint3
 
 __global__ __launch_bounds__(TPB) void k_weighted_dot(const uint32_t *__restrict__ in, size_t in_stride,
                                                       const uint32_t *__restrict__ w_m, size_t w_stride, size_t n,
-                                                      uint32_t *__restrict__ out) {
+                                                      uint32_t *__restrict__ out, EvalSkip skip, const uint32_t *__restrict__ cols,
+                                                      size_t col_stride) {
     __shared__ unsigned long long red[TPB / 64];
     const size_t col = blockIdx.x;
+    if (cols && eval_skips(skip, col)) {  // (workgroup-uniform) the extension of a constant column is the constant
+        if (threadIdx.x == 0) out[col] = cols[col * col_stride];
+        return;
+    }
     unsigned long long acc = 0;
     for (size_t i = threadIdx.x; i < n; i += TPB) acc += mont_mul(w_m[col * w_stride + i], in[col * in_stride + i]);
     acc = wave_sum(acc);
@@ -399,8 +419,10 @@ __global__ __launch_bounds__(TPB) void k_weighted_dot(const uint32_t *__restrict
 }
 
 void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
-                         uint32_t *d_out, size_t ncols, hipStream_t s) {
-    hipLaunchKernelGGL(k_weighted_dot, dim3((unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, d_w_m, w_stride, n, d_out);
+                         uint32_t *d_out, size_t ncols, hipStream_t s, const EvalSkip *skip, const uint32_t *d_cols,
+                         size_t col_stride) {
+    hipLaunchKernelGGL(k_weighted_dot, dim3((unsigned)ncols), dim3(TPB), 0, s, d_in, in_stride, d_w_m, w_stride, n, d_out,
+                       skip ? *skip : EvalSkip(), skip ? d_cols : nullptr, col_stride);
 }
 
 // ------------------------------------------------------------------ layout conversion at the boundary
@@ -942,7 +964,10 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
         cnt[4] = g_ctr ? g_ctr[8] : 0;
         cnt[5] = g_ctr ? g_ctr[9] : 0;
         cnt[6] = (r_ctr ? r_ctr[10] : 0) | ((g_ctr ? g_ctr[10] : 0) << 8);
-        cnt[7] = 0;
+        unsigned long long constant = 0;  // hinted (R) columns whose N leaves are all equal: the eval leaves them out (EvalSkip)
+        if (r_ctr)
+            for (unsigned y = 0; y < t.ncols && y < 64; y++) constant += r_ctr[RUN_CHANGED + y] == 0;
+        cnt[7] = constant;
     }
     if (blockIdx.x == 0 && threadIdx.x < 2 * RUN_MAX_LEVELS) {  // the longest sub-list of every level (what the next build needs)
         const unsigned l = threadIdx.x % RUN_MAX_LEVELS;
@@ -959,14 +984,14 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
 }
 __global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g) {
     const unsigned i = blockIdx.x * TPB + threadIdx.x;
-    if (i < RUN_CTRS) {
+    if (i < RUN_CTR_WORDS) {
         if (r) r[i] = 0;
         if (g) g[i] = 0;
     }
     if (sd && i < 2) sd[i] = 0;
 }
 void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s) {
-    hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTRS + TPB - 1) / TPB), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr);
+    hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTR_WORDS + TPB - 1) / TPB), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr);
 }
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s, DoneFlag done) {

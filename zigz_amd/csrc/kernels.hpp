@@ -83,23 +83,32 @@ void launch_block_sums(const uint32_t *d_in, size_t in_stride, size_t n, unsigne
 // Radix-2^k sumcheck stage (k rounds per pass over the table; pass 1 = launch_block_sums):
 //  (2) part[c][g][i] = sum over the g-th group of 64 consecutive b of W[c][b] * in[c][b*m + i]   (exact u64; i < m,
 //      m % 4 == 0, column c < ncols; W in Montgomery form; G = radix_fold_groups(nb) groups; strides in elements)
-size_t radix_fold_groups(size_t nb);
+size_t radix_fold_groups(size_t nb, int rloops = 0);  // rloops: 16-row chunks per thread (0 = the default, 4)
 //      t_start/t_stop (both or neither): events stamped with the dispatch's own begin/end timestamps.
+// Columns the eval may leave out: column c with y = y_of_col[c] >= 0 and changed[y] == 0 is constant (established from the
+// values by the run-aware structure pass of the same commit job), and the multilinear extension of a constant is that
+// constant -- the eq weights of a point sum to 1 -- so its 4 N bytes are not read: k_radix_fold returns at once for it and
+// k_weighted_dot writes the column's first value.  changed == nullptr: nothing is skipped.
+struct EvalSkip {
+    const unsigned long long *changed = nullptr;
+    signed char y_of_col[64];
+};
 void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
                        size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s,
-                       hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr);
+                       hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr, const EvalSkip *skip = nullptr, int rloops = 0);
 //  (3) out[c][i] = (sum_g part[c][g][i]) mod p; if d_sums (ncols == 1): sums[i >> log2_m2] += out[i]  (block sums of
 //      the next stage, m2 >= 256; must be zeroed by the caller)
 void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
                            size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
-                           hipStream_t s);
+                           hipStream_t s, const EvalSkip *skip = nullptr);
 // eq weights of k variables, Montgomery form: W[c][b] = prod_j (bit_j(b) ? r_cj : 1 - r_cj) with bit 0 of the
 // loop being the MOST significant bit of b; d_r_m[c*r_stride + j] = r_cj in Montgomery form.  k <= 14.
 void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
                        hipStream_t s);
 // out[c] = sum_i W[c][i] * in[c][i] mod p  (i < n <= 16384; W Montgomery, in canonical)
 void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
-                         uint32_t *d_out, size_t ncols, hipStream_t s);
+                         uint32_t *d_out, size_t ncols, hipStream_t s, const EvalSkip *skip = nullptr,
+                         const uint32_t *d_cols = nullptr, size_t col_stride = 0);
 
 // The columns a Keccak launch works on: blockIdx.y = k -> column c[k] (n == 0: identity, column = blockIdx.y).
 struct ColMap {
@@ -135,6 +144,10 @@ constexpr size_t RUN_MAX_LEAVES = (size_t)1 << RUN_NODE_BITS;
 // counters of a build: word 0 = nodes hashed in all; word 8 (the group's array only) = "group dropped" flag, word 9 = distinct
 // leaves found; per level l and sub-list s the length at word (1 + l * RUN_SUBS + s) * 16
 constexpr unsigned RUN_CTRS = (1 + RUN_MAX_LEVELS * RUN_SUBS) * 16;
+// ... followed, in the R counters, by one word per hinted column: != 0 -> the column is NOT constant (k_runs_stage sets it when
+// a segment holds a change or starts with a value other than the column's first).  What the eval of a commit job skips (EvalSkip).
+constexpr unsigned RUN_CHANGED = RUN_CTRS;
+constexpr unsigned RUN_CTR_WORDS = RUN_CTRS + 64;
 __host__ __device__ inline size_t run_ctr_index(unsigned level, unsigned sub) { return (size_t)(1 + level * RUN_SUBS + sub) * 16; }
 // the last list-driven level: 256 nodes per column
 inline unsigned run_top_level(size_t npad) { unsigned v = 0; while (((size_t)1 << v) < npad) v++; return v - 8; }
@@ -213,7 +226,7 @@ struct MerkleBuild {   // everything the structure-aware launches share (device 
     // R
     ColMap rcols;
     uint32_t *r_list;
-    unsigned long long *r_ctr;    // RUN_CTRS words, zeroed before the build; word 10: != 0 -> a list ran out of room
+    unsigned long long *r_ctr;    // RUN_CTR_WORDS words, zeroed before the build; word 10: != 0 -> a list ran out of room
     uint8_t *r_stage;             // runs_stage_scratch_bytes()
     // G
     ColMap gcols;                 // the group, ascending
@@ -284,10 +297,10 @@ void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t
 // The roots (canonical bytes) and behind them the counters of the build, in ONE buffer: ncols x 32 B, then JOB_SUMMARY_WORDS u64:
 //   [0] d_r_ctr[0] (nodes hashed on the run-aware levels), [1] / [2] d_sd_ctr[0] / [1] (waves that left the small-domain
 //   tables), [3] d_g_ctr[0] (digests computed on the content-addressed levels), [4] d_g_ctr[8] (group dropped?), [5] d_g_ctr[9]
-//   (its distinct leaves), [6] d_r_ctr[10] | d_g_ctr[10] << 8 (out of room / slabs missing), then per level l < RUN_MAX_LEVELS
+//   (its distinct leaves), [6] d_r_ctr[10] | d_g_ctr[10] << 8 (out of room / slabs missing), [7] constant R columns, then per level l < RUN_MAX_LEVELS
 //   the longest sub-list of the R lists [8 + l] and of the G lists [8 + RUN_MAX_LEVELS + l]; null pointers read as 0
 constexpr unsigned JOB_SUMMARY_WORDS = 8 + 2 * RUN_MAX_LEVELS;
-// the counters a build's kernels add to (2 words of small-domain fall-backs, RUN_CTRS words each of the R and G lists; null =
+// the counters a build's kernels add to (2 words of small-domain fall-backs, RUN_CTR_WORDS words each of the R and G lists; null =
 // not used by this build), zeroed by one launch
 void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s);
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,

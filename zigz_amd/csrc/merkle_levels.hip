@@ -188,6 +188,14 @@ __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stag
             }
         }
     }
+    if (STAGE0) {  // is the column still constant?  Not if this segment holds a change (beyond the forced bit of its first leaf) or
+        // starts with another value than the column does; no wave says so <=> all N leaves are equal (EvalSkip, kernels.hpp)
+        const unsigned long long inside = lane < words ? (lane == 0 ? E & ~1ull : E) : 0;
+        const uint32_t col_first = b.n_values ? b.vals[(size_t)b.rcols.c[y] * b.val_stride] : 0u;
+        const uint32_t seg_first = (uint32_t)__builtin_amdgcn_readfirstlane((int)fv_mine);  // (lane 0 holds chunk 0's first value)
+        if (__ballot(inside != 0) || seg_first != col_first)
+            if (lane == 0) b.r_ctr[RUN_CHANGED + y] = 1;
+    }
     // 2. all levels of the segment: lane j < words >> r holds word j of relative level r
     unsigned w = words;
     unsigned long long need_r[RUN_STAGE_LEVELS + 1];
