@@ -746,6 +746,53 @@ def main():
             return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
         legs["pcie"] = guard("pcie_inclusive", leg_pcie)
 
+        # What the GPU alone needs per proof, and what of it is hashing: the commit path of every lane -- Merkle builds, roots,
+        # 43 evals + openings, on the resident columns -- back to back WITHOUT the host transcript, three times: complete;
+        # with the hash launches left out; with the structure passes left out too (option debug_skip: wrong trees, measurement
+        # only).  The kernel-time shares of `roofline` sum launch durations, which count a small kernel's wait for a wave slot
+        # next to 80 proofs' hash waves as its time; these are wall-clock differences.
+        def gpu_bound(skip):
+            regs, small = 0x7fffffff << 2, (1 << 1) | (0x3f << 33) | (1 << 42)
+            want = {"small_domain_mask": small, "run_aware_mask": regs | (3 << 40), "cons_group_mask": 1 | (1 << 1) | (0x7f << 33) | (1 << 42)}
+            import numpy as np
+            rng_p = np.random.default_rng(4242)
+            pts = rng_p.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
+            saved = [{k: l.ctx.get_option(k) for k in want} for l in lanes]
+            iters = max(3, min(args.steps, 8))
+
+            def once(l):
+                job = zigz_amd.CommitJob(l.ctx, d_cols=l.d_cols, ncols=43, nv=nv, col_stride=N)
+                job.roots()
+                job.open_all(pts)
+                job.end()
+
+            def loop(l):
+                for _ in range(iters):
+                    once(l)
+            try:
+                for l in lanes:
+                    l.ctx.enable_timing(False)
+                    for k, v in want.items():
+                        l.ctx.set_option(k, v)
+                gather([pool.submit(once, l) for l in lanes])
+                for l in lanes:
+                    l.ctx.set_option("debug_skip", skip)
+                gather([pool.submit(once, l) for l in lanes])
+                sync_all()
+                t0 = time.perf_counter()
+                gather([pool.submit(loop, l) for l in lanes])
+                dtg = time.perf_counter() - t0
+            finally:
+                for l, sv in zip(lanes, saved):
+                    l.ctx.set_option("debug_skip", 0)
+                    for k, v in sv.items():
+                        l.ctx.set_option(k, v)
+                    l.timing = False
+            return {"dt": dtg, "steps": iters, "trace_steps": local_steps}
+        if args.merkle == "cons":
+            for skip, name in ((0, "gpu_all"), (1, "gpu_nohash"), (2, "gpu_nohash_nostruct")):
+                legs[name] = guard(name, lambda skip=skip: gpu_bound(skip))
+
         digests = []
 
         def leg_self_check():  # untimed: every lane's proof under this build ...
@@ -907,7 +954,8 @@ def main():
 
     # every leg of the fixed list is reduced by EVERY rank whether its own attempt succeeded or not (the number of collectives
     # must not depend on what failed where); a leg that failed on any rank is dropped everywhere
-    leg_names = ["pcie"] + ["variant:" + m for m in ("cons", "struct", "regs", "all", "tables", "dense")] + \
+    leg_names = ["pcie", "gpu_all", "gpu_nohash", "gpu_nohash_nostruct"] + \
+                ["variant:" + m for m in ("cons", "struct", "regs", "all", "tables", "dense")] + \
                 ["worst", "mixed", "straight", "nv16", "nv22", "nv24"]
     if torch is not None:
         def allmax(x):
@@ -1042,6 +1090,20 @@ def main():
                 detail["single_proof"]["vm_ms"] = solo["vm_ms"]
         if legs.get("pcie"):  # trace upload + witness kernels inside the loop
             cfg["pcie_inclusive_value"] = rate(legs["pcie"])
+        if legs.get("gpu_all"):  # the commit path alone: what the GPU needs per proof (ms), and the same without its hashing
+            def gpu_ms(leg):
+                return leg["dt"] / (leg["steps"] * B) * 1e3
+            cfg["gpu_bound_ms_per_proof"] = gpu_ms(legs["gpu_all"])
+            dec = {"complete": gpu_ms(legs["gpu_all"])}
+            if legs.get("gpu_nohash"):
+                dec["without_hash_launches"] = gpu_ms(legs["gpu_nohash"])
+            if legs.get("gpu_nohash_nostruct"):
+                dec["without_hash_and_structure_launches"] = gpu_ms(legs["gpu_nohash_nostruct"])
+            if "without_hash_launches" in dec:
+                dec["hashing_share_of_gpu_time"] = 1.0 - dec["without_hash_launches"] / dec["complete"]
+                roof["hash_share_of_gpu_time"] = dec["hashing_share_of_gpu_time"]  # (takes the place of structure_in_proof_hbm_frac)
+                detail["structure_in_proof_hbm_frac"] = roof.pop("structure_in_proof_hbm_frac", None)
+            detail["gpu_ms_per_proof_commit_path_only"] = dec
         for key, name in (("worst", "register_worst_case_value"), ("mixed", "config4_mixed_value"), ("straight", "straight_line_value")):
             if legs.get(key):
                 cfg[name] = rate(legs[key])
