@@ -758,7 +758,7 @@ def main():
             rng_p = np.random.default_rng(4242)
             pts = rng_p.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
             saved = [{k: l.ctx.get_option(k) for k in want} for l in lanes]
-            iters = max(3, min(args.steps, 8))
+            iters = max(4, min(2 * args.steps, 20))
 
             def once(l):
                 job = zigz_amd.CommitJob(l.ctx, d_cols=l.d_cols, ncols=43, nv=nv, col_stride=N)
