@@ -719,8 +719,7 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
     CHK(ws_get(ctx, WS_FOLD, ncols * (groups * m * 8 + nb * 4 + m * 4 + m * 4) + 256, &ws));
     unsigned long long *d_part = (unsigned long long *)ws;
     uint32_t *d_w1 = (uint32_t *)(d_part + ncols * groups * m), *d_w2 = d_w1 + ncols * nb, *d_t1 = d_w2 + ncols * m;
-    launch_eq_weights(d_rt, nv, k1, d_w1, nb, ncols, ctx->stream);
-    launch_eq_weights(d_rt + k1, nv, k2, d_w2, m, ncols, ctx->stream);
+    launch_eq_weights2(d_rt, nv, k1, d_w1, nb, k2, d_w2, m, ncols, ctx->stream);  // (one launch for both tables)
     bind_pool_reset(ctx);
     const bool rec = ctx->timing;
     // the one pass over the data; in timing mode the events carry the dispatch's own begin/end timestamps
@@ -731,6 +730,8 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
         // one read of the tables (those of the columns that are not skipped) + the partial sums
         ctx->pool_bytes = (uint64_t)(ncols - (skip ? ctx->stats.eval_constant_columns : 0)) * (N * 4 + groups * m * 8);
     }
+    // (finalize and dot stay two launches: fused into one workgroup per column they took 60-69 us in a batch against 13 + 9 --
+    // a column's 64 groups summed by ONE workgroup instead of four)
     launch_radix_finalize(d_part, groups * m, groups, d_t1, m, m, 0, nullptr, ncols, ctx->stream, skip);
     launch_weighted_dot(d_t1, m, d_w2, m, m, d_vals, ncols, ctx->stream, skip, d_cols, col_stride);
     HIPCHK(ctx, hipGetLastError());

@@ -390,6 +390,44 @@ __global__ __launch_bounds__(TPB) void k_eq_weights(const uint32_t *__restrict__
     for (size_t i = threadIdx.x; i < ((size_t)1 << k); i += TPB) w_m[col * w_stride + i] = eqw[i];
 }
 
+// both weight tables of the radix eval in ONE launch: blockIdx.y = 0 -> the first kA variables into wA, 1 -> the next kB into wB
+__global__ __launch_bounds__(TPB) void k_eq_weights2(const uint32_t *__restrict__ r_m, size_t r_stride, unsigned kA,
+                                                     uint32_t *__restrict__ wA, size_t strideA, unsigned kB,
+                                                     uint32_t *__restrict__ wB, size_t strideB) {
+    extern __shared__ uint32_t eqw[];
+    const size_t col = blockIdx.x;
+    const bool second = blockIdx.y != 0;
+    const unsigned k = second ? kB : kA;
+    const uint32_t *rr = r_m + col * r_stride + (second ? kA : 0);
+    uint32_t *w = second ? wB + col * strideB : wA + col * strideA;
+    if (threadIdx.x == 0) eqw[0] = R_MOD_P;
+    __syncthreads();
+    for (unsigned j = 0; j < k; j++) {
+        const uint32_t r = rr[j];
+        const uint32_t one_minus = sub_mod(R_MOD_P, r);
+        const size_t cur = (size_t)1 << j;
+        for (size_t base = 0; base < cur; base += TPB) {  // (as k_eq_weights: in-place doubling from the top)
+            const size_t x = cur - 1 - (base + threadIdx.x);
+            uint32_t v = 0;
+            const bool live = base + threadIdx.x < cur;
+            if (live) v = eqw[x];
+            __syncthreads();
+            if (live) {
+                eqw[2 * x + 1] = mont_mul(v, r);
+                eqw[2 * x] = mont_mul(v, one_minus);
+            }
+            __syncthreads();
+        }
+    }
+    for (size_t i = threadIdx.x; i < ((size_t)1 << k); i += TPB) w[i] = eqw[i];
+}
+void launch_eq_weights2(const uint32_t *d_r_m, size_t r_stride, unsigned kA, uint32_t *d_wA, size_t strideA, unsigned kB,
+                        uint32_t *d_wB, size_t strideB, size_t ncols, hipStream_t s) {
+    const unsigned kmax = kA > kB ? kA : kB;
+    hipLaunchKernelGGL(k_eq_weights2, dim3((unsigned)ncols, 2), dim3(TPB), ((size_t)1 << kmax) * 4, s, d_r_m, r_stride, kA, d_wA,
+                       strideA, kB, d_wB, strideB);
+}
+
 void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
                        hipStream_t s) {
     hipLaunchKernelGGL(k_eq_weights, dim3((unsigned)ncols), dim3(TPB), ((size_t)1 << k) * 4, s, d_r_m, r_stride, k, d_w_m,

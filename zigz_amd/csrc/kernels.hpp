@@ -106,6 +106,9 @@ void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_str
 void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
                        hipStream_t s);
 // out[c] = sum_i W[c][i] * in[c][i] mod p  (i < n <= 16384; W Montgomery, in canonical)
+// the two weight tables of a radix eval (variables 0..kA-1 and kA..kA+kB-1 of every column's point) in one launch
+void launch_eq_weights2(const uint32_t *d_r_m, size_t r_stride, unsigned kA, uint32_t *d_wA, size_t strideA, unsigned kB,
+                        uint32_t *d_wB, size_t strideB, size_t ncols, hipStream_t s);
 void launch_weighted_dot(const uint32_t *d_in, size_t in_stride, const uint32_t *d_w_m, size_t w_stride, size_t n,
                          uint32_t *d_out, size_t ncols, hipStream_t s, const EvalSkip *skip = nullptr,
                          const uint32_t *d_cols = nullptr, size_t col_stride = 0);
