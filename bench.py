@@ -514,12 +514,16 @@ def main():
             self.trace.witness_to_device(self.ctx, self.d_cols, self.N)
             self.ctx.synchronize()
 
-        def close(self):
+        def drop_upload_context(self):  # (after the PCIe-inclusive leg: the second context + stream of the lane go away)
             if self.up_ctx is not None:
                 self.up_ctx.synchronize()
                 self.up_ctx.dev_free(self.d_next)
                 self.up_ctx.close()
                 self.up_ctx = None
+                self.d_next = None
+
+        def close(self):
+            self.drop_upload_context()
             if self.ctx is not None:
                 self.ctx.dev_free(self.d_cols)
                 self.ctx.close()
@@ -740,12 +744,6 @@ def main():
             return r
         solo = guard("single_proof", leg_solo)
 
-        def leg_pcie():
-            run_step(Lane.upload_and_prove)
-            dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
-            return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
-        legs["pcie"] = guard("pcie_inclusive", leg_pcie)
-
         # What the GPU alone needs per proof, and what of it is hashing: the commit path of every lane -- Merkle builds, roots,
         # 43 evals + openings, on the resident columns -- back to back WITHOUT the host transcript, three times: complete;
         # with the hash launches left out; with the structure passes left out too (option debug_skip: wrong trees, measurement
@@ -792,6 +790,16 @@ def main():
         if args.merkle == "cons":
             for skip, name in ((0, "gpu_all"), (1, "gpu_nohash"), (2, "gpu_nohash_nostruct")):
                 legs[name] = guard(name, lambda skip=skip: gpu_bound(skip))
+
+        # (after the legs above: this one gives every lane a second context and stream for its uploads -- dropped again right
+        # after it: a process with twice the streams runs everything a few percent slower)
+        def leg_pcie():
+            run_step(Lane.upload_and_prove)
+            dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
+            return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
+        legs["pcie"] = guard("pcie_inclusive", leg_pcie)
+        guard("drop_upload_contexts", lambda: [l.drop_upload_context() for l in lanes])
+
 
         digests = []
 
