@@ -939,9 +939,10 @@ def main():
         for nv_s, steps_s in ((16, 10), (22, 5), (24, 2)):
             if nv_s == nv:
                 continue
-            # (the bench trace needs ~0.6 GiB per proof in flight at 2^20 -- 0.9 with the room a first build may ask for --
-            # and proportionally more above; below 2^20 the fixed workspaces dominate)
-            per_lane = int(0.9 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+            # (the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 -- resident columns,
+            # the compact trace's staging, lists and digests after the first build's learning -- measured; below 2^20 the
+            # fixed workspaces dominate)
+            per_lane = int(0.72 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
             nl = max(1, min(B, int(free_now * 0.8) // per_lane))
             ls = []
 
