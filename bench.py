@@ -499,6 +499,7 @@ def main():
             self.trace.pin(self.ctx)  # page-locked trace records (48 B per step): uploads run at PCIe rate
             self.trace.witness_to_device(self.ctx, self.d_cols, self.N)   # [2/6] witness resident in HBM before timing
             self.ctx.synchronize()
+            self.ctx.release_workspaces()  # (the upload's staging, 48 B per step, is not needed while the witness stays resident)
             self.proof = None
             self.up_ctx = None
             self.d_next = None
@@ -939,10 +940,10 @@ def main():
         for nv_s, steps_s in ((16, 10), (22, 5), (24, 2)):
             if nv_s == nv:
                 continue
-            # (the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 -- resident columns,
-            # the compact trace's staging, lists and digests after the first build's learning -- measured; below 2^20 the
-            # fixed workspaces dominate)
-            per_lane = int(0.72 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+            # (the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 -- resident columns, lists
+            # and digests after the first build's learning, and the compact trace's staging, which the lanes give back:
+            # 0.6 / 2.3 / 9.0 -- measured; below 2^20 the fixed workspaces dominate)
+            per_lane = int(0.66 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
             nl = max(1, min(B, int(free_now * 0.8) // per_lane))
             ls = []
 
