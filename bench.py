@@ -4,8 +4,9 @@
     python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B] [--nv 20] [--mode traces|shard]
                     [--no-cpu-baseline] [--kernels]
 
-A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces (default: 8 per
-sponge-server thread, 10 of those on a 16-CPU share of the host; every trace gets its own complete proof) whose 43 witness
+A "step" is ONE full pass of the prover hot path over one batch of `--batch` independent 2^20-step traces (default: 8.8 per
+sponge-server thread -- 8 slots each and a tenth more proofs than slots --, 10 servers on a 16-CPU share of the host;
+every trace gets its own complete proof) whose 43 witness
 columns each are already resident in HBM when the timed region starts.  Per trace: the exact Fiat-Shamir schedule of
 Prover.prove (public inputs, SUMCHECK_BEGIN, one LASSO_TABLE absorption per lookup step, POLY_COMMITMENTS, 43*v challenges,
 OPENING_CLAIMS), 43 SHA3 Merkle commits, 43 MLE evaluations, 43 openings, packagePublicIO and the ZIGZ v1 serialisation of
@@ -299,7 +300,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: 8 per "
+    ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: 8.8 per "
                     "sponge server, bounded by free HBM; without the service this rank's share of the host CPUs minus 2, at most "
                     "14).  One proof alone is bound by its sequential host transcript (~27 ms on one core) against ~0.55 ms of GPU "
                     "work with the default Merkle build, so a proving service keeps many proofs in flight, one host thread + one "
@@ -466,7 +467,10 @@ def main():
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
-    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers if servers else default_batch(ncpu)))
+    # 8 transcripts per server are in lock step; a tenth more proofs than sponge slots keeps the slots full while a proof is in
+    # its GPU phases (roots, challenges, openings: 2-4 of its 40-odd ms): 10 x 8 slots, 88 lanes -- 2.00-2.03 G steps/s against
+    # 1.95-1.98 G with 80 on one box, 14.0 of 16 CPUs busy (96 / 104 lanes: 2.02 / 2.05 G at 15.0 / 15.7 CPUs)
+    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers + max(1, 8 * servers // 10) if servers else default_batch(ncpu)))
     hbm_free = None
     if not shard and args.batch <= 0:  # a proof in flight holds ~3.5 GiB of HBM at 2^20 (trees, lists, witness): stay inside it
         probe = zigz_amd.Context(local_rank)
@@ -756,7 +760,9 @@ def main():
             import numpy as np
             rng_p = np.random.default_rng(4242)
             pts = rng_p.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
-            saved = [{k: l.ctx.get_option(k) for k in want} for l in lanes]
+            gl = lanes[:min(len(lanes), 28)]  # (28 lanes keep the GPU full; with all of them active at once -- in a proof only a
+            # tenth are in their GPU phases at any time -- the streams get in each other's way: 0.57 instead of 0.49-0.50 ms)
+            saved = [{k: l.ctx.get_option(k) for k in want} for l in gl]
             iters = max(4, min(2 * args.steps, 20))
 
             def once(l):
@@ -769,25 +775,25 @@ def main():
                 for _ in range(iters):
                     once(l)
             try:
-                for l in lanes:
+                for l in gl:
                     l.ctx.enable_timing(False)
                     for k, v in want.items():
                         l.ctx.set_option(k, v)
-                gather([pool.submit(once, l) for l in lanes])
-                for l in lanes:
+                gather([pool.submit(once, l) for l in gl])
+                for l in gl:
                     l.ctx.set_option("debug_skip", skip)
-                gather([pool.submit(once, l) for l in lanes])
+                gather([pool.submit(once, l) for l in gl])
                 sync_all()
                 t0 = time.perf_counter()
-                gather([pool.submit(loop, l) for l in lanes])
+                gather([pool.submit(loop, l) for l in gl])
                 dtg = time.perf_counter() - t0
             finally:
-                for l, sv in zip(lanes, saved):
+                for l, sv in zip(gl, saved):
                     l.ctx.set_option("debug_skip", 0)
                     for k, v in sv.items():
                         l.ctx.set_option(k, v)
                     l.timing = False
-            return {"dt": dtg, "steps": iters, "trace_steps": local_steps}
+            return {"dt": dtg, "steps": iters, "lanes": len(gl), "trace_steps": float(sum(l.trace.num_steps for l in gl))}
         if args.merkle == "cons":
             for skip, name in ((0, "gpu_all"), (1, "gpu_nohash"), (2, "gpu_nohash_nostruct")):
                 legs[name] = guard(name, lambda skip=skip: gpu_bound(skip))
@@ -1102,7 +1108,7 @@ def main():
             cfg["pcie_inclusive_value"] = rate(legs["pcie"])
         if legs.get("gpu_all"):  # the commit path alone: what the GPU needs per proof (ms), and the same without its hashing
             def gpu_ms(leg):
-                return leg["dt"] / (leg["steps"] * B) * 1e3
+                return leg["dt"] / (leg["steps"] * leg.get("lanes", B)) * 1e3
             cfg["gpu_bound_ms_per_proof"] = gpu_ms(legs["gpu_all"])
             dec = {"complete": gpu_ms(legs["gpu_all"])}
             if legs.get("gpu_nohash"):
