@@ -288,7 +288,14 @@ void zigz_shm_comm_destroy(zigz_shm_comm *comm);
  *    HBM on the given hipStream_t, no staging and no synchronisation;
  *  - zigz_dev_sumcheck_prove_rccl is zigz_dev_sumcheck_prove_sharded with the partial block sums of every radix stage
  *    (k <= 10 rounds of round-polynomial sums, sumcheck_prover.zig:50-77) all-reduced in HBM on the context's stream --
- *    one RCCL all-reduce per stage of rounds -- and the last <= 1024 * world entries all-gathered through the comm. */
+ *    one RCCL all-reduce per stage of rounds -- and the last <= 1024 * world entries all-gathered through the comm.
+ * RCCL itself never times out, so every wait behind a collective here has a deadline (zigz_rccl_comm_set_timeout, default
+ * 120 s): when it passes -- a peer never entered the collective -- the communicator is aborted (ncclCommAbort), the call
+ * returns nonzero / ZIGZ_ERR_COMM and every later call on that communicator fails at once.  Failure of a sharded proof is
+ * collective here too: the all-reduce of a stage carries one extra word, the number of ranks whose local pass failed, so
+ * all ranks leave the proof at the same collective (the failing one with its own error, the others with ZIGZ_ERR_COMM).
+ * zigz_rccl_stream_wait is the deadline wait for a stream that holds a ..._dev collective; zigz_rccl_comm_abort aborts by
+ * hand.  (ncclCommInitRank inside zigz_rccl_comm_create has no deadline: a rank that never calls create blocks the others.) */
 #define ZIGZ_RCCL_UNIQUE_ID_BYTES 128
 typedef struct zigz_rccl_comm zigz_rccl_comm;
 zigz_status zigz_rccl_unique_id(uint8_t id[ZIGZ_RCCL_UNIQUE_ID_BYTES]);
@@ -297,6 +304,9 @@ zigz_status zigz_rccl_comm_create(int device, const uint8_t id[ZIGZ_RCCL_UNIQUE_
 int zigz_rccl_allgather(void *comm, const void *send, size_t bytes, void *recv);
 int zigz_rccl_allreduce_u64(zigz_rccl_comm *comm, const uint64_t *send, size_t n, uint64_t *recv);
 int zigz_rccl_allreduce_u64_dev(zigz_rccl_comm *comm, uint64_t *d_words, size_t n, void *hip_stream);
+int zigz_rccl_stream_wait(zigz_rccl_comm *comm, void *hip_stream);
+void zigz_rccl_comm_set_timeout(zigz_rccl_comm *comm, double seconds);
+void zigz_rccl_comm_abort(zigz_rccl_comm *comm);
 int zigz_rccl_comm_rank(const zigz_rccl_comm *comm);
 int zigz_rccl_comm_world(const zigz_rccl_comm *comm);
 void zigz_rccl_comm_destroy(zigz_rccl_comm *comm);
@@ -315,6 +325,13 @@ typedef struct zigz_radix_ops {
 zigz_status zigz_sumcheck_radix_run(const zigz_radix_ops *ops, size_t n_local, int rank, int world,
                                     zigz_allgather_fn allgather, void *comm_user, const uint64_t *fixed_challenges,
                                     uint64_t *rounds, uint64_t *point, uint64_t *final_eval);
+/* ... over data passes whose sums are ALREADY the sums over all ranks (reduced inside the pass by a collective of its own,
+ * as the passes of zigz_dev_sumcheck_prove_rccl do with RCCL): no exchange per stage.  A pass that fails -- or learns inside
+ * its collective that a peer failed -- returns nonzero on every rank at the same stage; the run then skips the remaining
+ * passes everywhere and all ranks leave through the tail exchange, which carries the status words. */
+zigz_status zigz_sumcheck_radix_run_reduced(const zigz_radix_ops *ops, size_t n_local, int rank, int world,
+                                            zigz_allgather_fn allgather, void *comm_user, const uint64_t *fixed_challenges,
+                                            uint64_t *rounds, uint64_t *point, uint64_t *final_eval);
 
 /* ---------------------------------------------------------------- host SHA3 sponge / transcript
  * FiatShamirTranscript   src/core/hash.zig:255-324 (sequential by construction: stays on the host) */

@@ -1259,3 +1259,66 @@ def test_eval_leaves_out_constant_columns_only(ctx, nv):
             const.pop(3, None)
     finally:
         ctx.set_option("run_aware_mask", 0)
+
+
+@pytest.mark.gpu
+def test_commit_job_survives_a_hinted_build_in_between(ctx):
+    """a commit job's openings read the list counters of ITS build again (the "column is not constant" words of
+    EvalSkip, the "group dropped" word).  include/zigz_hip.h allows other calls on the context between zigz_commit_begin and
+    zigz_commit_open_all; a hinted zigz_merkle_commit of >= 2^15 values in that window runs the same structure passes and
+    must count in counters of its own.  Trace-like columns (loops: the group is kept; busy and constant registers), every
+    opening against the oracle; the tree built in between against the oracle too."""
+    import zigz_amd
+    nv = 15
+    N = 1 << nv
+    rng = np.random.default_rng(0xAD71CE)
+    cols = np.zeros((43, N), dtype=np.uint64)
+    body = rng.integers(0, 2013265921, size=(10, 12), dtype=np.uint64)  # a 12-step loop: the ten instruction columns repeat
+    grp = [0, 1, 33, 34, 35, 36, 37, 38, 39, 42]
+    for j, c in enumerate(grp):
+        cols[c] = np.tile(body[j], N // 12 + 1)[:N]
+    cols[1] = 0
+    for c in range(2, 33):       # registers: a few busy ones, the rest constant -- but NOT constant in the tree built in between
+        cols[c] = 7 * c
+    cols[5] = np.repeat(rng.integers(0, 2013265921, size=N // 64, dtype=np.uint64), 64)
+    cols[9] = np.repeat(rng.integers(0, 2013265921, size=N // 4096, dtype=np.uint64), 4096)
+    cols[40] = 0
+    cols[41] = 0
+    exp = O.generate_commitments(P, O.Transcript(), cols, fast=True)
+    other = np.repeat(rng.integers(0, 2013265921, size=N // 8, dtype=np.uint64), 8)  # changes everywhere, never constant
+    saved = {k: ctx.get_option(k) for k in ("run_aware_mask", "cons_group_mask", "small_domain_mask")}
+    try:
+        ctx.set_option("small_domain_mask", (1 << 1) | (0x3f << 33) | (1 << 42))
+        ctx.set_option("run_aware_mask", (0x7fffffff << 2) | (3 << 40))
+        ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
+        ctx.set_option("cons_always", 1)
+        for where in ("before_roots", "after_roots"):
+            job = zigz_amd.CommitJob(ctx, cols=cols)
+            if where == "after_roots":
+                assert np.array_equal(job.roots(), exp["roots"])
+            # a single tree whose one column is hinted as run-aware AND as a (one-column) group: clears and rewrites counters
+            ctx.set_option("run_aware_mask", 1)
+            ctx.set_option("cons_group_mask", 0)
+            t1 = zigz_amd.SimpleMerkleTree(ctx, other)
+            ctx.set_option("run_aware_mask", 0)
+            ctx.set_option("cons_group_mask", 1)
+            t2 = zigz_amd.SimpleMerkleTree(ctx, other)
+            lv, _ = O.merkle_levels(other)
+            want_root = lv[(2 * N - 2) * 32:(2 * N - 1) * 32].tobytes()
+            assert t1.root_hash == want_root and t2.root_hash == want_root
+            t1.deinit()
+            t2.deinit()
+            ctx.set_option("run_aware_mask", (0x7fffffff << 2) | (3 << 40))
+            ctx.set_option("cons_group_mask", 1 | (1 << 1) | (0x7f << 33) | (1 << 42))
+            if where == "before_roots":
+                assert np.array_equal(job.roots(), exp["roots"])
+                st = ctx.stats()  # (the stats are the last build's: in the other order the single trees have overwritten them)
+                assert st["cons_columns"] == 10 and st["eval_constant_columns"] >= 29, st
+            got = job.open_all(exp["points"])
+            job.end()
+            for k in ("values", "indices", "leaves", "siblings", "dirs"):
+                assert np.array_equal(got[k], exp[k]), (where, k)
+    finally:
+        ctx.set_option("cons_always", 0)
+        for k, v in saved.items():
+            ctx.set_option(k, v)

@@ -206,6 +206,102 @@ def test_sharded_sumcheck_fails_on_all_ranks_together():
     assert max(dt for _, dt in out.values()) < 20.0, out
 
 
+class _ReducedOps:
+    """Stand-in passes with the semantics of the RCCL passes of zigz_dev_sumcheck_prove_rccl (csrc/api.cpp: sums_out): a
+    pass returns the sums over ALL ranks -- reduced inside the pass by a collective of its own, which carries one more word,
+    the number of ranks whose local pass failed, and which EVERY rank takes part in whatever happened locally."""
+
+    def __init__(self, inner, comm, fail_in=None):
+        self.inner, self.comm, self.fail_in = inner, comm, fail_in
+
+    def _reduce(self, fn, n):
+        failed, v = 0, [0] * n
+        try:
+            v = fn()
+        except ValueError:
+            failed = 1
+        words = [int(x) for x in v] + [failed]
+        got = self.comm.all_gather(b"".join(int(w).to_bytes(16, "little") for w in words))  # (the collective: always issued)
+        tot = [sum(int.from_bytes(g[16 * i:16 * i + 16], "little") for g in got) for i in range(n + 1)]
+        if failed:
+            raise ValueError("this rank's data pass fails")
+        if tot[n]:
+            raise RuntimeError("a peer reported a failure inside the collective")
+        return tot[:n]
+
+    def block_sums(self, k):
+        def local():
+            if self.fail_in == "block_sums":
+                raise ValueError
+            return self.inner.block_sums(k)
+        return self._reduce(local, 1 << k)
+
+    def fold(self, k, weights, k_next):
+        def local():
+            if self.fail_in == "fold":
+                raise ValueError
+            return self.inner.fold(k, weights, k_next) or []
+        if not k_next:
+            return local()
+        return self._reduce(local, 1 << k_next)
+
+    def read_tail(self, m):
+        return self.inner.read_tail(m)
+
+
+def _reduced_worker(rank, world, name, nv, fail_in, q):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from zigz_amd import shard
+    import zigz_amd
+    import fake_engine
+    comm = shard.ShmComm(name, rank, world, max_bytes=1 << 15, timeout_s=60)
+    t0 = time.perf_counter()
+    try:
+        local = shard.interleave_rows(O.splitmix64_field(41 + nv, 1 << nv), rank, world)
+        ops = _ReducedOps(fake_engine.FakeRadixOps(local), comm, fail_in if rank == 1 else None)
+        r, p, fe = shard.sumcheck_radix_run(ops, len(local), None, allgather=comm, reduced=True)
+        q.put((rank, "ok", dict(rounds=r.tolist(), point=p.tolist(), fe=fe), time.perf_counter() - t0))
+    except zigz_amd.ZigzError as e:
+        q.put((rank, e.name, None, time.perf_counter() - t0))
+    except ValueError:
+        q.put((rank, "own error", None, time.perf_counter() - t0))
+    except RuntimeError:
+        q.put((rank, "peer failed", None, time.perf_counter() - t0))
+    finally:
+        comm.close()
+
+
+@pytest.mark.parametrize("fail_in", [None, "block_sums", "fold"])
+def test_radix_run_with_reduced_sums_stays_in_step(fail_in):
+    """with the sums reduced inside the passes (the RCCL form) there is no host exchange between the stages, so
+    a rank whose pass fails must still take part in that pass's collective, and its peers must learn of the failure THERE:
+    otherwise the failing rank goes straight to the tail exchange while the others enqueue the next stage's all-reduce, and
+    RCCL -- which has no timeout -- never returns.  zigz_sumcheck_radix_run_reduced over stand-in passes with exactly the
+    protocol of csrc/api.cpp:sums_out, 2^15 rows over 4 ranks (two stages): without a failure the proof is the unsharded
+    oracle's; with one, every rank returns at once -- rank 1 with its own error, the others with what the collective told them."""
+    world, nv = 4, 15
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    name = "zigz_test_red_%d_%s" % (os.getpid(), fail_in)
+    procs = [ctx.Process(target=_reduced_worker, args=(r, world, name, nv, fail_in, q)) for r in range(world)]
+    [p.start() for p in procs]
+    out = {r: (what, res, dt) for r, what, res, dt in (q.get(timeout=120) for _ in range(world))}
+    [p.join(timeout=60) for p in procs]
+    assert max(dt for _, _, dt in out.values()) < 30.0, out
+    if fail_in is None:
+        r, p, fe = O.sumcheck_prove(P, O.splitmix64_field(41 + nv, 1 << nv))
+        for rank in range(world):
+            what, res, _ = out[rank]
+            assert what == "ok" and res["rounds"] == [int(x) for x in r] and res["point"] == [int(x) for x in p] and res["fe"] == fe
+    else:
+        assert out[1][0] == "own error", out
+        # (at this size the table has ONE device stage: a failing fold has no collective of its own and the peers learn of it
+        # in the tail exchange -- CommError --; a failing block-sums pass tells them inside its collective)
+        for rank in (0, 2, 3):
+            assert out[rank][0] == ("peer failed" if fail_in == "block_sums" else "CommError"), out
+
+
 @pytest.mark.parametrize("world,nv", [(2, 13), (4, 14), (8, 14)])
 def test_row_sharded_radix_sumcheck_shm(world, nv):
     """The same orchestration with the built-in same-node transport (zigz_shm_comm, no torch, no sockets):

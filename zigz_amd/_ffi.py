@@ -106,6 +106,8 @@ SIGNATURES = {
     "zigz_dev_sumcheck_prove_sharded": (C.c_int32, [vp, vp, C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p, u64p]),
     "zigz_sumcheck_radix_run": (C.c_int32, [C.POINTER(RadixOps), C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p,
                                             u64p, u64p]),
+    "zigz_sumcheck_radix_run_reduced": (C.c_int32, [C.POINTER(RadixOps), C.c_size_t, C.c_int, C.c_int, ALLGATHER_FN, vp, u64p, u64p,
+                                                    u64p, u64p]),
     "zigz_shm_comm_create": (C.c_int32, [C.c_char_p, C.c_int, C.c_int, C.c_size_t, C.c_double, C.POINTER(vp)]),
     "zigz_shm_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "zigz_shm_comm_destroy": (None, [vp]),
@@ -114,6 +116,9 @@ SIGNATURES = {
     "zigz_rccl_allgather": (C.c_int, [vp, vp, C.c_size_t, vp]),
     "zigz_rccl_allreduce_u64": (C.c_int, [vp, u64p, C.c_size_t, u64p]),
     "zigz_rccl_allreduce_u64_dev": (C.c_int, [vp, vp, C.c_size_t, vp]),
+    "zigz_rccl_stream_wait": (C.c_int, [vp, vp]),
+    "zigz_rccl_comm_set_timeout": (None, [vp, C.c_double]),
+    "zigz_rccl_comm_abort": (None, [vp]),
     "zigz_rccl_comm_rank": (C.c_int, [vp]),
     "zigz_rccl_comm_world": (C.c_int, [vp]),
     "zigz_rccl_comm_destroy": (None, [vp]),

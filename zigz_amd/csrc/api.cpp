@@ -57,7 +57,10 @@ struct zigz_ctx {
     int debug_skip;              // option (measurement only, wrong trees): 1 = no level hashing / top, 2 = no structure passes
     uint64_t run_aware_mask;  // option: columns (bit c) whose Merkle levels are built run-aware (copies of the left neighbour
                               // are copied, not hashed); "merkle_dedup" = 1 is all columns
-    unsigned long long *d_run_count;  // nodes hashed by the run-aware launches of the last build
+    unsigned long long *d_run_count;  // counters of the run-aware lists of the ACTIVE COMMIT JOB's build (and its "column is
+                                      // not constant" words): read again by the job's openings, so nothing else adds to them
+    unsigned long long *d_run_aux, *d_cons_aux;  // the same counters for builds outside a job (zigz_merkle_commit): a hinted
+                                                 // build between a job's begin and its open_all must not clear the job's words
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
     int pool_used;
@@ -255,6 +258,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
     if (fail(hipSetDevice(device)) || fail(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking)) ||
         fail(hipMalloc((void **)&ctx->d_sums, SUMS_SLOTS * sizeof(unsigned long long))) ||
         fail(hipMalloc((void **)&ctx->d_flag, 64)) || fail(hipMalloc((void **)&ctx->d_run_count, RUN_CTR_WORDS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_count, RUN_CTR_WORDS * 8)) ||
+        fail(hipMalloc((void **)&ctx->d_run_aux, RUN_CTR_WORDS * 8)) || fail(hipMalloc((void **)&ctx->d_cons_aux, RUN_CTR_WORDS * 8)) ||
         fail(hipHostMalloc((void **)&ctx->h_pin, PIN_WORDS * sizeof(uint64_t), hipHostMallocDefault)) ||
         fail(hipHostMalloc((void **)&ctx->h_roots, ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8 + 64, hipHostMallocDefault)))
         st = ZIGZ_ERR_HIP;
@@ -289,6 +293,8 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
     if (ctx->d_flag) (void)hipFree(ctx->d_flag);
     if (ctx->d_run_count) (void)hipFree(ctx->d_run_count);
     if (ctx->d_cons_count) (void)hipFree(ctx->d_cons_count);
+    if (ctx->d_run_aux) (void)hipFree(ctx->d_run_aux);
+    if (ctx->d_cons_aux) (void)hipFree(ctx->d_cons_aux);
     if (ctx->h_pin) (void)hipHostFree(ctx->h_pin);
     if (ctx->h_roots) (void)hipHostFree(ctx->h_roots);
     for (int i = 0; i < 6; i++)
@@ -1060,14 +1066,36 @@ struct GpuRadix {
     unsigned stage;
     zigz_rccl_comm *rccl;  // != nullptr: block sums are all-reduced over the ranks in HBM, on the context's stream
 };
-// the partial block sums of this rank -> the sums over all ranks, in place, before they are read back.  Issued even after a
-// local launch error (st): the other ranks are inside the same collective and must not be left waiting for this one.
-zigz_status reduce_over_ranks(GpuRadix *g, unsigned long long *d_sums, size_t n, zigz_status st) {
-    if (!g->rccl) return st;
-    const int rc = zigz_rccl_allreduce_u64_dev(g->rccl, (uint64_t *)d_sums, n, g->ctx->stream);
-    if (st != ZIGZ_OK) return st;
+// The sums a data pass has just produced in d_sums[0, n) -> `out`.  Sharded over RCCL they are first all-reduced in place, on
+// the context's stream -- together with word n, the number of ranks whose local pass failed (st != OK: this rank adds 1) -- so
+// the collective is issued on EVERY rank whatever happened locally, and all ranks learn of a failure in the same collective:
+// the failing rank returns its own error, the others ZIGZ_ERR_COMM, and radix_run then skips the remaining passes on all of
+// them alike (their collectives stay matched).  The wait behind the collective has the communicator's deadline: a peer that
+// never enters it costs an abort and ZIGZ_ERR_COMM here, not a hang (RCCL has no timeout of its own).
+zigz_status sums_out(GpuRadix *g, unsigned long long *d_sums, size_t n, zigz_status st, uint64_t *out) {
+    zigz_ctx *ctx = g->ctx;
+    if (!g->rccl) {
+        CHK(st);
+        return read_u64(ctx, d_sums, n, out);
+    }
+    if (st != ZIGZ_OK) (void)hipMemsetAsync(d_sums + n, 1, 1, ctx->stream);  // (the word was zeroed with the sums: now 1)
+    const int rc = zigz_rccl_allreduce_u64_dev(g->rccl, (uint64_t *)d_sums, n + 1, ctx->stream);
+    if (st != ZIGZ_OK) {
+        (void)zigz_rccl_stream_wait(g->rccl, ctx->stream);
+        return st;
+    }
     if (rc != 0) {
-        set_err(g->ctx, "sharded sumcheck: the RCCL all-reduce failed (%d)", rc);
+        set_err(ctx, "sharded sumcheck: the RCCL all-reduce could not be enqueued (%d)", rc);
+        return ZIGZ_ERR_COMM;
+    }
+    HIPCHK(ctx, hipMemcpyAsync(ctx->h_pin, d_sums, (n + 1) * 8, hipMemcpyDeviceToHost, ctx->stream));
+    if (const int w = zigz_rccl_stream_wait(g->rccl, ctx->stream)) {
+        set_err(ctx, "sharded sumcheck: the RCCL all-reduce did not complete (%d): communicator aborted", w);
+        return ZIGZ_ERR_COMM;
+    }
+    memcpy(out, ctx->h_pin, n * 8);
+    if (ctx->h_pin[n] != 0) {
+        set_err(ctx, "sharded sumcheck: another rank reported an error");
         return ZIGZ_ERR_COMM;
     }
     return ZIGZ_OK;
@@ -1075,32 +1103,42 @@ zigz_status reduce_over_ranks(GpuRadix *g, unsigned long long *d_sums, size_t n,
 zigz_status gpu_block_sums(void *user, unsigned k, uint64_t *sums) {
     GpuRadix *g = (GpuRadix *)user;
     zigz_ctx *ctx = g->ctx;
-    HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, ((size_t)1 << k) * 8, ctx->stream));
-    launch_block_sums(g->cur, g->len, g->len, log2_floor(g->len >> k), 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream);
-    CHK(reduce_over_ranks(g, ctx->d_sums, (size_t)1 << k, hipGetLastError() == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP));
-    return read_u64(ctx, ctx->d_sums, (size_t)1 << k, sums);
+    const size_t nb = (size_t)1 << k;
+    auto local = [&]() -> zigz_status {
+        HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, (nb + 1) * 8, ctx->stream));
+        launch_block_sums(g->cur, g->len, g->len, log2_floor(g->len >> k), 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        return ZIGZ_OK;
+    };
+    return sums_out(g, ctx->d_sums, nb, local(), sums);
 }
 zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k_next, uint64_t *next_sums) {
     GpuRadix *g = (GpuRadix *)user;
     zigz_ctx *ctx = g->ctx;
     const size_t nb = (size_t)1 << k, m = g->len >> k;
-    uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
-    for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(weights[b]);
-    HIPCHK(ctx, hipMemcpyAsync(g->wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
     uint32_t *d_out = g->d_outs + (g->stage & 1) * g->m0;
-    const size_t groups = radix_fold_groups(nb);
-    launch_radix_fold(g->cur, 0, m, nb, (const uint32_t *)g->wbuf, 0, g->d_part, 0, 1, ctx->stream);
-    HIPCHK(ctx, hipGetLastError());
-    if (k_next) {
-        unsigned long long *d_B2 = ctx->d_sums + ((g->stage + 1) & 1 ? 1024 : 0);
-        HIPCHK(ctx, hipMemsetAsync(d_B2, 0, ((size_t)1 << k_next) * 8, ctx->stream));
-        launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream);
-        CHK(reduce_over_ranks(g, d_B2, (size_t)1 << k_next, hipGetLastError() == hipSuccess ? ZIGZ_OK : ZIGZ_ERR_HIP));
-        CHK(read_u64(ctx, d_B2, (size_t)1 << k_next, next_sums));
-    } else {
-        launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
+    // the next stage's block sums alternate between two regions of d_sums ((1 << RADIX_MAX_K) + 1 words each: sums + the
+    // failure word of sums_out), so a stage's memset never touches words a read-back of the stage before may still copy
+    unsigned long long *d_B2 = ctx->d_sums + ((g->stage + 1) & 1 ? 2048 : 0);
+    auto local = [&]() -> zigz_status {
+        uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
+        for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(weights[b]);
+        HIPCHK(ctx, hipMemcpyAsync(g->wbuf, wst, nb * 4, hipMemcpyHostToDevice, ctx->stream));
+        const size_t groups = radix_fold_groups(nb);
+        launch_radix_fold(g->cur, 0, m, nb, (const uint32_t *)g->wbuf, 0, g->d_part, 0, 1, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
-    }
+        if (k_next) {
+            HIPCHK(ctx, hipMemsetAsync(d_B2, 0, (((size_t)1 << k_next) + 1) * 8, ctx->stream));
+            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream);
+        } else {
+            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
+        }
+        HIPCHK(ctx, hipGetLastError());
+        return ZIGZ_OK;
+    };
+    const zigz_status st = local();
+    if (k_next) CHK(sums_out(g, d_B2, (size_t)1 << k_next, st, next_sums));
+    else CHK(st);
     g->cur = d_out;
     g->len = m;
     g->stage++;
@@ -1170,7 +1208,8 @@ extern "C" zigz_status zigz_dev_sumcheck_prove_rccl(zigz_ctx *ctx, const uint32_
     if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
     if (!aligned16(d_local)) return ZIGZ_ERR_INVALID_ARGUMENT;
     const ShardComm comm{rank, world, zigz_rccl_allgather, rccl, true};
-    return sumcheck_radix_sharded(ctx, d_local, n_local, &comm, nullptr, rounds, point, final_eval, world > 1 ? rccl : nullptr);
+    // (one rank: the all-reduce is RCCL's identity, and the path is the one several ranks take)
+    return sumcheck_radix_sharded(ctx, d_local, n_local, &comm, nullptr, rounds, point, final_eval, rccl);
 }
 
 // The orchestration alone, over caller-supplied data passes (multi-process tests on CPU drive exactly the code path of
@@ -1183,6 +1222,19 @@ extern "C" zigz_status zigz_sumcheck_radix_run(const zigz_radix_ops *ops, size_t
     if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
     if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
     const ShardComm comm{rank, world, allgather, comm_user, false};
+    const RadixOps r{ops->user, ops->block_sums, ops->fold, ops->read_tail};
+    return radix_run(nullptr, r, n_local, &comm, fixed_challenges, rounds, point, final_eval);
+}
+
+// ... for data passes that return the sums over ALL ranks already (reduced inside the pass, as the RCCL passes above do)
+extern "C" zigz_status zigz_sumcheck_radix_run_reduced(const zigz_radix_ops *ops, size_t n_local, int rank, int world,
+                                                       zigz_allgather_fn allgather, void *comm_user, const uint64_t *fixed_challenges,
+                                                       uint64_t *rounds, uint64_t *point, uint64_t *final_eval) {
+    if (!ops || !ops->block_sums || !ops->fold || !ops->read_tail || !rounds || !point || !final_eval) return ZIGZ_ERR_INVALID_ARGUMENT;
+    CHK(mle_check(n_local));
+    if (world < 1 || rank < 0 || rank >= world || !is_pow2((size_t)world) || (world > 1 && !allgather)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (n_local * (size_t)world == 1) return ZIGZ_ERR_NO_VARIABLES;
+    const ShardComm comm{rank, world, allgather, comm_user, true};
     const RadixOps r{ops->user, ops->block_sums, ops->fold, ops->read_tail};
     return radix_run(nullptr, r, n_local, &comm, fixed_challenges, rounds, point, final_eval);
 }
@@ -1328,6 +1380,9 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     ctx->build_cons_sd = 0;
     ctx->build_top_perms = 0;
     if (record) ctx->kev_n = 0;
+    // the list counters of a commit job's build are read again by its openings (EvalSkip, the "group dropped" word): they are
+    // the job's; any other build on the context counts in the auxiliary pair
+    unsigned long long *const r_ctr = ref ? ctx->d_run_count : ctx->d_run_aux, *const g_ctr = ref ? ctx->d_cons_count : ctx->d_cons_aux;
     // timing mode: every launch (or bracketed group of launches) carries its own begin / end timestamps, by class
     KTime kt_store;
     auto stamp = [&](int cls, uint64_t perms) -> const KTime * {
@@ -1354,7 +1409,9 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     const bool big = npad >= RUN_MIN_LEAVES && npad <= RUN_MAX_LEAVES && ncols <= 64;
     const bool sd_ok = ctx->small_domain_mask && npad >= 1024 && ncols <= 64 && val_stride % 2 == 0 && ((uintptr_t)d_vals & 7) == 0;
     const bool run_ok = ctx->run_aware_mask && big;
-    bool cons_ok = ctx->cons_group_mask && big;
+    // (a content-addressing key packs two child list slots into RUN_NODE_BITS bits each, and a slot is sub-list * capacity +
+    // position: at npad == 2^26 a nearly full last sub-list reaches 2^26 + 2047 -- the group path stops one size short of that)
+    bool cons_ok = ctx->cons_group_mask && big && npad < RUN_MAX_LEAVES;
     unsigned gn_hinted = 0;  // (what the context learnt is filed under the hints, not under whether this build tries the group)
     for (size_t c = 0; cons_ok && c < ncols; c++) gn_hinted += (unsigned)((ctx->cons_group_mask >> c) & 1);
     if (run_ok || cons_ok) {
@@ -1434,8 +1491,8 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
     }
     // every counter this build's kernels add to, zeroed by ONE launch (three memsets are three commands in the stream)
     if (H.n || GS.n || R.n || G.n)
-        launch_zero_counters((H.n || GS.n) ? ctx->d_sd_fallbacks : nullptr, R.n ? ctx->d_run_count : nullptr,
-                             G.n ? ctx->d_cons_count : nullptr, ctx->stream);
+        launch_zero_counters((H.n || GS.n) ? ctx->d_sd_fallbacks : nullptr, R.n ? r_ctr : nullptr,
+                             G.n ? g_ctr : nullptr, ctx->stream);
     if (H.n) {
         // in a commit job the leaf digests of these columns are left out (virtual): only an opening reads one, and it
         // hashes that value itself
@@ -1490,7 +1547,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             if (keep) t.upper = (uint8_t *)mw + kept;
             t.ncols = R.n;
             for (unsigned y = 0; y < R.n; y++) t.y_of_col[R.c[y]] = (signed char)y;
-            b.r_ctr = ctx->d_run_count;
+            b.r_ctr = r_ctr;
             ctx->stats.run_aware_columns = R.n;
             ctx->stats.run_aware_dense_nodes = (uint64_t)R.n * level_nodes;
         }
@@ -1520,10 +1577,10 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
             }
             b.g_gen = ctx->cons_gen;
             ctx->cons_gen += top + 1;
-            b.g_ctr = ctx->d_cons_count;
+            b.g_ctr = g_ctr;
             b.g_has_slabs = whole || ctx->caps.g_slabs;
             t.g_ncols = G.n;
-            t.g_dropped = ctx->d_cons_count + 8;
+            t.g_dropped = g_ctr + 8;
             for (unsigned k = 0; k < G.n; k++) t.g_j_of_col[G.c[k]] = (signed char)k;
             if (virt)
                 for (unsigned k = 0; k < GS.n; k++) t.g_sd_mask |= 1ull << GS.c[k];
@@ -1544,7 +1601,7 @@ static zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val
         if (GS.n && b.g_has_slabs) {  // only if the group was dropped: its small-domain members' levels 0 and 1 by table
             const ColMap gs = slab_map(GS);
             launch_keccak_small_l01(d_vals, val_stride, n_values, npad, t.slab, stride, GS, ctx->d_sd_tables, ctx->d_sd_fallbacks + 1,
-                                    (uint32_t *)sd_todo + sd_todo_words(npad, H.n), ctx->stream, stamp(3, 0), !virt, ctx->d_cons_count + 8,
+                                    (uint32_t *)sd_todo + sd_todo_words(npad, H.n), ctx->stream, stamp(3, 0), !virt, g_ctr + 8,
                                     &gs);
         }
     }
@@ -1753,6 +1810,8 @@ struct zigz_commit_job {
     uint64_t m_small, m_run, m_cons;
     bool m_whole;
     uint64_t run_cols, run_dense, sd_cols, cons_hinted, cons_levels_nodes, cons_sd, perms0;
+    bool no_eval_skip;  // built without its structure passes (option debug_skip 2, measurement only): the "column changed" words
+                        // were never written, so the eval must not take them for "constant"
 };
 
 // enqueues the builds of a job, the gather of its roots + counters into ONE pinned buffer, and the "built" event
@@ -1795,6 +1854,7 @@ static zigz_status job_build(zigz_commit_job *job) {
     job->cons_levels_nodes = ctx->build_cons_levels_nodes;
     job->cons_sd = ctx->build_cons_sd;
     job->perms0 = (uint64_t)ncols * (2 * job->N - 1) - job->sd_cols * (job->N + job->N / 2);
+    job->no_eval_skip = ctx->debug_skip == 2;
     return ZIGZ_OK;
 }
 
@@ -1972,8 +2032,9 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         // columns the run-aware structure pass of THIS job found constant are not read again (EvalSkip, kernels.hpp): of the 43
         // witness columns of a program that uses a handful of registers, most
         EvalSkip skip;
-        if (job->tree.lists && job->run_cols && job->col_stride >= job->N) {
-            skip.changed = ctx->d_run_count + RUN_CHANGED;
+        if (job->tree.lists && job->run_cols && job->col_stride >= job->N && !job->no_eval_skip) {
+            skip.changed = ctx->d_run_count + RUN_CHANGED;  // (the job's own counters: no other build on the context adds to them)
+            ctx->stats.eval_constant_columns = job->const_cols;  // (what dev_eval_radix sizes its launch by: this job's count)
             memcpy(skip.y_of_col, job->tree.y_of_col, sizeof(skip.y_of_col));
         }
         CHK(timed_begin(ctx, 4));

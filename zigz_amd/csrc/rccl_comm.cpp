@@ -14,6 +14,7 @@
 #include <hip/hip_runtime.h>
 #include <rccl/rccl.h>
 #include <string.h>
+#include <time.h>
 
 #include <mutex>
 #include <new>
@@ -66,7 +67,46 @@ struct zigz_rccl_comm {
     hipStream_t stream;
     uint8_t *d_send, *d_recv;  // max_bytes, world * max_bytes
     uint8_t *h_pin;            // (1 + world) * max_bytes, page-locked
+    double timeout_s;          // how long a wait for a collective may take before the communicator is aborted
+    bool dead;                 // aborted (a wait ran out, or a collective could not be enqueued): every later call fails at once
 };
+
+// RCCL has no timeout of its own: a rank that never enters a collective leaves its peers' kernels spinning for ever.  Every
+// wait behind a collective therefore polls the stream with a deadline; when it passes, the communicator is aborted (the
+// device-side kernels see the abort flag and exit) and the call fails with a nonzero code instead of hanging.
+static void comm_abort(zigz_rccl_comm *c) {
+    if (c->dead) return;
+    c->dead = true;
+    const Api *a = api();
+    if (a && a->CommAbort && c->comm) {
+        (void)a->CommAbort(c->comm);
+        c->comm = nullptr;  // (CommAbort frees it)
+    }
+}
+static int wait_stream(zigz_rccl_comm *c, hipStream_t s) {
+    timespec t0;
+    clock_gettime(CLOCK_MONOTONIC, &t0);
+    long ns = 2000;
+    for (;;) {
+        const hipError_t e = hipStreamQuery(s);
+        if (e == hipSuccess) return 0;
+        if (e != hipErrorNotReady) {
+            (void)hipGetLastError();
+            comm_abort(c);
+            return 6;
+        }
+        timespec t1;
+        clock_gettime(CLOCK_MONOTONIC, &t1);
+        if ((double)(t1.tv_sec - t0.tv_sec) + 1e-9 * (double)(t1.tv_nsec - t0.tv_nsec) > c->timeout_s) {
+            comm_abort(c);
+            (void)hipStreamSynchronize(s);  // (the aborted kernels drain)
+            return 7;
+        }
+        timespec ts{0, ns};
+        nanosleep(&ts, nullptr);
+        if (ns < 100000) ns += ns / 2;
+    }
+}
 
 static_assert(ZIGZ_RCCL_UNIQUE_ID_BYTES == NCCL_UNIQUE_ID_BYTES, "the id crosses the ABI as plain bytes");
 
@@ -106,6 +146,7 @@ extern "C" zigz_status zigz_rccl_comm_create(int device, const uint8_t id[ZIGZ_R
     c->rank = rank;
     c->world = world;
     c->max_bytes = (max_bytes + 63) & ~(size_t)63;
+    c->timeout_s = 120.0;
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess ||
         hipMalloc((void **)&c->d_send, c->max_bytes) != hipSuccess ||
         hipMalloc((void **)&c->d_recv, c->max_bytes * (size_t)world) != hipSuccess ||
@@ -129,13 +170,17 @@ extern "C" int zigz_rccl_allgather(void *user, const void *send, size_t bytes, v
     zigz_rccl_comm *c = (zigz_rccl_comm *)user;
     const Api *a = api();
     if (!c || !a || !send || !recv || bytes == 0 || bytes > c->max_bytes) return 1;
+    if (c->dead) return 8;
     if (hipSetDevice(c->device) != hipSuccess) return 2;
     memcpy(c->h_pin, send, bytes);
     uint8_t *h_recv = c->h_pin + c->max_bytes;
     if (hipMemcpyAsync(c->d_send, c->h_pin, bytes, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 3;
-    if (a->AllGather(c->d_send, c->d_recv, bytes, ncclInt8, c->comm, c->stream) != ncclSuccess) return 4;
+    if (a->AllGather(c->d_send, c->d_recv, bytes, ncclInt8, c->comm, c->stream) != ncclSuccess) {
+        comm_abort(c);  // (the peers that did enqueue theirs run into their own deadline)
+        return 4;
+    }
     if (hipMemcpyAsync(h_recv, c->d_recv, bytes * (size_t)c->world, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 5;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 6;
+    if (const int w = wait_stream(c, c->stream)) return w;
     memcpy(recv, h_recv, bytes * (size_t)c->world);
     return 0;
 }
@@ -144,12 +189,16 @@ extern "C" int zigz_rccl_allgather(void *user, const void *send, size_t bytes, v
 extern "C" int zigz_rccl_allreduce_u64(zigz_rccl_comm *c, const uint64_t *send, size_t n, uint64_t *recv) {
     const Api *a = api();
     if (!c || !a || !send || !recv || n == 0 || n * 8 > c->max_bytes) return 1;
+    if (c->dead) return 8;
     if (hipSetDevice(c->device) != hipSuccess) return 2;
     memcpy(c->h_pin, send, n * 8);
     if (hipMemcpyAsync(c->d_send, c->h_pin, n * 8, hipMemcpyHostToDevice, c->stream) != hipSuccess) return 3;
-    if (a->AllReduce(c->d_send, c->d_send, n, ncclUint64, ncclSum, c->comm, c->stream) != ncclSuccess) return 4;
+    if (a->AllReduce(c->d_send, c->d_send, n, ncclUint64, ncclSum, c->comm, c->stream) != ncclSuccess) {
+        comm_abort(c);
+        return 4;
+    }
     if (hipMemcpyAsync(c->h_pin, c->d_send, n * 8, hipMemcpyDeviceToHost, c->stream) != hipSuccess) return 5;
-    if (hipStreamSynchronize(c->stream) != hipSuccess) return 6;
+    if (const int w = wait_stream(c, c->stream)) return w;
     memcpy(recv, c->h_pin, n * 8);
     return 0;
 }
@@ -158,8 +207,29 @@ extern "C" int zigz_rccl_allreduce_u64(zigz_rccl_comm *c, const uint64_t *send, 
 extern "C" int zigz_rccl_allreduce_u64_dev(zigz_rccl_comm *c, uint64_t *d_words, size_t n, void *hip_stream) {
     const Api *a = api();
     if (!c || !a || !d_words || n == 0) return 1;
-    if (a->AllReduce(d_words, d_words, n, ncclUint64, ncclSum, c->comm, (hipStream_t)hip_stream) != ncclSuccess) return 4;
+    if (c->dead) return 8;
+    if (hipSetDevice(c->device) != hipSuccess) return 2;
+    if (a->AllReduce(d_words, d_words, n, ncclUint64, ncclSum, c->comm, (hipStream_t)hip_stream) != ncclSuccess) {
+        comm_abort(c);
+        return 4;
+    }
     return 0;
+}
+
+// The wait that belongs to zigz_rccl_allreduce_u64_dev: until `hip_stream` has drained or the communicator's deadline passes
+// (then the communicator is aborted and the call returns nonzero -- the caller's stream is usable again, the comm is not).
+extern "C" int zigz_rccl_stream_wait(zigz_rccl_comm *c, void *hip_stream) {
+    if (!c) return 1;
+    if (hipSetDevice(c->device) != hipSuccess) return 2;
+    return wait_stream(c, (hipStream_t)hip_stream);
+}
+extern "C" void zigz_rccl_comm_set_timeout(zigz_rccl_comm *c, double seconds) {
+    if (c && seconds > 0) c->timeout_s = seconds;
+}
+extern "C" void zigz_rccl_comm_abort(zigz_rccl_comm *c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    comm_abort(c);
 }
 
 extern "C" int zigz_rccl_comm_rank(const zigz_rccl_comm *c) { return c ? c->rank : -1; }

@@ -222,6 +222,21 @@ class RcclComm:
             raise RuntimeError("zigz_rccl_allreduce_u64 failed (%d)" % rc)
         return out
 
+    def all_reduce_u64_dev(self, ctx, d_words, n):
+        """zigz_rccl_allreduce_u64_dev: n u64 words already in HBM, summed over the ranks in place on the context's stream,
+        then the deadline wait that belongs to it (zigz_rccl_stream_wait)."""
+        from . import _ffi
+        s = _ffi.lib.zigz_ctx_get_stream(ctx.h)
+        rc = _ffi.lib.zigz_rccl_allreduce_u64_dev(self.h, d_words, n, s)
+        if rc == 0:
+            rc = _ffi.lib.zigz_rccl_stream_wait(self.h, s)
+        if rc != 0:
+            raise RuntimeError("zigz_rccl_allreduce_u64_dev failed (%d)" % rc)
+
+    def set_timeout(self, seconds):
+        from . import _ffi
+        _ffi.lib.zigz_rccl_comm_set_timeout(self.h, float(seconds))
+
     def close(self):
         if self.h:
             from . import _ffi
@@ -240,10 +255,12 @@ def sumcheck_prove_row_sharded_radix(ctx, d_local, n_local, dist, allgather=None
     return ctx.dev_sumcheck_prove_sharded(d_local, n_local, dist.get_rank(), dist.get_world_size(), cb)
 
 
-def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
+def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None, reduced=False):
     """The C++ orchestration of the radix sumcheck (zigz_sumcheck_radix_run) over Python data passes:
     py_ops.block_sums(k) -> 2^k ints, py_ops.fold(k, weights, k_next) -> 2^k_next ints or None, py_ops.read_tail(m) -> m
-    ints.  Used by the multi-process CPU tests to drive the exchange logic of the sharded prover without a GPU."""
+    ints.  Used by the multi-process CPU tests to drive the exchange logic of the sharded prover without a GPU.
+    reduced: the passes return the sums over ALL ranks (they reduce them in a collective of their own, as the RCCL passes of
+    zigz_dev_sumcheck_prove_rccl do): zigz_sumcheck_radix_run_reduced, no exchange per stage."""
     import ctypes as C
     from . import _ffi
     world = dist.get_world_size() if dist is not None else 1
@@ -289,7 +306,8 @@ def sumcheck_radix_run(py_ops, n_local, dist, challenges=None, allgather=None):
     ch = None
     if challenges is not None:
         ch = (C.c_uint64 * max(nv, 1))(*[int(c) for c in challenges])
-    rc = _ffi.lib.zigz_sumcheck_radix_run(C.byref(ops), n_local, rank, world, cb, comm_user, ch, r, pt, C.byref(fe))
+    run = _ffi.lib.zigz_sumcheck_radix_run_reduced if reduced else _ffi.lib.zigz_sumcheck_radix_run
+    rc = run(C.byref(ops), n_local, rank, world, cb, comm_user, ch, r, pt, C.byref(fe))
     if err:
         raise err[0]
     if rc != 0:
