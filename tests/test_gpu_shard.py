@@ -167,8 +167,26 @@ def test_rccl_comm_one_rank_on_the_gpu():
         r0, p0, fe0 = O.sumcheck_prove(P, table)
         r, p, fe = shard.sumcheck_prove_row_sharded_radix(ctx, d, 1 << 16, None, comm)    # the hook form
         assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
-        r, p, fe = ctx.dev_sumcheck_prove_rccl(d, 1 << 16, comm)                           # the native form
+        # the in-place device all-reduce on the context's stream (with one rank: RCCL's identity), called directly ...
+        # (torch only to put raw 64-bit words into HBM and read them back: the ABI's uploads narrow to field elements)
+        import torch
+        hw = np.concatenate([words, np.array([0], dtype=np.uint64)])
+        tw = torch.from_numpy(hw.view(np.int64).copy()).to("cuda:0")
+        torch.cuda.synchronize()
+        comm.all_reduce_u64_dev(ctx, tw.data_ptr(), 1025)
+        assert np.array_equal(tw.cpu().numpy().view(np.uint64), hw)
+        del tw
+        # ... and through the native form, which now issues it at world 1 as well: every radix stage's block sums + the
+        # failure word go through ncclAllReduce on the context's stream and the deadline wait behind it (two stages at 2^22)
+        r, p, fe = ctx.dev_sumcheck_prove_rccl(d, 1 << 16, comm)
         assert np.array_equal(r, r0) and np.array_equal(p, p0) and fe == fe0
+        big = O.splitmix64_field(4243, 1 << 22)
+        db = ctx.dev_alloc((1 << 22) * 4)
+        ctx.upload(big, db)
+        rb, pb, feb = ctx.dev_sumcheck_prove(db, 1 << 22)
+        r, p, fe = ctx.dev_sumcheck_prove_rccl(db, 1 << 22, comm)
+        assert np.array_equal(r, rb) and np.array_equal(p, pb) and fe == feb
+        ctx.dev_free(db)
         t0 = time.perf_counter()
         for _ in range(200):
             comm.all_gather(b"x" * 8192)
