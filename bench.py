@@ -321,6 +321,11 @@ def main():
                     "shared-memory mailbox (zigz_shm_comm: 2-5 us per exchange between the ranks of one node); rccl = RCCL bound "
                     "natively (zigz_rccl_comm, no torch in the loop: ~60 us per exchange of <= 8 KiB, for ranks on several nodes).  "
                     "rccl needs one GPU per rank")
+    ap.add_argument("--slots", type=int, default=-1, help="GPU slots: contexts (HIP stream + tree / list workspaces) the lanes share; a "
+                    "lane holds one only for its proof's GPU phases (begin -> roots -> challenges -> open_all -> end), so proofs in "
+                    "flight are not bounded by HBM for workspaces.  -1 (default): lanes / 5 + 2, between 4 and 16; 0: a context per "
+                    "lane (round 3's form: the build overlaps the proof's own transcript, and every proof in flight holds its "
+                    "workspaces throughout)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
     ap.add_argument("--merkle", choices=["cons", "struct", "regs", "all", "tables", "dense"], default="cons",
                     help="Merkle build of the 43 columns (identical trees and proofs in every mode).  cons (the product's default): "
@@ -470,16 +475,30 @@ def main():
     # 8 transcripts per server are in lock step; a tenth more proofs than sponge slots keeps the slots full while a proof is in
     # its GPU phases (roots, challenges, openings: 2-4 of its 40-odd ms): 10 x 8 slots, 88 lanes -- 2.00-2.03 G steps/s against
     # 1.95-1.98 G with 80 on one box, 14.0 of 16 CPUs busy (96 / 104 lanes: 2.02 / 2.05 G at 15.0 / 15.7 CPUs)
-    B = 1 if shard else (args.batch if args.batch > 0 else (8 * servers + max(1, 8 * servers // 10) if servers else default_batch(ncpu)))
+    use_slots_ = not shard and args.slots != 0
+    # lanes: with slots a lane's GPU phases are no longer underneath its own transcript, so a sixth more proofs than sponge slots
+    # keeps the slots full (a tenth with a context per lane)
+    B = 1 if shard else (args.batch if args.batch > 0 else
+                         (8 * servers + max(1, 8 * servers // (6 if use_slots_ else 10)) if servers else default_batch(ncpu)))
+
+    def lane_bytes(nv_l):   # what a lane holds between its proofs: the 43 resident columns
+        return 43 * 4 * (1 << nv_l) + (32 << 20)
+
+    def slot_bytes(nv_l, worst=True):  # what a GPU slot's workspaces grow to: lists + digests in list order (0.45 GiB at 2^20 on the
+        # bench trace, measured), slabs for a dropped group and longer lists on a trace that never loops (2.2 GiB)
+        return int((2.4 if worst else 0.6) * (1 << 30) * (1 << max(nv_l - 20, 0)))
     hbm_free = None
-    if not shard and args.batch <= 0:  # a proof in flight holds ~3.5 GiB of HBM at 2^20 (trees, lists, witness): stay inside it
+    if not shard and args.batch <= 0:
         probe = zigz_amd.Context(local_rank)
         hbm_free = probe.mem_info()[0]
         probe.close()
-        # (~0.6 GiB at 2^20 on the bench trace with the digests in list order; a trace that does not loop needs ~2.3 GiB --
-        # slabs for the dropped group, longer lists -- and the legs below run such traces on the same lanes: budget for that)
-        per_lane = int(2.4 * (1 << 30) * (1 << max(args.nv - 20, 0)))
-        B = max(1, min(B, int(hbm_free * 0.9) // per_lane))
+        if use_slots_:
+            k_guess = args.slots if args.slots > 0 else max(4, min(16, B // 5 + 2))
+            B = max(1, min(B, (int(hbm_free * 0.9) - k_guess * slot_bytes(args.nv)) // lane_bytes(args.nv)))
+        else:
+            # (a context per lane: ~0.6 GiB at 2^20 on the bench trace with the digests in list order; a trace that does not loop
+            # needs ~2.3 GiB -- slabs for the dropped group, longer lists -- and the legs below run such traces on the same lanes)
+            B = max(1, min(B, int(hbm_free * 0.9) // (slot_bytes(args.nv) + lane_bytes(args.nv))))
     blocking = B + servers + 2 > ncpu  # more threads than cores: wait for the GPU asleep, not spinning
     if os.environ.get("ZIGZ_BENCH_BLOCKING_SYNC"):
         blocking = os.environ["ZIGZ_BENCH_BLOCKING_SYNC"] == "1"
@@ -489,35 +508,62 @@ def main():
             sys.stderr.write("bench.py: zigz_device_set_blocking_sync -> %d (threads will spin while waiting)\n" % rc)
             blocking = False
 
-    class Lane:  # one trace + its own context (HIP stream, workspaces) + resident witness
-        def __init__(self, k, nv_l=None, prog=None):
+    # ---- GPU slots (zigz_amd/csrc/host/zigz_host.hpp: GpuSlots).  A proof needs the GPU for a few milliseconds and a sponge
+    # slot for tens: the lanes therefore share K contexts (stream + tree / list workspaces each) and a lane holds one only
+    # between the end of its transcript's step 5 and the end of its openings; between proofs a lane holds its resident
+    # witness and nothing else.  Proofs in flight are then bounded by host cores and witness bytes, not by HBM for
+    # workspaces (21 lanes at 2^24 with a context per lane).  --slots 0: a context per lane, as in round 3.
+    use_slots = use_slots_
+    slots = None
+    setup_ctx = zigz_amd.Context(local_rank)  # allocations, witness uploads (set-up; its workspaces are given back after it)
+
+    def make_slots(k):
+        sl = host.Slots(local_rank, k)
+        return sl
+
+    def slot_count(nl, nv_l):
+        """Slots for nl lanes at 2^nv_l: a lane spends ~1/10 of its cycle in a slot (2-4 of ~42 ms at 2^20; the ratio holds
+        at the other sizes, GPU phase and sponge both scale with the trace); twice that keeps queueing short, and a slot is
+        cheap while it is not needed (the most recently released one is handed out first: unused ones never grow)."""
+        if args.slots > 0:
+            return args.slots
+        return max(4, min(16, nl // 5 + 2))
+
+    class Lane:  # one trace + its resident witness; proves through the shared GPU slots (or, --slots 0 / --mode shard, a context of its own)
+        def __init__(self, k, nv_l=None, prog=None, pin=True):
             self.nv = nv if nv_l is None else nv_l
             self.N = 1 << self.nv
-            self.ctx = zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
+            self.ctx = None if use_slots else zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
+            c = setup_ctx if use_slots else self.ctx
             # synthetic RV64I ADD/XOR loop (SURVEY s8d config 3); every lane / rank proves a different trace
             self.prog = prog if prog is not None else \
                 programs.add_xor_loop((self.N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
             self.trace = host.Trace(self.prog, 0x1000, None, 2 * self.N)  # [1/6] VM execution: outside the timed region
             assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
-            self.d_cols = self.ctx.dev_alloc(43 * self.N * 4)
-            self.trace.pin(self.ctx)  # page-locked trace records (48 B per step): uploads run at PCIe rate
-            self.trace.witness_to_device(self.ctx, self.d_cols, self.N)   # [2/6] witness resident in HBM before timing
-            self.ctx.synchronize()
-            self.ctx.release_workspaces()  # (the upload's staging, 48 B per step, is not needed while the witness stays resident)
+            self.d_cols = c.dev_alloc(43 * self.N * 4)
+            if pin:
+                self.trace.pin(c)  # page-locked trace records (48 B per step): uploads run at PCIe rate
+            self.trace.witness_to_device(c, self.d_cols, self.N)   # [2/6] witness resident in HBM before timing
+            c.synchronize()
+            if not use_slots:
+                c.release_workspaces()  # (the upload's staging, 48 B per step, is not needed while the witness stays resident)
             self.proof = None
             self.up_ctx = None
             self.d_next = None
             self.k = k
-            self.timing = False     # per-launch timestamps on the next proof?
+            self.want_log = False   # slots: fetch the launch log of every proof (the roofline leg)
+            self.logs = []
+            self.timing = False     # per-launch timestamps on the next proof?  (--slots 0)
             self.timing_every = 0   # 0: leave the context's timing mode alone
             self.proofs_done = 0
 
         def retrace(self, prog):  # the same lane on another program of the same size (overwrites the resident witness)
+            c = setup_ctx if use_slots else self.ctx
             self.prog = prog
             self.trace = host.Trace(prog, 0x1000, None, 2 * self.N)
             assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
-            self.trace.witness_to_device(self.ctx, self.d_cols, self.N)
-            self.ctx.synchronize()
+            self.trace.witness_to_device(c, self.d_cols, self.N)
+            c.synchronize()
 
         def drop_upload_context(self):  # (after the PCIe-inclusive leg: the second context + stream of the lane go away)
             if self.up_ctx is not None:
@@ -529,13 +575,21 @@ def main():
 
         def close(self):
             self.drop_upload_context()
+            if self.d_cols is not None:
+                (setup_ctx if use_slots else self.ctx).dev_free(self.d_cols)
+                self.d_cols = None
             if self.ctx is not None:
-                self.ctx.dev_free(self.d_cols)
                 self.ctx.close()
                 self.ctx = None
 
         def prove(self):
-            if self.timing_every:  # per-launch timestamps on every timing_every-th proof of this lane (see the timed region)
+            if use_slots:
+                self.proof, st, log = self.trace.prove_slots(slots, self.d_cols, self.N, want_log=self.want_log)
+                if log:
+                    self.logs.append(log)
+                st["_timed"] = 1 if self.want_log else 0
+                return st, host.last_timings()
+            if self.timing_every:  # per-launch timestamps on every timing_every-th proof of this lane
                 self.proofs_done += 1
                 on = (self.proofs_done + self.k) % self.timing_every == 0
                 if on != self.timing:
@@ -556,9 +610,14 @@ def main():
             return r
 
         def upload_and_prove(self):  # PCIe-inclusive: one upload of the compact trace (48 B per step) + one run of the witness
-            # kernels per proof, inside the loop -- pipelined as a service would: while this proof runs, the NEXT proof's trace
-            # crosses PCIe on a second stream into the lane's other column buffer (with 40 proofs in flight an upload queued in
-            # front of its own proof adds its wait for the link to that proof's latency: 483 M steps/s instead of ~640)
+            # kernels per proof, inside the loop.  With slots: inside the proof's GPU slot, into a column buffer the slot owns
+            # (upload, expansion and builds on the slot's stream; the other slots' kernels run underneath the copy) -- a lane
+            # then needs no resident witness at all.  --slots 0: pipelined as round 3 did -- while this proof runs, the NEXT
+            # proof's trace crosses PCIe on a second stream into the lane's other column buffer.
+            if use_slots:
+                self.proof, st, _ = self.trace.prove_slots(slots, None, 0)
+                st["_timed"] = 0
+                return st, host.last_timings()
             if self.up_ctx is None:
                 self.up_ctx = zigz_amd.Context(local_rank)
                 self.d_next = self.up_ctx.dev_alloc(43 * N * 4)
@@ -594,12 +653,20 @@ def main():
             allgather_hook = host.make_allgather(dist)
         else:
             allgather_hook = make_comm("shard", 120.0)
+    if use_slots:
+        slots = make_slots(slot_count(B, nv))
     lanes = [Lane(k) for k in range(B)]
+    setup_ctx.release_workspaces()
     pool = ThreadPoolExecutor(max_workers=B)
 
+    def all_contexts():
+        if use_slots:
+            return slots.contexts() if slots is not None else []
+        return [l.ctx for l in lanes if l.ctx is not None]
+
     def sync_all():
-        for l in lanes:
-            l.ctx.synchronize()
+        for c in all_contexts():
+            c.synchronize()
         if torch is not None:
             if backend == "nccl":
                 torch.cuda.synchronize()
@@ -660,16 +727,16 @@ def main():
         run_step()
     # Per-launch kernel timestamps (HIP events on every launch's own stream) cost host CPU -- two events per launch, collected
     # per proof, and their completion handlers on the runtime's event thread: ~0.5 ms of the ~8 ms of CPU per proof on a
-    # host-bound box.  In the timed region every lane therefore carries them on every 4th of its proofs, the lanes taking
-    # turns (lane k on proofs k, k + 4, ...: at any moment a quarter of the proofs in flight are timed, and all lanes cost the
-    # same -- timing every 8th LANE instead made lanes of unequal cost and a tail: 1.72-1.75 G against 1.77-1.83 G with all
-    # lanes timed).  `roofline` is computed from those launches (`timed_launches_sampled`); ZIGZ_BENCH_TIMING_EVERY=1 times
-    # every proof, a large value none.
-    timing_every = max(1, int(os.environ.get("ZIGZ_BENCH_TIMING_EVERY", "4")))
+    # host-bound box.  THE timed region therefore carries none (VERDICT r3 #3d); `roofline` comes from a short leg right after it
+    # -- the same lanes, the same workload, every launch of every proof timed -- whose own rate stands beside it
+    # (`roofline.leg_value`).  With a context per lane (--slots 0) ZIGZ_BENCH_TIMING_EVERY = n times every n-th proof of each
+    # lane inside the timed region instead, as round 3 did.
+    timing_every = int(os.environ.get("ZIGZ_BENCH_TIMING_EVERY", "0")) if not use_slots else 0
     for k, l in enumerate(lanes):
-        l.timing_every = timing_every
-        l.timing = timing_every == 1
-        l.ctx.enable_timing(l.timing)
+        if l.ctx is not None and timing_every:
+            l.timing_every = timing_every
+            l.timing = timing_every == 1
+            l.ctx.enable_timing(l.timing)
     if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import thread_cpu
@@ -693,10 +760,51 @@ def main():
     trace_steps, trace_lookups, prog = lanes[0].trace.num_steps, lanes[0].trace.num_lookups, lanes[0].prog
     proof = lanes[0].proof.tobytes()  # (the legs below reuse the borrowed buffers and, at the end, the lanes' traces)
 
+    # ---- the roofline leg: the timed region once more, shorter, with every launch of every proof carrying its own begin / end
+    # on ONE time axis (zigz_ctx_set_epoch / zigz_ctx_launch_log: microseconds since a common epoch, comparable across the
+    # slots' streams).  What is taken from it per kernel class is the UNION of its launches' intervals -- the time during which
+    # at least one launch of the class was on the GPU -- next to their count and the sum of their durations: dozens of proofs
+    # share the chip, so the sum exceeds the wall clock, the union cannot (VERDICT r3 #1b).
+    def union_us(iv):
+        if not iv:
+            return 0.0
+        iv = sorted(iv)
+        tot, cs, ce = 0.0, iv[0][0], iv[0][1]
+        for a, b in iv[1:]:
+            if a > ce:
+                tot += ce - cs
+                cs, ce = a, b
+            elif b > ce:
+                ce = b
+        return tot + (ce - cs)
+
+    roof_leg = None
+    if use_slots and not shard:
+        try:
+            ctxs = slots.contexts()
+            ctxs[0].set_epoch()
+            for c in ctxs[1:]:
+                c.set_epoch(ctxs[0])
+            for c in ctxs:
+                c.enable_timing(True)
+            for l in lanes:
+                l.want_log, l.logs = True, []
+            steps_r = max(2, min(args.steps, 4))
+            dt_r, acc_r, _ = timed(steps_r)
+            recs = [r for l in lanes for lg in l.logs for r in lg]
+            roof_leg = {"dt": dt_r, "steps": steps_r, "acc": acc_r, "recs": recs}
+        except Exception as e:  # noqa: BLE001
+            sys.stderr.write("bench.py: roofline leg failed: %r\n" % (e,))
+        finally:
+            for c in slots.contexts():
+                c.enable_timing(False)
+            for l in lanes:
+                l.want_log, l.logs = False, []
+
     # ---- legs outside the timed region (same run, same resident data).  Each runs under a guard: a leg that fails (out of
     # HBM on an unusual box, say) is recorded in detail.leg_errors and left out; the line with `value` goes out regardless.
     extras = not args.no_extras and not shard
-    solo = kern = None
+    solo = kern = gpu_one = None
     legs = {}         # name -> {"dt", "steps", "trace_steps", ...}: what is reduced over the ranks below
     leg_errors = {}
     self_check = {}
@@ -707,7 +815,7 @@ def main():
             r = fn()
             if rank == 0:  # (one progress line per leg on stderr: a long default run is not silent)
                 try:
-                    free_gib = lanes[0].ctx.mem_info()[0] / 2.0**30 if lanes and lanes[0].ctx is not None else float("nan")
+                    free_gib = setup_ctx.mem_info()[0] / 2.0**30
                 except Exception:
                     free_gib = float("nan")
                 sys.stderr.write("bench.py: leg %s: %.1f s, %.0f GiB of HBM free\n" % (name, time.perf_counter() - t_leg, free_gib))
@@ -719,14 +827,14 @@ def main():
             leg_errors[name] = repr(e)[:200]
             sys.stderr.write("bench.py: leg %s failed: %r\n" % (name, e))
             try:  # what the backend recorded (the failing HIP call, if any)
-                msgs = {zigz_amd._ffi.lib.zigz_last_error(l.ctx.h).decode(errors="replace") for l in lanes if l.ctx is not None}
+                msgs = {zigz_amd._ffi.lib.zigz_last_error(c.h).decode(errors="replace") for c in all_contexts()}
                 sys.stderr.write("bench.py:   backend: %s\n" % "; ".join(sorted(m for m in msgs if m))[:600])
             except Exception:
                 pass
             try:
-                for l in lanes:
-                    l.ctx.synchronize()
-                    l.ctx.release_workspaces()
+                for c in all_contexts():
+                    c.synchronize()
+                    c.release_workspaces()
             except Exception:
                 pass
             return None
@@ -735,17 +843,24 @@ def main():
         def leg_solo():
             ksolo = max(3, min(args.steps, 8))
             run_step(which=lanes[:1])
-            dts, accs, _ = timed(ksolo, which=lanes[:1])           # one proof at a time on the GPU
+            for c in all_contexts():  # (per-launch timestamps: this leg's stats feed detail.single_proof)
+                c.enable_timing(True)
+            try:
+                dts, accs, _ = timed(ksolo, which=lanes[:1])       # one proof at a time on the GPU
+            finally:
+                for c in all_contexts():
+                    c.enable_timing(False)
             r = {"dt": dts, "n": ksolo, "acc": accs}
             if rank == 0:  # Prover.prove from program bytes: VM + compact trace upload + witness kernels + proof + serialisation
-                host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
+                host.prove(setup_ctx, lanes[0].prog, 0x1000, None, 2 * N)
                 t0 = time.perf_counter()
                 for _ in range(2):
-                    host.prove(lanes[0].ctx, lanes[0].prog, 0x1000, None, 2 * N)
+                    host.prove(setup_ctx, lanes[0].prog, 0x1000, None, 2 * N)
                 r["from_program_ms"] = (time.perf_counter() - t0) / 2 * 1e3
                 t0 = time.perf_counter()
                 host.Trace(lanes[0].prog, 0x1000, None, 2 * N)
                 r["vm_ms"] = (time.perf_counter() - t0) * 1e3
+            setup_ctx.release_workspaces()
             return r
         solo = guard("single_proof", leg_solo)
 
@@ -754,49 +869,69 @@ def main():
         # with the hash launches left out; with the structure passes left out too (option debug_skip: wrong trees, measurement
         # only).  The kernel-time shares of `roofline` sum launch durations, which count a small kernel's wait for a wave slot
         # next to 80 proofs' hash waves as its time; these are wall-clock differences.
-        def gpu_bound(skip):
+        def gpu_bound(skip, nl=28, timing=False):
+            """nl worker threads, each: take a context (a GPU slot, or its lane's own), commit job on a lane's resident
+            columns -- begin, roots, 43 evals + openings, end -- back to back, no transcript.  timing: per-launch timestamps
+            (one worker: the launches of ONE proof at a time on a GPU that stays busy, i.e. at its clocks)."""
             regs, small = 0x7fffffff << 2, (1 << 1) | (0x3f << 33) | (1 << 42)
             want = {"small_domain_mask": small, "run_aware_mask": regs | (3 << 40), "cons_group_mask": 1 | (1 << 1) | (0x7f << 33) | (1 << 42)}
             import numpy as np
             rng_p = np.random.default_rng(4242)
             pts = rng_p.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
-            gl = lanes[:min(len(lanes), 28)]  # (28 lanes keep the GPU full; with all of them active at once -- in a proof only a
-            # tenth are in their GPU phases at any time -- the streams get in each other's way: 0.57 instead of 0.49-0.50 ms)
-            saved = [{k: l.ctx.get_option(k) for k in want} for l in gl]
+            gl = lanes[:min(len(lanes), nl)]  # (28 workers keep the GPU full; more get in each other's way: 0.57 against 0.49 ms)
+            cs = all_contexts() if use_slots else [l.ctx for l in gl]
+            saved = [{k: c.get_option(k) for k in want} for c in cs]
             iters = max(4, min(2 * args.steps, 20))
+            acc_g = {}
 
             def once(l):
-                job = zigz_amd.CommitJob(l.ctx, d_cols=l.d_cols, ncols=43, nv=nv, col_stride=N)
+                if use_slots:
+                    with slots.borrow() as c:
+                        return once_on(c, l)
+                return once_on(l.ctx, l)
+
+            def once_on(c, l):
+                job = zigz_amd.CommitJob(c, d_cols=l.d_cols, ncols=43, nv=nv, col_stride=N)
                 job.roots()
                 job.open_all(pts)
                 job.end()
+                return c.stats() if timing else None
 
             def loop(l):
+                out = []
                 for _ in range(iters):
-                    once(l)
+                    out.append(once(l))
+                return out
             try:
-                for l in gl:
-                    l.ctx.enable_timing(False)
+                for c in cs:
+                    c.enable_timing(timing)
                     for k, v in want.items():
-                        l.ctx.set_option(k, v)
+                        c.set_option(k, v)
                 gather([pool.submit(once, l) for l in gl])
-                for l in gl:
-                    l.ctx.set_option("debug_skip", skip)
+                for c in cs:
+                    c.set_option("debug_skip", skip)
                 gather([pool.submit(once, l) for l in gl])
                 sync_all()
                 t0 = time.perf_counter()
-                gather([pool.submit(loop, l) for l in gl])
+                res = gather([pool.submit(loop, l) for l in gl])
                 dtg = time.perf_counter() - t0
+                for r in res:
+                    for st in r:
+                        for k, v in (st or {}).items():
+                            acc_g[k] = acc_g.get(k, 0) + v
             finally:
-                for l, sv in zip(gl, saved):
-                    l.ctx.set_option("debug_skip", 0)
+                for c, sv in zip(cs, saved):
+                    c.enable_timing(False)
+                    c.set_option("debug_skip", 0)
                     for k, v in sv.items():
-                        l.ctx.set_option(k, v)
+                        c.set_option(k, v)
+                for l in gl:
                     l.timing = False
-            return {"dt": dtg, "steps": iters, "lanes": len(gl), "trace_steps": float(sum(l.trace.num_steps for l in gl))}
+            return {"dt": dtg, "steps": iters, "lanes": len(gl), "trace_steps": float(sum(l.trace.num_steps for l in gl)), "acc": acc_g}
         if args.merkle == "cons":
             for skip, name in ((0, "gpu_all"), (1, "gpu_nohash"), (2, "gpu_nohash_nostruct")):
                 legs[name] = guard(name, lambda skip=skip: gpu_bound(skip))
+            gpu_one = guard("gpu_one_at_a_time", lambda: gpu_bound(0, nl=1, timing=True))
 
         # (after the legs above: this one gives every lane a second context and stream for its uploads -- dropped again right
         # after it: a process with twice the streams runs everything a few percent slower)
@@ -806,6 +941,7 @@ def main():
             return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
         legs["pcie"] = guard("pcie_inclusive", leg_pcie)
         guard("drop_upload_contexts", lambda: [l.drop_upload_context() for l in lanes])
+        guard("release", lambda: [c.release_workspaces() for c in all_contexts()])  # (the slots' column buffers and staging)
 
 
         digests = []
@@ -822,19 +958,21 @@ def main():
         # node-addressed trees, 2.75 GiB per proof in flight at 2^20: these legs run on as many of the lanes as fit -- the GPU
         # bounds them long before that -- and give the memory back afterwards
         def variant_lanes():
-            for l in lanes:
-                l.ctx.release_workspaces()
-            return lanes[:max(1, min(B, int(lanes[0].ctx.mem_info()[0] * 0.85) // int(3.6 * (1 << 30) * (1 << max(nv - 20, 0)))))]
+            for c in all_contexts():
+                c.release_workspaces()
+            if use_slots:  # (node-addressed trees live in the SLOTS' workspaces now: every lane takes part)
+                return lanes
+            return lanes[:max(1, min(B, int(setup_ctx.mem_info()[0] * 0.85) // int(3.6 * (1 << 30) * (1 << max(nv - 20, 0)))))]
         vl = guard("merkle_variants", variant_lanes) if have_digests else None
         for mode in ("cons", "struct", "regs", "all", "tables", "dense"):
             if mode == args.merkle or not vl:
                 continue
 
             def leg_variant(mode=mode):
-                for l in vl:  # (workspaces only grow: what one build kept must not add to what the next one needs)
-                    l.ctx.release_workspaces()
+                for c in all_contexts():  # (workspaces only grow: what one build kept must not add to what the next one needs)
+                    c.release_workspaces()
                 if rank == 0:
-                    sys.stderr.write("bench.py: %s on %d lanes, %.0f GiB of HBM free\n" % (mode, len(vl), vl[0].ctx.mem_info()[0] / 2.0**30))
+                    sys.stderr.write("bench.py: %s on %d lanes, %.0f GiB of HBM free\n" % (mode, len(vl), setup_ctx.mem_info()[0] / 2.0**30))
                 set_merkle_mode(mode)
                 run_step(Lane.prove_and_digest, which=vl)
                 # ... must be byte-identical under every other build (dense hashes every node of every tree)
@@ -845,12 +983,13 @@ def main():
                         "trace_steps": float(sum(l.trace.num_steps for l in vl))}
             legs["variant:" + mode] = guard("merkle_variant_" + mode, leg_variant)
             set_merkle_mode(args.merkle)
-        guard("release", lambda: [l.ctx.release_workspaces() for l in lanes])
+        guard("release", lambda: [c.release_workspaces() for c in all_contexts()])
         if not all(self_check.values()):
             raise SystemExit("bench.py: proofs differ between builds / transcript paths: %r" % self_check)
         if rank == 0:
-            kern = guard("kernel_leg", lambda: kernel_leg(lanes[0].ctx, nv, 43, max(3, min(args.kernel_iters, 10)),
+            kern = guard("kernel_leg", lambda: kernel_leg(setup_ctx, nv, 43, max(3, min(args.kernel_iters, 10)),
                                                           big_nv=24 if nv <= 22 else 0))
+            guard("release", lambda: setup_ctx.release_workspaces())
         # The structure-aware levels make the GPU time depend on the trace, so the same batch also runs on three other traces
         # (same lanes, same everything else; the lanes' witness buffers are overwritten: these are the last legs on them):
         #   worst     the worst case BY CONSTRUCTION for the run-aware register levels: a loop that writes 30 different
@@ -868,7 +1007,7 @@ def main():
             # zigz_commit_roots) and, where the group finds nothing twice in a row, stops trying it; what is timed is the
             # service's steady state on that trace, and `rebuilds` says how many builds were repeated inside the timed steps
             def repeated():  # (a context counts the builds it had to repeat since it was created)
-                return sum(l.ctx.stats()["rebuilds"] for l in lanes)
+                return sum(c.stats()["rebuilds"] for c in all_contexts())
             r0 = repeated()
             run_step()
             run_step()
@@ -894,7 +1033,7 @@ def main():
         sd = None
         ok = 1.0
         try:  # set-up: a rank that fails before the transport exists is noticed by the others as a timeout of its creation
-            sctx = lanes[0].ctx
+            sctx = setup_ctx
             sprog = programs.add_xor_loop((N - 3) // 4)  # the same trace on every rank
             strace = host.Trace(sprog, 0x1000, None, 2 * N)
             sd = sctx.dev_alloc(43 * N * 4)
@@ -925,14 +1064,15 @@ def main():
             shard_leg = {"error": "another rank could not set the leg up"}
         try:
             if sd is not None:
-                lanes[0].ctx.dev_free(sd)
+                setup_ctx.dev_free(sd)
             if comm is not None:
                 comm.close()
         except Exception:
             pass
 
     # ---- the other trace sizes of the north-star (2^16 .. 2^24), same bench trace, same build: small step counts, after the
-    # main lanes have given their HBM back (a 2^24 proof in flight holds ~55 GiB)
+    # main lanes have given their HBM back.  With GPU slots a lane holds its witness only (2.75 GiB at 2^24) and the tree / list
+    # workspaces belong to the few slots (~7 GiB each there): 64+ proofs in flight at 2^24 instead of 21.
     if extras:
         for l in lanes:
             try:
@@ -940,31 +1080,54 @@ def main():
             except Exception:
                 pass
         lanes_main, lanes = lanes, []
-        probe = zigz_amd.Context(local_rank)
-        free_now = probe.mem_info()[0]
-        probe.close()
+        if use_slots:
+            try:
+                slots.close()
+            except Exception:
+                pass
+            slots = None
+        setup_ctx.release_workspaces()
+        free_now = setup_ctx.mem_info()[0]
         for nv_s, steps_s in ((16, 10), (22, 5), (24, 2)):
             if nv_s == nv:
                 continue
-            # (the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 -- resident columns, lists
-            # and digests after the first build's learning, and the compact trace's staging, which the lanes give back:
-            # 0.6 / 2.3 / 9.0 -- measured; below 2^20 the fixed workspaces dominate)
-            per_lane = int(0.66 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
-            nl = max(1, min(B, int(free_now * 0.8) // per_lane))
+            if use_slots:
+                k_s = slot_count(B, nv_s)
+                while k_s > 4 and k_s * slot_bytes(nv_s, worst=False) > 0.35 * free_now:
+                    k_s -= 1
+                nl = max(1, min(B, (int(free_now * 0.88) - k_s * slot_bytes(nv_s, worst=False)) // lane_bytes(nv_s)))
+            else:
+                # (a context per lane: the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 --
+                # resident columns, lists and digests after the first build's learning -- measured; below 2^20 the fixed
+                # workspaces dominate)
+                per_lane = int(0.66 * (1 << 30) * (1 << max(nv_s - 20, 0))) if nv_s >= 20 else int(0.3 * (1 << 30))
+                k_s = 0
+                nl = max(1, min(B, int(free_now * 0.8) // per_lane))
             ls = []
 
-            def leg_size(nv_s=nv_s, steps_s=steps_s, nl=nl, ls=ls):
-                ls.extend(Lane(k, nv_s) for k in range(nl))
+            def leg_size(nv_s=nv_s, steps_s=steps_s, nl=nl, ls=ls, k_s=k_s):
+                nonlocal slots
+                if use_slots:
+                    slots = make_slots(k_s)
+                ls.extend(Lane(k, nv_s, pin=False) for k in range(nl))
+                setup_ctx.release_workspaces()
                 run_step(which=ls)
                 run_step(which=ls)
                 dts_, _, _ = timed(steps_s, which=ls)
-                return {"dt": dts_, "steps": steps_s, "lanes": nl, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
+                return {"dt": dts_, "steps": steps_s, "lanes": nl, "slots": k_s, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
             legs["nv%d" % nv_s] = guard("value_nv%d" % nv_s, leg_size)
             for l in ls:
                 try:
                     l.close()
                 except Exception:
                     pass
+            if use_slots and slots is not None:
+                try:
+                    slots.close()
+                except Exception:
+                    pass
+                slots = None
+            setup_ctx.release_workspaces()
     else:
         lanes_main = lanes
 
@@ -1002,66 +1165,98 @@ def main():
     if rank == 0:
         assert host.verify(proof, prog) == "Accept"
         ic = isa_counts()
-        # ---- where the kernel time of the TIMED REGION went, by class (every launch of the lanes in timing mode carries its own
-        # begin / end timestamps; concurrent proofs share the chip, so the per-launch durations are stretched by the overlap)
-        acc_all, nproofs_all = acc, nproofs
-        acc, nproofs = (acc["_timed"], acc["_timed_proofs"]) if acc.get("_timed_proofs") else (acc, nproofs)
+        # ---- `roofline`: the kernel class that dominates, from the roofline leg (every launch of every proof timed, absolute
+        # begin / end).  Per class: launches, sum of durations, UNION of the intervals (time with >= 1 launch of the class on
+        # the GPU).  achieved = the class's work / its union: what the chip delivered for the class while it had any of it in
+        # flight -- bounded by the wall clock, unlike work / sum-of-overlapping-durations (round 3's definition, kept as
+        # frac_by_sum_of_durations; it divides by more time than passed).
+        CLS = {0: "dense", 1: "dense", 2: "dense", 3: "tables", 4: "structure", 5: "level_hash", 6: "top", 7: "eval"}
+        nproofs_all = nproofs
+        cls_iv = {}
+        acc_l, nproofs_l, wall_us, leg_value = acc, nproofs, dt * 1e6, None
+        if roof_leg and roof_leg["recs"]:
+            for c_, _p, a, b in roof_leg["recs"]:
+                cls_iv.setdefault(CLS.get(c_, "other"), []).append((a, b))
+            acc_l, nproofs_l = roof_leg["acc"], roof_leg["steps"] * B
+            allr = [x for v in cls_iv.values() for x in v]
+            wall_us = max(b for _, b in allr) - min(a for a, _ in allr)  # first launch begin .. last launch end, GPU clock
+            leg_value = local_steps * roof_leg["steps"] / roof_leg["dt"]
+        elif acc.get("_timed_proofs"):  # a context per lane with ZIGZ_BENCH_TIMING_EVERY: sums of durations only
+            acc_l, nproofs_l = acc["_timed"], acc["_timed_proofs"]
         classes = {
-            "level_hash": acc.get("list_hash_us", 0.0),       # k_level_hash: the list-driven levels 0 .. v - 8
-            "structure": acc.get("structure_us", 0.0),        # k_runs_stage + k_cons_*: which nodes are hashed (no hashing)
-            "top": acc.get("top_us", 0.0),                    # k_merkle_top: the last 8 levels
-            "dense": acc["keccak_leaves_us"] + acc["keccak_level_wide_us"] + acc["keccak_level_small_us"],
-            "tables": acc["small_domain_us"],                 # k_keccak_small_l01
-            "eval": acc["eval_us"],                           # k_eq_weights + k_radix_fold + ...
+            "level_hash": acc_l.get("list_hash_us", 0.0),       # k_level_hash: the list-driven levels 0 .. v - 8
+            "structure": acc_l.get("structure_us", 0.0),        # k_runs_stage + k_cons_*: which nodes are hashed (no hashing)
+            "top": acc_l.get("top_us", 0.0),                    # k_merkle_top: the last 8 levels
+            "dense": acc_l.get("keccak_leaves_us", 0.0) + acc_l.get("keccak_level_wide_us", 0.0) + acc_l.get("keccak_level_small_us", 0.0),
+            "tables": acc_l.get("small_domain_us", 0.0),        # k_keccak_small_l01
+            "eval": acc_l.get("bind_vec_us", 0.0),              # k_radix_fold
         }
+        unions = {k: union_us(v) for k, v in cls_iv.items()}
         kernel_us = max(sum(classes.values()), 1e-9)
         share = {k: v / kernel_us for k, v in classes.items()}
-        kernel_us_per_proof = {k: v / max(nproofs, 1) for k, v in classes.items()}
+        kernel_us_per_proof = {k: v / max(nproofs_l, 1) for k, v in classes.items()}
 
         def valu_frac(perms, instr, us):
             return perms * instr / (us / 1e6) / 1e12 / VALU_PEAK_TOPS if us else None
-        lh_perms = acc.get("list_hash_perms", 0)
-        lh_launches = (nv - 7) * nproofs                      # one k_level_hash launch per level 0 .. v - 8 and proof
-        dense_perms = acc["keccak_leaves_perms"] + acc["keccak_level_wide_perms"] + acc["keccak_level_small_perms"]
+        lh_perms = acc_l.get("list_hash_perms", 0)
+        lh_launches = len(cls_iv.get("level_hash", [])) or (nv - 7) * nproofs_l  # one k_level_hash launch per level 0 .. v - 8
+        dense_perms = acc_l.get("keccak_leaves_perms", 0) + acc_l.get("keccak_level_wide_perms", 0) + acc_l.get("keccak_level_small_perms", 0)
         traffic = traffic_alg = None
-        tpath = os.path.join(ROOT, "profiles", "r03_traffic.json")
-        if os.path.exists(tpath):
-            try:
-                tj = json.load(open(tpath))["k_level_hash"]
-                traffic = tj["hbm_bytes_per_hash"] * lh_perms / max(lh_launches, 1)      # per launch, like `achieved`
-                traffic_alg = tj["algorithmic_bytes_per_hash"] * lh_perms / max(lh_launches, 1)
-            except Exception:
-                pass
+        for tname in ("r04_traffic.json", "r03_traffic.json"):
+            tpath = os.path.join(ROOT, "profiles", tname)
+            if os.path.exists(tpath):
+                try:
+                    tj = json.load(open(tpath))["k_level_hash"]
+                    traffic = tj["hbm_bytes_per_hash"] * lh_perms / max(lh_launches, 1)      # per launch, like `achieved`
+                    traffic_alg = tj["algorithmic_bytes_per_hash"] * lh_perms / max(lh_launches, 1)
+                    break
+                except Exception:
+                    pass
         if share["level_hash"] >= share["dense"]:
+            busy = unions.get("level_hash") or classes["level_hash"]   # (no intervals: the sum of durations, as round 3)
             roof = {"kernel": "k_level_hash", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
-                    "achieved": lh_perms * ic["level_hash"] / (classes["level_hash"] / 1e6) / 1e12 if classes["level_hash"] else 0.0,
+                    "achieved": lh_perms * ic["level_hash"] / (busy / 1e6) / 1e12 if busy else 0.0,
                     "traffic": traffic, "traffic_algorithmic": traffic_alg,
                     "avg_launch_us": classes["level_hash"] / max(lh_launches, 1), "launches": lh_launches,
-                    "hashes_per_launch": lh_perms / max(lh_launches, 1), "valu_instr_per_hash": ic["level_hash"]}
+                    "hashes_per_launch": lh_perms / max(lh_launches, 1), "valu_instr_per_hash": ic["level_hash"],
+                    "busy_us": busy, "sum_of_durations_us": classes["level_hash"],
+                    "frac_by_sum_of_durations": valu_frac(lh_perms, ic["level_hash"], classes["level_hash"])}
         else:  # a dense build (--merkle dense / tables): the dense leaf + level kernels dominate
+            busy = unions.get("dense") or classes["dense"]
+            nl_d = len(cls_iv.get("dense", [])) or nproofs_l
             roof = {"kernel": "k_keccak_leaves+k_keccak_level", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
-                    "achieved": dense_perms * ic["level"] / (classes["dense"] / 1e6) / 1e12 if classes["dense"] else 0.0,
+                    "achieved": dense_perms * ic["level"] / (busy / 1e6) / 1e12 if busy else 0.0,
                     "traffic": None, "traffic_algorithmic": None,
-                    "avg_launch_us": classes["dense"] / max(nproofs, 1), "launches": nproofs,
-                    "hashes_per_launch": dense_perms / max(nproofs, 1), "valu_instr_per_hash": ic["level"]}
+                    "avg_launch_us": classes["dense"] / max(nl_d, 1), "launches": nl_d,
+                    "hashes_per_launch": dense_perms / max(nl_d, 1), "valu_instr_per_hash": ic["level"],
+                    "busy_us": busy, "sum_of_durations_us": classes["dense"],
+                    "frac_by_sum_of_durations": valu_frac(dense_perms, ic["level"], classes["dense"])}
         roof["frac"] = roof["achieved"] / VALU_PEAK_TOPS
         roof = {k: roof[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "traffic", "traffic_algorithmic",
-                                     "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash")}
-        roof["level_hash_share"] = share["level_hash"]
-        roof["structure_share"] = share["structure"]
-        roof["eval_share"] = share["eval"]
+                                     "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash", "busy_us",
+                                     "sum_of_durations_us", "frac_by_sum_of_durations")}
+        # what share of the leg's wall clock (first launch begin .. last launch end) had >= 1 launch of a class on the GPU
+        roof["leg_wall_us"] = wall_us
+        roof["busy_share_of_wall"] = roof["busy_us"] / wall_us if unions else None
+        roof["leg_value"] = leg_value  # the rate of the roofline leg itself (events on every launch): what the timing costs
+        detail_busy = {k: v / wall_us for k, v in unions.items()} if unions else None
         # the structure passes are HBM-side work: their algorithmic bytes (4 B per leaf of the 33 run-aware columns; the group's
         # ten columns twice + 12 B per node of its levels) over their time with ONE proof on the GPU at a time
         struct_bytes = {"cons": 224.0, "struct": 132.0, "regs": 124.0, "all": 140.0}.get(args.merkle, 0.0) * N
-        roof["eval_hbm_frac"] = ((acc["bind_vec_bytes"] / 1e9) / (acc["bind_vec_us"] / 1e6) / HBM_PEAK_GBS) if acc.get("bind_vec_us") else None
-        if solo:  # the same class with one proof on the GPU at a time (no overlap between proofs)
-            a = solo["acc"]
+        roof["eval_hbm_frac"] = ((acc_l["bind_vec_bytes"] / 1e9) / (acc_l["bind_vec_us"] / 1e6) / HBM_PEAK_GBS) if acc_l.get("bind_vec_us") else None
+        # the same class with ONE proof on the GPU at a time (no overlap between proofs), its launches back to back on a GPU that
+        # stays busy (the commit path without the host transcript, one worker): the kernel's own quality inside a proof.  The
+        # single-proof leg -- 27 ms of host sponge between two 1 ms bursts of GPU work -- measures the same launches on a chip
+        # that has dropped its clocks in between (`in_proof_frac_idle_gaps`; the driver's round-3 line: 0.25 against 0.37).
+        if gpu_one and gpu_one.get("acc"):
+            a = gpu_one["acc"]
             roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
             if a.get("structure_us") and struct_bytes:
-                roof["structure_in_proof_hbm_frac"] = struct_bytes * solo["n"] / 1e9 / (a["structure_us"] / 1e6) / HBM_PEAK_GBS
-        roof["timed_launches_sampled"] = nproofs / max(nproofs_all, 1)  # share of the region's proofs whose launches were timed
-        acc, nproofs = acc_all, nproofs_all
-        # all Keccak work of the region over its wall time: a lower bound on what the chip sustained while the bench ran
+                roof["structure_in_proof_hbm_frac"] = struct_bytes * gpu_one["steps"] / 1e9 / (a["structure_us"] / 1e6) / HBM_PEAK_GBS
+        if solo and solo["acc"].get("list_hash_us"):
+            a = solo["acc"]
+            roof["in_proof_frac_idle_gaps"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
+        # all Keccak work of the TIMED REGION over its wall time: a lower bound on what the chip sustained while the bench ran
         roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * ic["level_hash"] / dt / 1e12 / VALU_PEAK_TOPS
         kl = kern.get("k_keccak_leaves[43x2^%d]" % nv) if kern else None
         if kl:  # what the permutation code reaches back to back on 43 x 2^nv leaves in this process: the ceiling of its mix
@@ -1074,24 +1269,36 @@ def main():
 
         def rate(leg):
             return leg["trace_steps"] * leg["steps"] / leg["dt"]
+        host_cpu_ms = acc.get("process_cpu_s", 0.0) / nproofs * 1e3  # CPU time of all threads of the process, per proof
         cfg = {
             "workload": "synthetic RV64I ADD/XOR loop, 2^%d trace, 43 columns in HBM; full Prover.prove hot path; %d proofs/GPU/step" % (nv, B),
-            "trace_steps": trace_steps, "traces_per_step_per_gpu": B, "sponge_servers": servers,
+            # which side bounded the line, and what each side could carry (whole job, all ranks): the host -- this rank's CPUs /
+            # the CPU time one proof costs (sponge servers, lanes, serialiser, runtime threads) -- and the GPU -- the commit path
+            # alone, back to back without the transcript (filled in below from the gpu_bound leg).  On a node whose cgroup gives
+            # a rank few CPUs the line is host-bound at host_bound_ceiling_value whatever the GPUs could do.
+            "bound": None, "host_bound_ceiling_value": (ncpu / host_cpu_ms * 1e3 * trace_steps * world) if host_cpu_ms else None,
+            "gpu_bound_ceiling_value": None,
+            "gpu_slots": slot_count(B, nv) if use_slots else 0,
+            "traces_per_step_per_gpu": B, "sponge_servers": servers,
             "merkle_build": args.merkle, "keccak_permutations_per_proof": acc["keccak_permutations"] / nproofs,
-            "ms_per_proof_per_gpu": dt / nproofs * 1e3,
-            "host_cpus_available": ncpu, "cpus_pinned": pin.get("pinned", 0),
+            "ms_per_proof_per_gpu": dt / nproofs * 1e3, "cpus_pinned": pin.get("pinned", 0),
             "parallelism": ("1 proof/step, columns sharded over %d GPUs (strong)" % world) if shard else
                            ("independent traces: %d GPU(s) x %d proofs in flight, no data-path collective" % (world, B)),
-            "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
-            "commit_begin_ms": phases.get("commit_begin", 0.0) / nproofs * 1e3,
         }
         detail = {"merkle_build": "--merkle %s: " % args.merkle + MERKLE_BUILDS[args.merkle], "lookup_steps": trace_lookups,
                   "blocking_sync": bool(blocking), "pin": pin, "hbm_free_at_start": hbm_free, "proof_bytes": len(proof),
                   "host_transcripts": ("%d sponge-server threads per GPU, each advancing up to 8 proofs' transcripts in lock "
                                        "step (8-way AVX-512 Keccak-f); the proofs' own threads sleep meanwhile" % servers)
                                       if servers else "every proof absorbs its transcript on its own host thread",
-                  "kernel_time_shares_timed_region": share,
-                  "kernel_us_per_proof_timed_region": kernel_us_per_proof}
+                  "trace_steps": trace_steps, "host_cpus_available": ncpu,
+                  "backend": ("rccl" if backend == "nccl" else backend) if world > 1 else "none",
+                  "commit_begin_ms": phases.get("commit_begin", 0.0) / nproofs * 1e3,
+                  "kernel_time_shares_roofline_leg": share, "kernel_us_per_proof_roofline_leg": kernel_us_per_proof,
+                  "class_busy_share_of_wall_roofline_leg": detail_busy,
+                  "roofline_leg": {"steps": roof_leg["steps"], "proofs": roof_leg["steps"] * B, "wall_us": wall_us,
+                                   "launches_logged": len(roof_leg["recs"])} if roof_leg else None}
+        for k_ in ("leg_wall_us", "sum_of_durations_us", "valu_instr_per_hash", "eval_hbm_frac"):
+            detail["roofline_" + k_] = roof.pop(k_, None)
         if solo:
             cfg["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
             a = solo["acc"]
@@ -1110,6 +1317,9 @@ def main():
             def gpu_ms(leg):
                 return leg["dt"] / (leg["steps"] * leg.get("lanes", B)) * 1e3
             cfg["gpu_bound_ms_per_proof"] = gpu_ms(legs["gpu_all"])
+            cfg["gpu_bound_ceiling_value"] = trace_steps / cfg["gpu_bound_ms_per_proof"] * 1e3 * world
+            if cfg["host_bound_ceiling_value"]:
+                cfg["bound"] = "host" if cfg["host_bound_ceiling_value"] < cfg["gpu_bound_ceiling_value"] else "gpu"
             dec = {"complete": gpu_ms(legs["gpu_all"])}
             if legs.get("gpu_nohash"):
                 dec["without_hash_launches"] = gpu_ms(legs["gpu_nohash"])
@@ -1152,7 +1362,7 @@ def main():
         if kern:
             detail["kernel_leg"] = {k: {"frac": v["frac"], "avg_us": v["avg_us"]} for k, v in kern.items()}
         detail["host_phase_ms_per_proof"] = {k: v / nproofs * 1e3 for k, v in phases.items()}
-        detail["host_cpu_ms_per_proof"] = acc.get("process_cpu_s", 0.0) / nproofs * 1e3  # CPU time of all threads, per proof
+        detail["host_cpu_ms_per_proof"] = host_cpu_ms
         detail["host_cpus_busy"] = acc.get("process_cpu_s", 0.0) / dt
         detail["host_keccak"] = zigz_amd._ffi.lib.zigz_host_keccak_impl().decode()
         out = {
@@ -1173,6 +1383,9 @@ def main():
     pool.shutdown()
     for l in lanes_main:
         l.close()
+    if slots is not None:
+        slots.close()
+    setup_ctx.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -230,6 +230,12 @@ zigz_status zigz_dev_witness_from_steps(zigz_ctx *ctx, const zigz_trace_step *h_
  * and stay unmodified until the stream has passed the copy (zigz_commit_roots / zigz_ctx_synchronize). */
 zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
                                               const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride);
+/* The asynchronous form into a column buffer the CONTEXT owns (a workspace, reused call after call: nothing is allocated
+ * on the steady-state path of a service that proves trace after trace on a pool of contexts).  *d_cols / *col_stride are
+ * valid until the next call of this function, zigz_commit_begin (host columns), zigz_bench_kernel or
+ * zigz_ctx_release_workspaces on the context -- in particular through a commit job begun on them. */
+zigz_status zigz_dev_witness_from_steps_ws(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                           const uint64_t *initial_regs, const uint32_t **d_cols, size_t *col_stride);
 /* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
  * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer; page-locking belongs
  * to the process, so unregister accepts ctx == NULL (the registering context may already be destroyed). */
@@ -441,6 +447,25 @@ typedef struct zigz_bench_result {
 zigz_status zigz_bench_kernel(zigz_ctx *ctx, const char *kernel, size_t nv, size_t ncols, int iters, int cold,
                               zigz_bench_result *out);
 zigz_status zigz_ctx_enable_timing(zigz_ctx *ctx, int enable);
+/* Timing mode, launch by launch: the timed launches of the context's last commit job (its build after zigz_commit_roots, its
+ * eval fold after zigz_commit_open_all) with their own begin / end on ONE time axis -- microseconds since the epoch of
+ * `zigz_ctx_set_epoch` -- so that a caller that runs many contexts at once can take the UNION of a kernel class's intervals
+ * (time during which at least one launch of the class was on the GPU) instead of the sum of durations of launches that
+ * overlap.  The events carry the dispatch's own timestamps (first wave started .. last wave ended: within 1 us of a clock
+ * read inside the kernel, tools/event_semantics.hip; a launch's wait behind its predecessor in the stream is not part of it,
+ * its wait for wave slots next to other streams' kernels is), and are comparable across the streams of a device.
+ * zigz_ctx_set_epoch(ctx, owner): owner == ctx records a new epoch on the context's stream; otherwise ctx adopts the
+ * owner's (which must outlive its use).  Without an epoch, times count from the job's first timed launch.
+ * class: 0 k_keccak_leaves, 1 / 2 k_keccak_level (wide / small), 3 k_keccak_small_l01, 4 structure passes (k_runs_stage,
+ * k_cons_*: first .. last launch of each group), 5 k_level_hash, 6 k_merkle_top, 7 k_radix_fold (eval). */
+typedef struct zigz_launch_rec {
+    uint32_t cls;
+    uint32_t reserved;
+    uint64_t perms;      /* Keccak permutations where the host knows them at launch time (classes 0-2, 6), else 0 */
+    double start_us, end_us;
+} zigz_launch_rec;
+zigz_status zigz_ctx_set_epoch(zigz_ctx *ctx, zigz_ctx *owner);
+zigz_status zigz_ctx_launch_log(zigz_ctx *ctx, zigz_launch_rec *out, size_t cap, size_t *n);
 /* tuning / test switches: "per_round_sumcheck" = 1 forces the one-launch-per-round sumcheck form;
  * "fold_eval" = 1 forces eval by v successive binds instead of the one-pass radix form;
  * "run_aware_mask" = bit c set: column c of the following batched commits (<= 64 columns, 2^15 .. 2^26 rows) is expected to be

@@ -19,9 +19,9 @@ typedef struct zigzh_trace zigzh_trace; /* an executed program: compact trace re
 
 const char *zigzh_last_error(void);
 void zigzh_free(void *p);
-/* wall-clock seconds of the phases of the last zigzh_prove_trace on this thread: commit_begin, sumcheck transcript,
- * lasso transcript, wait for roots, roots+challenges, open_all, packaging, serialize */
-void zigzh_last_timings(double out[8]);
+/* wall-clock seconds of the phases of the last zigzh_prove_trace[_slots] on this thread: commit_begin, sumcheck transcript,
+ * lasso transcript, wait for roots, roots+challenges, open_all, packaging, serialize, wait for a GPU slot, time in the slot */
+void zigzh_last_timings(double out[10]);
 
 /* Prover(F).prove(program, entry_pc, initial_regs, max_steps, null, input) + BinarySerializer.serialize
  * src/prover/prover.zig:73-226, src/prover/serialization.zig:70-97 */
@@ -61,6 +61,27 @@ int zigzh_trace_witness_dev_async(const zigzh_trace *t, zigz_ctx *ctx, uint32_t 
  * call on this thread; do not free). */
 int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_cols, size_t stride, int want_bytes,
                       uint8_t **proof_out, size_t *proof_len);
+
+/* GPU slots of a proving service (zigz_host.hpp: GpuSlots): k contexts (stream + workspaces each) shared by any number of
+ * proving threads.  zigzh_prove_trace_slots is zigzh_prove_trace(want_bytes = 2) for such a thread: the transcript of
+ * steps [4/6]-[5/6] runs holding nothing on the GPU, then the thread takes a slot for begin -> roots -> challenges ->
+ * open_all -> end (the trees do not depend on the transcript, the points do: prover.zig:405-424) and gives it back.
+ * d_cols: the 43 resident columns (any allocation of the process on that device), or NULL: the compact trace records
+ * (pin them: zigzh_trace_pin) are uploaded and expanded inside the slot, into a column buffer the slot owns -- a proof in
+ * flight then holds no HBM at all outside its few milliseconds in a slot.  stats_out / log_out (optional): the kernel
+ * statistics and, in timing mode, the launch log (zigz_ctx_launch_log) of the context the proof ran on.
+ * zigzh_slots_ctx: the i-th context, for set-up (options, timing, epochs) while nobody proves; zigzh_slots_acquire /
+ * _release: a slot for work of the caller's own (uploads, allocations). */
+typedef struct zigzh_slots zigzh_slots;
+int zigzh_slots_create(int device, size_t k, zigzh_slots **out);
+void zigzh_slots_destroy(zigzh_slots *s);
+size_t zigzh_slots_size(const zigzh_slots *s);
+zigz_ctx *zigzh_slots_ctx(zigzh_slots *s, size_t i);
+zigz_ctx *zigzh_slots_acquire(zigzh_slots *s);
+void zigzh_slots_release(zigzh_slots *s, zigz_ctx *ctx);
+int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, const uint32_t *d_cols, size_t stride,
+                            uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_out, zigz_launch_rec *log_out,
+                            size_t log_cap, size_t *log_n);
 
 /* One proof over `world` GPUs, sharded by column: every rank calls this with the SAME trace and its own
  * context / resident copy of the 43 columns; rank r builds, commits and opens only its contiguous block of columns

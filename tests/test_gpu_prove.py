@@ -323,3 +323,60 @@ def test_config5_fibonacci_2_24_full_size():
     """BASELINE config 5 at full size (fibonacci guest semantics, 2^24 trace, 403 MB proof), same checks as config 4."""
     out = _run_config(5, 1200)
     assert out["nv"] == 24 and out["checked_columns_vs_oracle"] == 1
+
+
+def test_prove_through_gpu_slots_is_byte_identical(ctx):
+    """The service form (GpuSlots, csrc/host/zigz_host.hpp): many proving threads, few contexts -- a thread runs
+    its transcript holding nothing on the GPU and takes one of K slots only for begin -> roots -> challenges -> open_all ->
+    end (prover.zig:405-424: the trees do not depend on the transcript, the points do).  9 threads x 3 proofs each over 2
+    slots, on resident columns and with the witness built inside the slot from the pinned compact trace, every proof against
+    the oracle's bytes -- including looping traces >= 2^15 steps, where the slots' contexts learn list capacities from each
+    other's traces (a build that runs out of room is repeated inside the slot)."""
+    import threading
+    from zigz_amd import host
+    cases = [("fibonacci", 50), ("add_xor_loop", 300), ("mixed_loop", 200), ("fibonacci", 1500), ("add_xor_loop", 9000),
+             ("mixed_loop", 3000), ("register_round_robin", 1100), ("add_xor_loop", 8190), ("add_xor_loop", 5)]
+    traces, want = [], []
+    for maker, arg in cases:
+        r = getattr(programs, maker)(arg)
+        prog, inp = r if isinstance(r, tuple) else (r, None)
+        tr = host.Trace(prog, 0x1000, None, 1 << 20, inp)
+        tr.pin(ctx)
+        traces.append(tr)
+        want.append(hashlib.sha3_256(O.prove(P, prog, 0x1000, None, 1 << 20, inp)[0]).hexdigest())
+    slots = host.Slots(0, 2)
+    bufs = []
+    for tr in traces:
+        N = max(1 << tr.num_vars, 4)
+        d = ctx.dev_alloc(43 * N * 4)
+        tr.witness_to_device(ctx, d, N)
+        bufs.append((d, N))
+    errs, got = [], {}
+
+    def worker(i):
+        try:
+            tr, (d, N) = traces[i], bufs[i]
+            for rep, dc in enumerate((d, None, d)):
+                proof, st, _ = tr.prove_slots(slots, dc, N)
+                got[(i, rep)] = hashlib.sha3_256(proof.tobytes()).hexdigest()
+                assert st["keccak_permutations"] > 0
+                t = host.last_timings()
+                assert t["in_slot"] > 0 and t["commit_begin"] <= t["in_slot"]
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(cases))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    try:
+        assert not errs, errs
+        for i in range(len(cases)):
+            for rep in range(3):
+                assert got[(i, rep)] == want[i], (cases[i], rep)
+        # one slot context after the run: no job left active, options as its owner left them (0)
+        for c in slots.contexts():
+            assert c.get_option("run_aware_mask") == 0 and c.get_option("cons_group_mask") == 0
+    finally:
+        for d, _ in bufs:
+            ctx.dev_free(d)
+        slots.close()
+        del traces

@@ -20,6 +20,10 @@ szp = C.POINTER(C.c_size_t)
 vp = C.c_void_p
 
 
+class LaunchRec(C.Structure):  # zigz_launch_rec
+    _fields_ = [("cls", C.c_uint32), ("reserved", C.c_uint32), ("perms", C.c_uint64), ("start_us", C.c_double), ("end_us", C.c_double)]
+
+
 class KernelStats(C.Structure):
     _fields_ = [("merkle_build_us", C.c_double), ("eval_us", C.c_double), ("path_us", C.c_double),
                 ("bind_us", C.c_double), ("bind_launches", C.c_uint64), ("keccak_permutations", C.c_uint64),
@@ -95,6 +99,8 @@ SIGNATURES = {
     "zigz_dev_witness_from_steps": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_witness_from_steps_async": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_mem_info": (C.c_int32, [vp, szp, szp]),
+    "zigz_ctx_set_epoch": (C.c_int32, [vp, vp]),
+    "zigz_ctx_launch_log": (C.c_int32, [vp, C.POINTER(LaunchRec), C.c_size_t, szp]),
     "zigz_ctx_release_workspaces": (C.c_int32, [vp]),
     "zigz_host_register": (C.c_int32, [vp, vp, C.c_size_t]),
     "zigz_host_unregister": (C.c_int32, [vp, vp]),

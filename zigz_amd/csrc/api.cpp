@@ -64,6 +64,7 @@ struct zigz_ctx {
     hipEvent_t ev[6];
     hipEvent_t pool[2 * 64];  // per-launch event pairs timing the bulk MLE-bind launches (k_radix_fold / k_bind_vec)
     int pool_used;
+    bool pool_is_fold;  // pool[0..1] carry the k_radix_fold launch of a commit job's eval
     uint64_t pool_bytes;
     // kernel-exact timestamps of the Keccak launches of the last batched commit (timing mode): pair i = kev[2i], kev[2i+1]
     hipEvent_t kev[2 * KEV_MAX];
@@ -71,6 +72,10 @@ struct zigz_ctx {
                                  // 4 run-aware levels
     uint64_t kev_perms[KEV_MAX];
     int kev_n;
+    // launch log of the last commit job (timing mode): begin / end of every timed launch since the epoch (zigz_ctx_set_epoch)
+    hipEvent_t epoch_own, epoch;  // epoch: the event times are counted from (this context's or another's), or null
+    zigz_launch_rec log[KEV_MAX + 2];
+    int log_n;
     void *d_flush;          // 1 GiB read-only scratch of zigz_bench_kernel (cold-HBM runs), allocated on first use
     uint64_t small_domain_mask;  // option: columns (bit c) whose values are < 128 by construction -> levels 0-1 by table
     uint8_t *d_sd_tables;        // T0 | T1 (kernels.hpp SD_TABLE_BYTES), built on first use
@@ -273,6 +278,7 @@ extern "C" zigz_status zigz_ctx_create(int device, zigz_ctx **out) {
         if (fail(hipEventCreate(&ctx->pool[i]))) st = ZIGZ_ERR_HIP;
     for (int i = 0; st == ZIGZ_OK && i < 2 * KEV_MAX; i++)
         if (fail(hipEventCreate(&ctx->kev[i]))) st = ZIGZ_ERR_HIP;
+    if (st == ZIGZ_OK && fail(hipEventCreate(&ctx->epoch_own))) st = ZIGZ_ERR_HIP;
     if (st != ZIGZ_OK) {
         zigz_ctx_destroy(ctx);
         return st;
@@ -303,6 +309,7 @@ extern "C" void zigz_ctx_destroy(zigz_ctx *ctx) {
         if (ctx->pool[i]) (void)hipEventDestroy(ctx->pool[i]);
     for (int i = 0; i < 2 * KEV_MAX; i++)
         if (ctx->kev[i]) (void)hipEventDestroy(ctx->kev[i]);
+    if (ctx->epoch_own) (void)hipEventDestroy(ctx->epoch_own);
     if (ctx->d_flush) (void)hipFree(ctx->d_flush);
     if (ctx->d_sd_tables) (void)hipFree(ctx->d_sd_tables);
     if (ctx->d_sd_fallbacks) (void)hipFree(ctx->d_sd_fallbacks);
@@ -418,6 +425,43 @@ extern "C" zigz_status zigz_ctx_get_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "small_domain_mask") == 0) { *value = (int64_t)ctx->small_domain_mask; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
+extern "C" zigz_status zigz_ctx_set_epoch(zigz_ctx *ctx, zigz_ctx *owner) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !owner || owner->device != ctx->device) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (owner == ctx) {
+        HIPCHK(ctx, hipEventRecord(ctx->epoch_own, ctx->stream));
+        HIPCHK(ctx, hipEventSynchronize(ctx->epoch_own));
+    }
+    ctx->epoch = owner->epoch_own;
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_ctx_launch_log(zigz_ctx *ctx, zigz_launch_rec *out, size_t cap, size_t *n) {
+    if (!ctx || !n || (cap && !out)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const size_t k = (size_t)ctx->log_n < cap ? (size_t)ctx->log_n : cap;
+    if (k) memcpy(out, ctx->log, k * sizeof(zigz_launch_rec));
+    *n = (size_t)ctx->log_n;
+    return ZIGZ_OK;
+}
+// one timed launch (both events stamped by the dispatch itself) -> the log; `first`: the job's first timed launch, the origin
+// of the time axis when the context has no epoch
+static zigz_status log_launch(zigz_ctx *ctx, int cls, uint64_t perms, hipEvent_t start, hipEvent_t stop, hipEvent_t first, double *dur_us) {
+    float d = 0, b = 0;
+    HIPCHK(ctx, hipEventElapsedTime(&d, start, stop));
+    *dur_us = (double)d * 1000.0;
+    if (ctx->log_n >= KEV_MAX + 2) return ZIGZ_OK;
+    const hipEvent_t origin = ctx->epoch ? ctx->epoch : first;
+    if (origin == stop || hipEventElapsedTime(&b, origin, stop) != hipSuccess) {  // (origin == start of this very launch)
+        (void)hipGetLastError();
+        b = origin == start ? d : 0.0f;
+    }
+    zigz_launch_rec &r = ctx->log[ctx->log_n++];
+    r.cls = (uint32_t)cls;
+    r.reserved = 0;
+    r.perms = perms;
+    r.end_us = (double)b * 1000.0;
+    r.start_us = r.end_us - *dur_us;
+    return ZIGZ_OK;
+}
 extern "C" zigz_status zigz_ctx_get_stats(zigz_ctx *ctx, zigz_kernel_stats *out) {
     ZIGZ_ENTER(ctx);
     if (!ctx || !out) return ZIGZ_ERR_INVALID_ARGUMENT;
@@ -519,6 +563,20 @@ extern "C" zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zi
                                                          size_t col_stride) {
     ZIGZ_ENTER(ctx);
     return witness_from_steps(ctx, h_steps, num_steps, nv, initial_regs, d_cols, col_stride, false);
+}
+
+extern "C" zigz_status zigz_dev_witness_from_steps_ws(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
+                                                      const uint64_t *initial_regs, const uint32_t **d_cols, size_t *col_stride) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !d_cols || !col_stride || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;  // (the job may be reading the workspace)
+    const size_t N = (size_t)1 << nv, stride = N < 4 ? 4 : N;
+    void *d;
+    CHK(ws_get(ctx, WS_COLS, ZIGZ_NUM_COLUMNS * stride * 4, &d));
+    CHK(witness_from_steps(ctx, h_steps, num_steps, nv, initial_regs, (uint32_t *)d, stride, false));
+    *d_cols = (const uint32_t *)d;
+    *col_stride = stride;
+    return ZIGZ_OK;
 }
 
 extern "C" zigz_status zigz_host_register(zigz_ctx *ctx, void *h_ptr, size_t bytes) {
@@ -631,9 +689,16 @@ static zigz_status bind_pool_collect(zigz_ctx *ctx) {
     for (int i = 0; i < ctx->pool_used; i++) {
         float ms = 0;
         HIPCHK(ctx, hipEventSynchronize(ctx->pool[2 * i + 1]));
+        if (ctx->pool_is_fold && i == 0) {  // the eval's k_radix_fold of a commit job: into the job's launch log as well
+            double d = 0;
+            CHK(log_launch(ctx, 7, 0, ctx->pool[0], ctx->pool[1], ctx->pool[0], &d));
+            us += d;
+            continue;
+        }
         HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->pool[2 * i], ctx->pool[2 * i + 1]));
         us += (double)ms * 1000.0;
     }
+    ctx->pool_is_fold = false;
     ctx->stats.bind_vec_us = us;
     ctx->stats.bind_vec_launches = (uint64_t)ctx->pool_used;
     ctx->stats.bind_vec_bytes = ctx->pool_bytes;
@@ -733,6 +798,7 @@ static zigz_status dev_eval_radix(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
                       rec ? ctx->pool[1] : nullptr, skip, rloops);
     if (rec) {
         ctx->pool_used = 1;
+        ctx->pool_is_fold = ctx->active_job != nullptr;
         // one read of the tables (those of the columns that are not skipped) + the partial sums
         ctx->pool_bytes = (uint64_t)(ncols - (skip ? ctx->stats.eval_constant_columns : 0)) * (N * 4 + groups * m * 8);
     }
@@ -1657,11 +1723,12 @@ static zigz_status keccak_times_collect(zigz_ctx *ctx) {
     // addressing table passes: no hashing), 5 list-driven level hashing, 6 the top of the trees
     double us[7] = {0, 0, 0, 0, 0, 0, 0};
     uint64_t perms[7] = {0, 0, 0, 0, 0, 0, 0};
+    ctx->log_n = 0;
     for (int i = 0; i < ctx->kev_n; i++) {
-        float ms = 0;
+        double d = 0;
         HIPCHK(ctx, hipEventSynchronize(ctx->kev[2 * i + 1]));
-        HIPCHK(ctx, hipEventElapsedTime(&ms, ctx->kev[2 * i], ctx->kev[2 * i + 1]));
-        us[ctx->kev_class[i]] += (double)ms * 1000.0;
+        CHK(log_launch(ctx, ctx->kev_class[i], ctx->kev_perms[i], ctx->kev[2 * i], ctx->kev[2 * i + 1], ctx->kev[0], &d));
+        us[ctx->kev_class[i]] += d;
         perms[ctx->kev_class[i]] += ctx->kev_perms[i];
     }
     ctx->stats.keccak_leaves_us = us[0];

@@ -10,7 +10,7 @@
 using namespace zigz;
 
 static thread_local std::string g_err;
-static thread_local double g_timings[8] = {0};
+static thread_local double g_timings[10] = {0};
 // trace storage recycled across executions on this thread (first-touch page faults of a fresh buffer are not free)
 static thread_local std::vector<zigz_trace_step> g_step_pool;
 static thread_local std::vector<uint8_t> g_proof;  // borrowed-proof buffer of zigzh_prove_trace(want_bytes = 2)
@@ -41,7 +41,7 @@ static uint8_t *dup_bytes(const std::vector<uint8_t> &v) {
 
 extern "C" const char *zigzh_last_error(void) { return g_err.c_str(); }
 extern "C" void zigzh_free(void *p) { free(p); }
-extern "C" void zigzh_last_timings(double out[8]) { memcpy(out, g_timings, sizeof(g_timings)); }
+extern "C" void zigzh_last_timings(double out[10]) { memcpy(out, g_timings, sizeof(g_timings)); }
 
 struct zigzh_trace {
     PublicIO io;
@@ -167,6 +167,44 @@ extern "C" int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint
             *proof_out = dup_bytes(b);
             *proof_len = b.size();
             g_timings[7] = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+        }
+    });
+}
+
+// ---------------------------------------------------------------- GPU slots of a proving service (zigz_host.hpp: GpuSlots)
+struct zigzh_slots {
+    GpuSlots slots;
+    zigzh_slots(int device, size_t k) : slots(device, k) {}
+};
+extern "C" int zigzh_slots_create(int device, size_t k, zigzh_slots **out) {
+    return guard([&] { *out = new zigzh_slots(device, k); });
+}
+extern "C" void zigzh_slots_destroy(zigzh_slots *s) { delete s; }
+extern "C" size_t zigzh_slots_size(const zigzh_slots *s) { return s ? s->slots.size() : 0; }
+extern "C" zigz_ctx *zigzh_slots_ctx(zigzh_slots *s, size_t i) { return s && i < s->slots.size() ? s->slots.at(i) : nullptr; }
+extern "C" zigz_ctx *zigzh_slots_acquire(zigzh_slots *s) { return s ? s->slots.acquire() : nullptr; }
+extern "C" void zigzh_slots_release(zigzh_slots *s, zigz_ctx *ctx) {
+    if (s && ctx) s->slots.release(ctx);
+}
+
+extern "C" int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, const uint32_t *d_cols, size_t stride,
+                                       uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_out,
+                                       zigz_launch_rec *log_out, size_t log_cap, size_t *log_n) {
+    return guard([&] {
+        if (!t || !s || !proof_out || !proof_len) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "null argument");
+        if (t->trace.stepCount() == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+        Prover prover(&s->slots, 0);
+        const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
+        if (d_cols) prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
+        else prover.proveStepsToBytes(t->io, t->num_lookups, t->trace.steps.data(), t->trace.initial_regs, t->num_vars, ir, g_proof);
+        memcpy(g_timings, prover.timings, sizeof(g_timings));
+        *proof_out = g_proof.data();
+        *proof_len = g_proof.size();
+        if (stats_out) *stats_out = prover.last_stats;
+        if (log_n) {
+            const size_t n = prover.last_log.size() < log_cap ? prover.last_log.size() : log_cap;
+            if (n && log_out) memcpy(log_out, prover.last_log.data(), n * sizeof(zigz_launch_rec));
+            *log_n = log_out ? n : 0;
         }
     });
 }

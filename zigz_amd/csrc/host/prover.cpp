@@ -287,86 +287,147 @@ void Prover::proveWitnessToBytes(const PublicIO &io, size_t num_lookups, const W
     (void)proveWitnessImpl(io, num_lookups, witness, d_cols, d_col_stride, num_vars, initial_regs, &out);
 }
 
+void Prover::proveStepsToBytes(const PublicIO &io, size_t num_lookups, const zigz_trace_step *steps, const uint64_t *regs_before,
+                               size_t num_vars, const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out) {
+    if (!slots_) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "proveStepsToBytes: needs a prover of a service (GpuSlots)");
+    if (!steps) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "proveStepsToBytes: no trace records");
+    (void)proveWitnessImpl(io, num_lookups, nullptr, nullptr, 0, num_vars, initial_regs, &out, steps, regs_before);
+}
+
+// ---------------------------------------------------------------- GpuSlots
+GpuSlots::GpuSlots(int device, size_t k) {
+    if (k == 0) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "GpuSlots: no slots");
+    for (size_t i = 0; i < k; i++) {
+        zigz_ctx *c = nullptr;
+        const zigz_status st = zigz_ctx_create(device, &c);
+        if (st != ZIGZ_OK) {
+            for (zigz_ctx *x : all_) zigz_ctx_destroy(x);
+            throw Error(st, std::string("GpuSlots: zigz_ctx_create failed: ") + zigz_status_name(st));
+        }
+        all_.push_back(c);
+    }
+    free_.assign(all_.rbegin(), all_.rend());  // (slot 0 is handed out first)
+}
+GpuSlots::~GpuSlots() {
+    for (zigz_ctx *c : all_) zigz_ctx_destroy(c);
+}
+zigz_ctx *GpuSlots::acquire() {
+    std::unique_lock<std::mutex> lk(m_);
+    const uint64_t mine = next_ticket_++;
+    cv_.wait(lk, [&] { return serving_ == mine && !free_.empty(); });
+    zigz_ctx *c = free_.back();
+    free_.pop_back();
+    serving_++;
+    if (!free_.empty() && serving_ != next_ticket_) cv_.notify_all();  // the next waiter may go at once
+    return c;
+}
+void GpuSlots::release(zigz_ctx *ctx) {
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        free_.push_back(ctx);
+    }
+    cv_.notify_all();
+}
+
 Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                                size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
-                               std::vector<uint8_t> *bytes_out) {
+                               std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps, const uint64_t *regs_before) {
     // transcript binding of the public inputs (prover.zig:91-110)
     bindPublicInputs(io.program_hash, io.initial_pc, initial_regs);
     const size_t num_steps = io.num_steps;
     if (num_steps == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
     Proof proof = Proof::init(num_steps);
     if (proof.metadata.num_vars != num_vars) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "witness num_vars != log2_int_ceil(num_steps)");
-    // [6/6 phase 1] Merkle builds do not depend on the transcript: start them first, asynchronously on
-    // the GPU, so they run underneath the sequential host absorption of steps 4 and 5.
-    // RAII: the job is ended (and the context's active-job slot released) on every exit path, including a bad_alloc
-    // between begin and the transcript work
+    for (double &t : timings) t = 0;
+    // RAII, in the order the destructors must run: the job is ended (and the context's active-job slot released) and the hint
+    // masks are put back BEFORE a borrowed context goes back to its pool -- on every exit path, including a bad_alloc between
+    // begin and the transcript work
+    GpuSlots::Lease lease;
+    // the hint masks are options of the CONTEXT: remember what its owner had set and put that back when this proof is done
+    // (on every exit path), whatever this proof sets below
+    struct MaskRestore {
+        zigz_ctx *ctx = nullptr;
+        int64_t sd = 0, ra = 0, cg = 0;
+        void arm(zigz_ctx *c) {
+            ctx = c;
+            (void)zigz_ctx_get_option(ctx, "small_domain_mask", &sd);
+            (void)zigz_ctx_get_option(ctx, "run_aware_mask", &ra);
+            (void)zigz_ctx_get_option(ctx, "cons_group_mask", &cg);
+        }
+        void restore() {
+            if (!ctx) return;
+            (void)zigz_ctx_set_option(ctx, "small_domain_mask", sd);
+            (void)zigz_ctx_set_option(ctx, "run_aware_mask", ra);
+            (void)zigz_ctx_set_option(ctx, "cons_group_mask", cg);
+            ctx = nullptr;
+        }
+        ~MaskRestore() { restore(); }
+    } mask_restore;
     struct JobGuard {
         zigz_commit_job *job = nullptr;
         ~JobGuard() { if (job) zigz_commit_end(job); }
     } guard;
-    double t0 = now_s();
     size_t c0 = 0, c1 = ZIGZ_NUM_COLUMNS;  // sharded: this rank commits its block of columns only
     if (shard_.world > 1) {
         if (shard_.rank < 0 || shard_.rank >= shard_.world || shard_.world > (int)ZIGZ_NUM_COLUMNS)
             throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "sharded prove: bad rank / world");
         columnBlock(ZIGZ_NUM_COLUMNS, shard_.world, shard_.rank, c0, c1);
     }
-    // Columns that hold values < 128 by construction (x0; opcode, rd, rs1, rs2, funct3, funct7; mem.is_read --
-    // witness.zig:164-169,239, registers.zig:38-48): their leaf and level-1 digests come from constant tables
-    // (zigz_hip.h, option "small_domain_mask"; checked on the device, identical trees for any input).
-    // the hint masks are options of the CONTEXT: remember what its owner had set and put that back when this proof is done
-    // (on every exit path), whatever this proof sets below
-    struct MaskRestore {
-        zigz_ctx *ctx;
-        int64_t sd = 0, ra = 0, cg = 0;
-        explicit MaskRestore(zigz_ctx *c) : ctx(c) {
-            (void)zigz_ctx_get_option(ctx, "small_domain_mask", &sd);
-            (void)zigz_ctx_get_option(ctx, "run_aware_mask", &ra);
-            (void)zigz_ctx_get_option(ctx, "cons_group_mask", &cg);
+    // [6/6 phase 1] Merkle builds do not depend on the transcript (prover.zig:405-416).  A prover with a context of its own
+    // starts them first, asynchronously on the GPU, so that they run underneath its sequential host absorption of steps 4 and
+    // 5; a prover of a service takes a GPU slot only after step 5 and starts them then (GpuSlots, zigz_host.hpp).
+    auto begin_job = [&]() {
+        double t0 = now_s();
+        mask_restore.arm(ctx_);
+        // Columns that hold values < 128 by construction (x0; opcode, rd, rs1, rs2, funct3, funct7; mem.is_read --
+        // witness.zig:164-169,239, registers.zig:38-48): their leaf and level-1 digests come from constant tables
+        // (zigz_hip.h, option "small_domain_mask"; checked on the device, identical trees for any input).
+        if (small_domain_tables) {
+            const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
+            check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
         }
-        ~MaskRestore() {
-            (void)zigz_ctx_set_option(ctx, "small_domain_mask", sd);
-            (void)zigz_ctx_set_option(ctx, "run_aware_mask", ra);
-            (void)zigz_ctx_set_option(ctx, "cons_group_mask", cg);
+        // The register columns x1..x31 are piecewise constant by construction: a step writes at most one register
+        // (VMState.writeReg, src/vm/state.zig), so together they change at most once per step.  Their large Merkle levels are
+        // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
+        // the values on the device; identical trees for any input).  So are mem.address and mem.value between memory accesses:
+        // a step that is not a LOAD / STORE records 0 in both (witness.zig:236-253), so each of them changes at most twice per
+        // memory access.  run_aware: 1 = the registers, 3 = registers + the two memory columns, 2 = every column that is not
+        // small-domain, 4 (default) = 3 + the ten columns that are functions of the instruction at pc -- pc, x0, opcode, rd, rs1,
+        // rs2, funct3, funct7, imm, is_read -- as a content-addressed group (zigz_hip.h, option "cons_group_mask": wherever the
+        // program loops the same nodes recur in all ten; probed first, dropped for a trace that does not repeat).
+        if (run_aware) {
+            const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
+            const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
+            const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware >= 3 ? regs | mem : regs;
+            if (run_aware == 4) {
+                const uint64_t group = 1ull | (1ull << 1) | (0x7full << 33) | (1ull << 42);
+                check(ctx_, zigz_ctx_set_option(ctx_, "cons_group_mask", (int64_t)((group >> c0) & ((1ull << (c1 - c0)) - 1))));
+            }
+            check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
         }
-    } mask_restore(ctx_);
-    if (small_domain_tables) {
-        const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
-        check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
-    }
-    // The register columns x1..x31 are piecewise constant by construction: a step writes at most one register
-    // (VMState.writeReg, src/vm/state.zig), so together they change at most once per step.  Their large Merkle levels are
-    // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
-    // the values on the device; identical trees for any input).  So are mem.address and mem.value between memory accesses:
-    // a step that is not a LOAD / STORE records 0 in both (witness.zig:236-253), so each of them changes at most twice per
-    // memory access.  run_aware: 1 = the registers, 3 = registers + the two memory columns, 2 = every column that is not
-    // small-domain, 4 (default) = 3 + the ten columns that are functions of the instruction at pc -- pc, x0, opcode, rd, rs1,
-    // rs2, funct3, funct7, imm, is_read -- as a content-addressed group (zigz_hip.h, option "cons_group_mask": wherever the
-    // program loops the same nodes recur in all ten; probed first, dropped for a trace that does not repeat).
-    if (run_aware) {
-        const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
-        const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
-        const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware >= 3 ? regs | mem : regs;
-        if (run_aware == 4) {
-            const uint64_t group = 1ull | (1ull << 1) | (0x7full << 33) | (1ull << 42);
-            check(ctx_, zigz_ctx_set_option(ctx_, "cons_group_mask", (int64_t)((group >> c0) & ((1ull << (c1 - c0)) - 1))));
+        if (steps) {  // the witness from the compact trace, inside the slot: upload + expansion + builds on one stream
+            const uint32_t *wc = nullptr;
+            size_t ws = 0;
+            check(ctx_, zigz_dev_witness_from_steps_ws(ctx_, steps, num_steps, num_vars, regs_before, &wc, &ws));
+            check(ctx_, zigz_commit_begin_dev(ctx_, wc + c0 * ws, c1 - c0, ws, num_vars, &guard.job));
+        } else if (witness) {
+            check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
+                                          (size_t)1 << num_vars, num_vars, &guard.job));
+        } else {
+            check(ctx_, zigz_commit_begin_dev(ctx_, d_cols + c0 * d_col_stride, c1 - c0, d_col_stride, num_vars, &guard.job));
         }
-        check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
-    }
-    if (witness)
-        check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
-                                      (size_t)1 << num_vars, num_vars, &guard.job));
-    else
-        check(ctx_, zigz_commit_begin_dev(ctx_, d_cols + c0 * d_col_stride, c1 - c0, d_col_stride, num_vars, &guard.job));
-    timings[0] = now_s() - t0;
+        timings[0] = now_s() - t0;
+    };
+    if (!slots_) begin_job();
     // packagePublicIO (:514-559) only copies VM results; doing it here lets the serialiser start early
     proof.public_io = io;
     if (initial_regs) proof.public_io.initial_regs = *initial_regs;
     else proof.public_io.initial_regs.reset();
     proof.lookup_placeholders = num_lookups;  // final before the writer thread exists
     bool writing = false;
+    double t_slot = 0;
     try {
-        t0 = now_s();
+        double t0 = now_s();
         generateSumcheckProof(proof, num_steps, num_vars);  // [4/6]
         timings[1] = now_s() - t0;
         if (bytes_out) {
@@ -381,15 +442,35 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         t0 = now_s();
         generateLassoProofs(proof, num_lookups);            // [5/6]
         timings[2] = now_s() - t0;
+        if (slots_) {
+            t0 = now_s();
+            lease.slots = slots_;
+            lease.ctx = ctx_ = slots_->acquire();
+            t_slot = now_s();
+            timings[8] = t_slot - t0;
+            begin_job();
+        }
         generateCommitments(proof, guard.job, num_vars);    // [6/6]
     } catch (...) {
         if (writing) try { t_helper.wait(); } catch (...) {}  // (the helper reads `proof`: it must be done before the unwind)
+        if (slots_) ctx_ = nullptr;  // (the guards release the job, the masks and the slot, in that order)
         throw;
     }
     zigz_commit_end(guard.job);
     guard.job = nullptr;
+    if (slots_) {  // what the caller may want to know about the context this proof ran on, before somebody else has it
+        (void)zigz_ctx_get_stats(ctx_, &last_stats);
+        size_t n = 0;
+        last_log.resize(80);
+        if (zigz_ctx_launch_log(ctx_, last_log.data(), last_log.size(), &n) != ZIGZ_OK) n = 0;
+        last_log.resize(n < last_log.size() ? n : last_log.size());
+        mask_restore.restore();
+        lease.drop();
+        ctx_ = nullptr;
+        timings[9] = now_s() - t_slot;
+    }
     if (bytes_out) {
-        t0 = now_s();
+        double t0 = now_s();
         t_helper.wait();
         BinarySerializer::writeCommitments(proof, bytes_out->data() + BinarySerializer::prefixSize(proof));
         timings[7] = now_s() - t0;
@@ -432,9 +513,11 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
         void *p = nullptr;
         ~DevCols() { if (p) zigz_dev_free(ctx, p); }
     } dcols{ctx_};
-    check(ctx_, zigz_dev_alloc(ctx_, ROW_WORDS * stride * sizeof(uint32_t), &dcols.p));
-    check(ctx_, zigz_dev_witness_from_steps(ctx_, vm->trace.steps.data(), num_steps, nv, vm->trace.initial_regs, (uint32_t *)dcols.p,
-                                            stride));
+    if (!slots_) {  // (a prover of a service builds the witness inside its GPU slot, from the records: proveWitnessImpl)
+        check(ctx_, zigz_dev_alloc(ctx_, ROW_WORDS * stride * sizeof(uint32_t), &dcols.p));
+        check(ctx_, zigz_dev_witness_from_steps(ctx_, vm->trace.steps.data(), num_steps, nv, vm->trace.initial_regs, (uint32_t *)dcols.p,
+                                                stride));
+    }
     // [3/6] constraint system: only the number of lookup constraints is observable (builder.zig:253-267)
     size_t L = 0;
     for (uint8_t f : vm->trace.is_lookup) L += f;
@@ -444,6 +527,7 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     io.final_regs = fr;
     io.num_steps = num_steps;
     if (!vm->output_tape.empty()) io.outputs = vm->output_tape;
+    if (slots_) return proveWitnessImpl(io, L, nullptr, nullptr, 0, nv, initial_regs, serialized, vm->trace.steps.data(), vm->trace.initial_regs);
     return proveWitnessImpl(io, L, nullptr, (const uint32_t *)dcols.p, stride, nv, initial_regs, serialized);
 }
 

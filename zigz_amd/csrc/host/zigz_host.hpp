@@ -8,7 +8,9 @@
 // sequential host logic (VM, transcript schedule, proof packaging).
 #pragma once
 #include <array>
+#include <condition_variable>
 #include <cstdint>
+#include <mutex>
 #include <optional>
 #include <stdexcept>
 #include <string>
@@ -275,9 +277,48 @@ inline void columnBlock(size_t ncols, int world, int rank, size_t &c0, size_t &c
     c1 = c0 + base + (r < extra ? 1 : 0);
 }
 
+// GPU slots of a proving service.  One proof needs the GPU for a few milliseconds -- Merkle builds, roots, openings -- and a
+// host core for tens: its sequential O(L) transcript (prover.zig:292-363).  A service that proves many traces at once
+// therefore does NOT give every proof in flight a context of its own (stream + tree / list workspaces: 0.6 GiB at 2^20,
+// 9-10 GiB at 2^24, held through the whole transcript): it keeps K contexts, and a proving thread takes one only between the
+// end of its step [5/6] and the end of its openings.  The reference's order permits that: the trees do not depend on the
+// transcript, the points do (prover.zig:405-424), so "begin" may run at any time before "roots".  Proofs in flight are then
+// bounded by host cores and by the witnesses themselves, not by HBM for workspaces; the overlap of one proof's build with
+// its own transcript is given up (it is other proofs' builds that keep the GPU busy meanwhile).
+// FIFO among waiters; the most recently released context is handed out first, so K may be generous: contexts that are never
+// needed never grow workspaces.
+class GpuSlots {
+  public:
+    GpuSlots(int device, size_t k);
+    ~GpuSlots();
+    GpuSlots(const GpuSlots &) = delete;
+    GpuSlots &operator=(const GpuSlots &) = delete;
+    zigz_ctx *acquire();
+    void release(zigz_ctx *ctx);
+    size_t size() const { return all_.size(); }
+    zigz_ctx *at(size_t i) const { return all_[i]; }  // set-up only (options, timing): while nobody proves
+    struct Lease {
+        GpuSlots *slots = nullptr;
+        zigz_ctx *ctx = nullptr;
+        ~Lease() { drop(); }
+        void drop() {
+            if (slots && ctx) slots->release(ctx);
+            ctx = nullptr;
+        }
+    };
+
+  private:
+    std::mutex m_;
+    std::condition_variable cv_;
+    std::vector<zigz_ctx *> all_, free_;
+    uint64_t next_ticket_ = 0, serving_ = 0;
+};
+
 class Prover {  // src/prover/prover.zig
   public:
     Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
+    // a prover of a service: the context is taken from `slots` for the GPU phases of each proof only (see GpuSlots)
+    Prover(GpuSlots *slots, uint64_t seed) : ctx_(nullptr), seed_(seed), slots_(slots) {}
     void setShard(const ShardSpec &s) { shard_ = s; }
     // prove(program, entry_pc, initial_regs, max_steps, segments, input), :73-226
     // serialized (optional): also BinarySerializer.serialize, with the early sections written underneath the transcript
@@ -293,9 +334,19 @@ class Prover {  // src/prover/prover.zig
     void proveWitnessToBytes(const PublicIO &io_template, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                              size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
                              std::vector<uint8_t> &out);
+    // The same from the compact trace records (zigz_trace_step, page-locked): the witness is built inside the proof's GPU
+    // slot, in a column buffer the slot's context owns (upload + expansion kernels + commit job on one stream) -- a proof in
+    // flight then holds nothing in HBM outside its slot.  Needs a prover of a service (GpuSlots).
+    void proveStepsToBytes(const PublicIO &io_template, size_t num_lookups, const zigz_trace_step *steps, const uint64_t *regs_before,
+                           size_t num_vars, const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out);
     // wall-clock seconds of the phases of the last proveWitness: 0 commit_begin, 1 sumcheck transcript,
-    // 2 lasso transcript, 3 wait for roots, 4 absorb roots + challenges, 5 open_all, 6 packaging
-    double timings[8] = {0};
+    // 2 lasso transcript, 3 wait for roots, 4 absorb roots + challenges, 5 open_all, 6 packaging, 7 serialisation tail,
+    // 8 wait for a GPU slot, 9 the whole time in the slot
+    double timings[10] = {0};
+    // a prover of a service: the kernel statistics (and, in timing mode, the launch log) of the context the last proof used,
+    // copied while it still held it
+    zigz_kernel_stats last_stats{};
+    std::vector<zigz_launch_rec> last_log;
     bool verbose = false;  // the reference prints progress banners unconditionally (prover.zig:82-85); off by default here
     // leaf / level-1 digests of the structurally small-domain witness columns by table lookup (identical trees); the
     // environment variable ZIGZ_DENSE_MERKLE=1 turns it off process-wide (A/B measurements)
@@ -316,9 +367,10 @@ class Prover {  // src/prover/prover.zig
     void generateCommitments(Proof &proof, zigz_commit_job *job, size_t num_vars);                                   // :366-467
     Proof proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                            size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
-                           std::vector<uint8_t> *bytes_out);
+                           std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps = nullptr, const uint64_t *regs_before = nullptr);
     zigz_ctx *ctx_;
     uint64_t seed_;
+    GpuSlots *slots_ = nullptr;
     FiatShamirTranscript transcript_;
     ShardSpec shard_;
 };

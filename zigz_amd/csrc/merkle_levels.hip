@@ -585,7 +585,8 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
     const size_t r_cap = uniform64(b.t.r_lists.cap[L]), g_cap = uniform64(b.t.g_lists.cap[L]);
     const size_t g_base = uniform64(b.t.g_lists.base[L]), g_base_c = uniform64(b.t.g_lists.base[LEAF ? 0 : L - 1]);
     const size_t g_rep_c = slab_level_offset(b.npad, LEAF ? 0 : L - 1);
-    const unsigned g_magic = gn ? (unsigned)(0x100000000ull / gn) : 0;  // floor(2^32 / group size)
+    // floor(2^32 / group size); a group of ONE column: 2^32 does not fit, and 2^32 - 1 gives "the quotient or one short of it" too
+    const unsigned g_magic = gn > 1 ? (unsigned)(0x100000000ull / gn) : 0xffffffffu;
 #pragma unroll 1
     for (size_t e = (size_t)blockIdx.x * TPB + threadIdx.x; e < total; e += (size_t)gridDim.x * TPB) {
         size_t col, k;

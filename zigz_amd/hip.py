@@ -50,7 +50,11 @@ def device_count():
 class Context:
     """zigz_ctx: one HIP device + stream + workspace.  Raises ZigzError(NoDevice) without a gfx950 GPU."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, _borrowed=None):
+        self.owned = _borrowed is None
+        if _borrowed is not None:  # a context somebody else owns (a GPU slot of host.Slots): never destroyed from here
+            self.h = _borrowed
+            return
         h = vp()
         rc = lib.zigz_ctx_create(device, C.byref(h))
         if rc != 0:
@@ -59,7 +63,8 @@ class Context:
 
     def close(self):
         if getattr(self, "h", None):
-            lib.zigz_ctx_destroy(self.h)
+            if self.owned:
+                lib.zigz_ctx_destroy(self.h)
             self.h = None
 
     def __del__(self):
@@ -143,6 +148,19 @@ class Context:
         s = KernelStats()
         self.check(lib.zigz_ctx_get_stats(self.h, C.byref(s)))
         return {f: getattr(s, f) for f, _ in KernelStats._fields_}
+
+    def set_epoch(self, owner=None):
+        """zigz_ctx_set_epoch: a new epoch of this context's (owner None) or the adoption of another context's: what the
+        times of launch_log() count from."""
+        self.check(lib.zigz_ctx_set_epoch(self.h, (owner or self).h))
+
+    def launch_log(self):
+        """zigz_ctx_launch_log: [(class, permutations, start_us, end_us)] of the timed launches of the last commit job."""
+        from ._ffi import LaunchRec
+        buf = (LaunchRec * 80)()
+        n = C.c_size_t()
+        self.check(lib.zigz_ctx_launch_log(self.h, buf, 80, C.byref(n)))
+        return [(buf[i].cls, buf[i].perms, buf[i].start_us, buf[i].end_us) for i in range(min(n.value, 80))]
 
     def bench_kernel(self, kernel, nv, ncols, iters=10, cold=True):
         """zigz_bench_kernel: per-launch kernel durations of one hot kernel on a synthetic resident table."""

@@ -39,6 +39,13 @@ SIGNATURES = {
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_trace_witness_dev_async": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
+    "zigzh_slots_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
+    "zigzh_slots_destroy": (None, [vp]),
+    "zigzh_slots_size": (C.c_size_t, [vp]),
+    "zigzh_slots_ctx": (vp, [vp, C.c_size_t]),
+    "zigzh_slots_acquire": (vp, [vp]),
+    "zigzh_slots_release": (None, [vp, vp]),
+    "zigzh_prove_trace_slots": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(u8p), szp, vp, vp, C.c_size_t, szp]),
     "zigzh_prove_trace_sharded": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.POINTER(u8p), szp]),
     "zigzh_vm_run": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, szp]),
     "zigzh_sumcheck_prove_bytes": (C.c_int, [vp, u64p, C.c_size_t, u8p, szp]),
@@ -80,12 +87,12 @@ def _take(ptr, n):
 
 
 TIMING_NAMES = ["commit_begin", "sumcheck_transcript", "lasso_transcript", "wait_roots", "roots_challenges", "open_all",
-                "packaging", "serialize"]
+                "packaging", "serialize", "wait_slot", "in_slot"]
 
 
 def last_timings():
     """Per-phase wall-clock seconds of the last Trace.prove on this thread."""
-    a = (C.c_double * 8)()
+    a = (C.c_double * 10)()
     lib.zigzh_last_timings(a)
     return dict(zip(TIMING_NAMES, list(a)))
 
@@ -175,6 +182,22 @@ class Trace:
             return BorrowedProof(out, n.value)
         return _take(out, n) if want_bytes else None
 
+    def prove_slots(self, slots, d_cols=None, stride=0, want_log=False):
+        """zigzh_prove_trace_slots: the proof of a thread of a proving service -- the transcript of steps 4-5 holding nothing
+        on the GPU, then a GPU slot of `slots` for begin -> roots -> challenges -> open_all -> end.  d_cols None: the compact
+        records are uploaded and expanded inside the slot (pin the trace first).  Returns (BorrowedProof, stats of the
+        context the proof ran on, its launch log in timing mode if want_log else None)."""
+        from ._ffi import KernelStats, LaunchRec
+        out, n = u8p(), C.c_size_t()
+        st = KernelStats()
+        log = (LaunchRec * 80)() if want_log else None
+        ln = C.c_size_t()
+        _check(lib.zigzh_prove_trace_slots(self.h, slots.h, vp(d_cols) if d_cols else None, stride, C.byref(out), C.byref(n),
+                                           C.byref(st), log, 80 if want_log else 0, C.byref(ln)))
+        stats = {f: getattr(st, f) for f, _ in KernelStats._fields_}
+        recs = [(log[i].cls, log[i].perms, log[i].start_us, log[i].end_us) for i in range(ln.value)] if want_log else None
+        return BorrowedProof(out, n.value), stats, recs
+
     def prove_sharded(self, ctx, d_cols, stride, dist, allgather=None):
         """ONE proof over dist.get_world_size() GPUs, sharded by column (zigzh_prove_trace_sharded): every rank holds
         the same trace and a resident copy of the 43 columns, commits / opens its own block, and returns the complete
@@ -193,6 +216,45 @@ class Trace:
 
 from ._ffi import ALLGATHER_FN  # noqa: E402  zigzh_allgather_fn == zigz_allgather_fn
 from .shard import make_allgather  # noqa: E402,F401  (the hook on torch.distributed)
+
+
+class Slots:
+    """GpuSlots (csrc/host/zigz_host.hpp): k contexts shared by the proving threads of a service; a proof holds one only for
+    its GPU phases (Trace.prove_slots).  ctx(i) / borrow(): the contexts themselves, for set-up and for work of the caller's
+    own (allocations, witness uploads)."""
+
+    def __init__(self, device, k):
+        h = vp()
+        _check(lib.zigzh_slots_create(device, k, C.byref(h)))
+        self.h, self.k, self.device = h, k, device
+
+    def ctx(self, i):
+        from .hip import Context
+        return Context(_borrowed=vp(lib.zigzh_slots_ctx(self.h, i)))
+
+    def contexts(self):
+        return [self.ctx(i) for i in range(self.k)]
+
+    def borrow(self):
+        slots = self
+
+        class _Lease:
+            def __enter__(self_l):
+                from .hip import Context
+                self_l.raw = vp(lib.zigzh_slots_acquire(slots.h))
+                return Context(_borrowed=self_l.raw)
+
+            def __exit__(self_l, *a):
+                lib.zigzh_slots_release(slots.h, self_l.raw)
+        return _Lease()
+
+    def close(self):
+        if getattr(self, "h", None):
+            lib.zigzh_slots_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        self.close()
 
 
 class BorrowedProof:
