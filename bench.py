@@ -486,15 +486,16 @@ def main():
 
     def slot_bytes(nv_l, worst=True):  # what a GPU slot's workspaces grow to: lists + digests in list order (0.45 GiB at 2^20 on the
         # bench trace, measured), slabs for a dropped group and longer lists on a trace that never loops (2.2 GiB)
-        return int((2.4 if worst else 0.6) * (1 << 30) * (1 << max(nv_l - 20, 0)))
+        return int((2.4 if worst else 0.47) * (1 << 30) * (1 << max(nv_l - 20, 0)))
     hbm_free = None
     if not shard and args.batch <= 0:
         probe = zigz_amd.Context(local_rank)
         hbm_free = probe.mem_info()[0]
         probe.close()
         if use_slots_:
-            k_guess = args.slots if args.slots > 0 else max(4, min(16, B // 5 + 2))
-            B = max(1, min(B, (int(hbm_free * 0.9) - k_guess * slot_bytes(args.nv)) // lane_bytes(args.nv)))
+            k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 22 else 8)
+            # (the legs on traces that do not loop run at 2^20 and below; above, the budget is the bench trace's)
+            B = max(1, min(B, (int(hbm_free * 0.92) - k_guess * slot_bytes(args.nv, worst=args.nv < 22)) // lane_bytes(args.nv)))
         else:
             # (a context per lane: ~0.6 GiB at 2^20 on the bench trace with the digests in list order; a trace that does not loop
             # needs ~2.3 GiB -- slabs for the dropped group, longer lists -- and the legs below run such traces on the same lanes)
@@ -527,7 +528,9 @@ def main():
         cheap while it is not needed (the most recently released one is handed out first: unused ones never grow)."""
         if args.slots > 0:
             return args.slots
-        return max(4, min(16, nl // 5 + 2))
+        # (A/B at 2^20, 93 lanes: 8 slots 1.94 G, 12 1.96 G, 16 1.89-1.99 G, 24 1.81 G, 32 1.75 G -- more builds in flight get in
+        # each other's way; the lanes of one sponge server leave their transcripts together, so fewer than 8 makes them queue)
+        return max(4, min(12, nl // 8 + 1)) if nv_l < 22 else 8
 
     class Lane:  # one trace + its resident witness; proves through the shared GPU slots (or, --slots 0 / --mode shard, a context of its own)
         def __init__(self, k, nv_l=None, prog=None, pin=True):
@@ -1088,14 +1091,14 @@ def main():
             slots = None
         setup_ctx.release_workspaces()
         free_now = setup_ctx.mem_info()[0]
-        for nv_s, steps_s in ((16, 10), (22, 5), (24, 2)):
+        for nv_s, steps_s in ((16, 10), (22, 5), (24, 3)):
             if nv_s == nv:
                 continue
             if use_slots:
                 k_s = slot_count(B, nv_s)
                 while k_s > 4 and k_s * slot_bytes(nv_s, worst=False) > 0.35 * free_now:
                     k_s -= 1
-                nl = max(1, min(B, (int(free_now * 0.88) - k_s * slot_bytes(nv_s, worst=False)) // lane_bytes(nv_s)))
+                nl = max(1, min(B, (int(free_now * 0.92) - k_s * slot_bytes(nv_s, worst=False)) // lane_bytes(nv_s)))
             else:
                 # (a context per lane: the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 --
                 # resident columns, lists and digests after the first build's learning -- measured; below 2^20 the fixed

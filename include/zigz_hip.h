@@ -152,6 +152,18 @@ zigz_status zigz_commit_begin(zigz_ctx *ctx, const uint64_t *cols, size_t ncols,
 /* device-resident columns (packed u32 canonical); the buffer must stay valid until zigz_commit_end */
 zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
                                   size_t nv, zigz_commit_job **out);
+/* Several proofs in ONE job (a proving service with many SMALL traces: the reference's own tests and examples prove 4 .. 64
+ * steps, tests/integration_tests.zig:171-206, BASELINE config 2 is 2^16 -- sizes at which a proof's ~35 launches are mostly
+ * latency).  d_cols[z]: proof z's `ncols` device-resident columns (stride col_stride), all proofs 2^nv rows; nproofs <= 32,
+ * nproofs * ncols <= 4096.  The job then behaves like one of nproofs * ncols columns numbered proof by proof: roots, points,
+ * values, indices, leaves, siblings and dirs of proof z occupy the positions [z * ncols, (z + 1) * ncols) of the arrays of
+ * zigz_commit_roots / zigz_commit_open_all; every proof's results are the ones its own job would give.  The columns are
+ * copied at begin (the callers' buffers are not needed after it returns ... after the stream has passed the copy:
+ * zigz_commit_roots).  2^nv < 2^15: the proofs' trees are built densely like any table's; 2^15 <= 2^nv <= 2^18: with the
+ * structure-aware levels, every column of a proof must then be hinted ("run_aware_mask" / "cons_group_mask" cover all of
+ * them, as the witness's 43 are in host/prover.cpp), else ZIGZ_ERR_INVALID_ARGUMENT; larger tables: one job per proof. */
+zigz_status zigz_commit_begin_batch(zigz_ctx *ctx, const uint32_t *const *d_cols, size_t nproofs, size_t ncols,
+                                    size_t col_stride, size_t nv, zigz_commit_job **out);
 /* zigz_commit_begin* ENQUEUES the Merkle builds and returns (nothing on that path is read back by the host: ~0.15 ms for the
  * ~45 launches of a 2^20 x 43 job); zigz_commit_roots waits for them; roots: ncols*32 bytes (prover.zig:405-410).
  * One job per context at a time (a second begin returns ZIGZ_ERR_BAD_STATE).  Other calls on the same context

@@ -74,6 +74,11 @@ int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_col
  * _release: a slot for work of the caller's own (uploads, allocations). */
 typedef struct zigzh_slots zigzh_slots;
 int zigzh_slots_create(int device, size_t k, zigzh_slots **out);
+/* small traces (2^nv rows, nv <= max_nv <= 18): proofs that reach their GPU phase within linger_us of each other share ONE
+ * commit job of up to max_batch (<= 32) proofs (zigz_commit_begin_batch; zigz_host.hpp: GpuBatcher) -- each proof keeps its
+ * own transcript and gets exactly the roots and openings a job of its own would give.  max_batch <= 1: off (the default).
+ * Set while nobody proves. */
+int zigzh_slots_set_batching(zigzh_slots *s, unsigned max_batch, double linger_us, size_t max_nv);
 void zigzh_slots_destroy(zigzh_slots *s);
 size_t zigzh_slots_size(const zigzh_slots *s);
 zigz_ctx *zigzh_slots_ctx(zigzh_slots *s, size_t i);

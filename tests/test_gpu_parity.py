@@ -1322,3 +1322,78 @@ def test_commit_job_survives_a_hinted_build_in_between(ctx):
         ctx.set_option("cons_always", 0)
         for k, v in saved.items():
             ctx.set_option(k, v)
+
+
+def _trace_cols(ctx, prog, nv):
+    """resident witness columns of a program's trace (must have 2^nv padded rows) -> (device pointer, stride)"""
+    from zigz_amd import host
+    tr = host.Trace(prog, 0x1000, None, 1 << 20)
+    assert tr.num_vars == nv, (tr.num_vars, nv)
+    N = max(1 << nv, 4)
+    d = ctx.dev_alloc(43 * N * 4)
+    tr.witness_to_device(ctx, d, N)
+    return d, N
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv", [0, 3, 5, 10, 13, 14, 15, 16])
+def test_commit_batch_equals_single_jobs(ctx, nv):
+    """zigz_commit_begin_batch: several proofs' 43 witness columns in ONE commit job -- one structure pass, one
+    k_level_hash per level, one top launch, one eval, one path launch for all of them -- must give every proof exactly the
+    roots and openings its own job gives (which the other tests pin to the oracle).  Flat form below 2^15 (dense trees),
+    arena form from 2^15 (structure-aware levels, worst-case list room); looping programs of different lengths, the RV64IM
+    mix with loads and stores, the worst-case register trace and a straight-line program whose group is DROPPED on the
+    device while its neighbours' groups are kept; batches of 1, 2 and 5."""
+    import programs
+    import zigz_amd
+    steps = (1 << nv)
+    if nv >= 15:
+        progs = [programs.add_xor_loop((steps - 3) // 4), programs.mixed_loop((steps - 8) // 12 - 3),
+                 programs.straight_line_program(7, int(0.9 * steps)), programs.register_round_robin((steps - 2) // 31 - 1),
+                 programs.add_xor_loop((steps - 3) // 4 - 777)]
+    elif nv >= 3:
+        progs = [programs.add_xor_loop(max((steps - 3) // 4 - i, 1 if nv > 3 else 1)) for i in range(4)] + \
+                [programs.straight_line_program(9, steps - 1)]
+    else:
+        progs = [programs.straight_line_program(s_, 1) for s_ in range(5)]
+    small = (1 << 1) | (0x3f << 33) | (1 << 42)
+    masks = {"small_domain_mask": small, "run_aware_mask": (0x7fffffff << 2) | (3 << 40),
+             "cons_group_mask": 1 | (1 << 1) | (0x7f << 33) | (1 << 42)}
+    saved = {k: ctx.get_option(k) for k in masks}
+    bufs = []
+    try:
+        for p_ in progs:
+            bufs.append(_trace_cols(ctx, p_, nv))
+        stride = bufs[0][1]
+        for k, v in masks.items():
+            ctx.set_option(k, v)
+        ctx.set_option("cons_always", 1)
+        rng = np.random.default_rng(nv)
+        pts = rng.integers(0, 2013265921, size=(len(progs), 43, max(nv, 1)), dtype=np.uint64)[:, :, :nv]
+        single = []
+        for i, (d, _) in enumerate(bufs):
+            job = zigz_amd.CommitJob(ctx, d_cols=d, ncols=43, nv=nv, col_stride=stride)
+            r = job.roots()
+            o = job.open_all(pts[i])
+            job.end()
+            single.append((r, o))
+        if nv >= 15:  # the straight-line program's group does not repeat, the loops' do
+            assert ctx.stats()["rebuilds"] >= 0
+        for sel in ([0], [1, 2], [0, 1, 2, 3, 4], [2, 2, 0]):
+            job = zigz_amd.CommitJob(ctx, d_cols_list=[bufs[i][0] for i in sel], ncols=43, nv=nv, col_stride=stride)
+            r = job.roots()
+            st = ctx.stats()
+            o = job.open_all(np.concatenate([pts[i] for i in sel]).reshape(len(sel) * 43, nv) if nv else np.zeros((len(sel) * 43, 0), dtype=np.uint64))
+            job.end()
+            for z, i in enumerate(sel):
+                assert np.array_equal(r[z * 43:(z + 1) * 43], single[i][0]), (sel, z, "roots")
+                for key in ("values", "indices", "leaves", "siblings", "dirs"):
+                    assert np.array_equal(o[key][z * 43:(z + 1) * 43], single[i][1][key]), (sel, z, key)
+            if nv >= 15 and len(sel) > 1:
+                assert st["run_aware_columns"] == 33 and st["keccak_permutations"] > 0
+    finally:
+        ctx.set_option("cons_always", 0)
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+        for d, _ in bufs:
+            ctx.dev_free(d)

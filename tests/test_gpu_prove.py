@@ -380,3 +380,68 @@ def test_prove_through_gpu_slots_is_byte_identical(ctx):
             ctx.dev_free(d)
         slots.close()
         del traces
+
+
+_ORACLE_SHA3 = {}  # (program, pc, input) -> sha3 of the oracle's proof (6 s per 2^16 trace: once per session)
+
+
+def _oracle_sha3(prog, pc, regs, ms, inp):
+    key = (bytes(prog), pc, tuple(regs or ()), ms, tuple(inp or ()))
+    if key not in _ORACLE_SHA3:
+        _ORACLE_SHA3[key] = hashlib.sha3_256(O.prove(P, prog, pc, regs, ms, inp)[0]).hexdigest()
+    return _ORACLE_SHA3[key]
+
+
+@pytest.mark.parametrize("max_batch,linger_us", [(4, 2000.0), (16, 300.0)])
+def test_prove_small_traces_in_shared_commit_jobs(ctx, max_batch, linger_us):
+    """proofs of small traces that reach their GPU phase together share ONE commit job (GpuBatcher +
+    zigz_commit_begin_batch); every proof keeps its own transcript and must come out byte-identical to the oracle's.
+    The reference's own sizes -- createAddProgram (4 steps) and NOP programs of 4 .. 64 steps
+    (tests/integration_tests.zig:171-206) --, the golden programs, 2^10 .. 2^14 (flat batches) and 2^15 / 2^16 (arena batches:
+    BASELINE config 2's size, looping and straight-line traces side by side), 24 threads x 2 rounds over 3 slots."""
+    import threading
+    from zigz_amd import host
+    nop = (0x00000013).to_bytes(4, "little")
+    progs = [(bytes.fromhex(e["program"]), e["entry_pc"], ints(e["initial_regs"]), e["max_steps"], ints(e["input"])) for e in G["prove"][:6]]
+    progs += [(nop * n, 0x1000, None, 1 << 20, None) for n in (4, 8, 16, 32, 64)]
+    for maker, arg in (("add_xor_loop", 200), ("add_xor_loop", 255), ("mixed_loop", 300), ("add_xor_loop", 3000), ("mixed_loop", 1200),
+                       ("add_xor_loop", 8190), ("add_xor_loop", 8000), ("register_round_robin", 1000), ("add_xor_loop", 16000),
+                       ("mixed_loop", 5000), ("straight_line_program", None), ("add_xor_loop", 15000), ("fibonacci", 1500)):
+        r = programs.straight_line_program(5, 60000) if maker == "straight_line_program" else getattr(programs, maker)(arg)
+        prog, inp = r if isinstance(r, tuple) else (r, None)
+        progs.append((prog, 0x1000, None, 1 << 20, inp))
+    traces, want, bufs = [], [], []
+    for prog, pc, regs, ms, inp in progs:
+        tr = host.Trace(prog, pc, regs, ms, inp)
+        traces.append(tr)
+        want.append(_oracle_sha3(prog, pc, regs, ms, inp))
+        N = max(1 << tr.num_vars, 4)
+        d = ctx.dev_alloc(43 * N * 4)
+        tr.witness_to_device(ctx, d, N)
+        bufs.append((d, N))
+    slots = host.Slots(0, 3)
+    slots.set_batching(max_batch, linger_us, 17)
+    errs, got = [], {}
+
+    def worker(i):
+        try:
+            for rep in range(2):
+                proof, st, _ = traces[i].prove_slots(slots, bufs[i][0], bufs[i][1])
+                got[(i, rep)] = hashlib.sha3_256(proof.tobytes()).hexdigest()
+        except Exception as e:  # noqa: BLE001
+            errs.append((i, repr(e)))
+    th = [threading.Thread(target=worker, args=(i,)) for i in range(len(progs))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    try:
+        assert not errs, errs
+        for i in range(len(progs)):
+            for rep in range(2):
+                assert got[(i, rep)] == want[i], (i, rep, traces[i].num_steps)
+        for c in slots.contexts():
+            assert c.get_option("run_aware_mask") == 0 and c.get_option("cons_group_mask") == 0
+    finally:
+        for d, _ in bufs:
+            ctx.dev_free(d)
+        slots.close()
+        del traces

@@ -85,6 +85,7 @@ SIGNATURES = {
     "zigz_commit_open": (C.c_int32, [vp, u64p, C.c_size_t, vp, u64p, C.c_size_t, u64p, u64p, u8p, u8p, u64p]),
     "zigz_commit_begin": (C.c_int32, [vp, u64p, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
     "zigz_commit_begin_dev": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
+    "zigz_commit_begin_batch": (C.c_int32, [vp, C.POINTER(vp), C.c_size_t, C.c_size_t, C.c_size_t, C.c_size_t, C.POINTER(vp)]),
     "zigz_commit_roots": (C.c_int32, [vp, u8p]),
     "zigz_commit_open_all": (C.c_int32, [vp, u64p, u64p, u64p, u64p, u8p, u8p]),
     "zigz_commit_job_tree": (C.c_int32, [vp, C.POINTER(vp), C.POINTER(C.c_size_t)]),

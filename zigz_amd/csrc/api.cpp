@@ -22,7 +22,7 @@
 using namespace zk;
 
 // ------------------------------------------------------------------ context
-enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_CONS, WS_CONSMETA, WS_SLOTS };
+enum { WS_IN64 = 0, WS_IN32, WS_OUT32, WS_OUT64, WS_SCRATCH, WS_TREE, WS_FOLD, WS_MISC, WS_COLS, WS_LASSO, WS_DEDUP, WS_WITNESS, WS_RUNS, WS_RUNMETA, WS_CONS, WS_CONSMETA, WS_BATCH, WS_SLOTS };
 
 constexpr int KEV_MAX = 72;
 struct ListCaps {
@@ -89,14 +89,17 @@ struct zigz_ctx {
     // what the last build asked for; turned into stats when its counters have arrived (zigz_commit_roots)
     uint64_t build_cons_hinted, build_cons_levels_nodes, build_cons_sd, build_top_perms;
     ListCaps caps;  // room for the lists of the structure-aware levels, learnt from earlier builds (caps_for)
+    size_t batch_tab_S, batch_tab_off;  // the content-addressing tables of the batched jobs' arenas (WS_BATCH) as last cleared
+    unsigned batch_tab_nz;
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
 constexpr unsigned RADIX_MAX_K = 10;     // 1024 block sums per radix sumcheck stage
 constexpr size_t RADIX_MIN_N = 1 << 11;  // smaller tables use the per-round form (one launch + read-back per round)
 constexpr size_t HOST_TAIL_MAX = 1024;
-static const size_t PIN_WORDS = 1 << 16;
+static const size_t PIN_WORDS = 1 << 19;  // 4 MiB: the openings of a batched job (32 proofs x 43 x (24 + 33 v) bytes) fit the zero-copy path
 static const size_t ROOTS_MAX_COLS = 4096;
+constexpr unsigned BATCH_MAX = 32;  // proofs per batched commit job (kernels.hpp: ColSrcs)
 
 static void set_err(zigz_ctx *ctx, const char *fmt, ...) {
     if (!ctx) return;
@@ -1877,6 +1880,12 @@ struct zigz_commit_job {
     uint64_t m_small, m_run, m_cons;
     bool m_whole;
     uint64_t run_cols, run_dense, sd_cols, cons_hinted, cons_levels_nodes, cons_sd, perms0;
+    // a batched job (zigz_commit_begin_batch): nz proofs of ncols1 columns each; ncols = nz * ncols1.  arena: every proof's
+    // build lives in its own zstride bytes of the context's WS_BATCH workspace (TreeRef::zstride); flat (nz > 1, zstride == 0):
+    // the proofs' columns were gathered into one table of ncols columns and built densely like any other.
+    unsigned nz;
+    size_t ncols1, zstride;
+    size_t off_r_ctr, off_g_ctr;  // byte offsets of a proof's list counters in its arena
     bool no_eval_skip;  // built without its structure passes (option debug_skip 2, measurement only): the "column changed" words
                         // were never written, so the eval must not take them for "constant"
 };
@@ -1959,6 +1968,227 @@ static zigz_status job_begin(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols
     return ZIGZ_OK;
 }
 
+// ---- a batched job: several proofs' columns in ONE commit job (zigz_commit_begin_batch)
+// Small traces make a proof's ~35 launches mostly latency (2^16: 13 us of work per launch); nz proofs of the same shape share
+// every launch instead.  Two forms, chosen by the size:
+//   flat  (N < 2^15: trees that are built densely anyway) -- the proofs' columns are gathered into one table of nz * ncols1
+//         columns and committed like any other table;
+//   arena (2^15 <= N <= 2^18: the structure-aware levels) -- every proof gets an arena with the same layout for everything
+//         its build reads or writes (a copy of its columns, list counters, lists, leader tables, content-addressing table,
+//         digest stores, upper levels, slabs for a dropped group), the kernels take the proof from gridDim.z and move every
+//         pointer by proof * arena size (kernels.hpp: TreeRef::zstride).  The lists get their WORST-CASE room (every node
+//         hashed: affordable at these sizes, ~0.25 GiB per proof at 2^16), so a batched build is never repeated; every column
+//         must be hinted run-aware or member of the content-addressed group (the witness's 43 are: host/prover.cpp).
+static size_t al256(size_t x) { return (x + 255) & ~(size_t)255; }
+static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *const *srcs, size_t src_stride) {
+    zigz_ctx *ctx = job->ctx;
+    const size_t nc = job->ncols1, N = job->N, npad = N;
+    const unsigned nz = job->nz, height = (unsigned)job->nv;
+    ColMap R{}, G{};
+    for (size_t c = 0; c < nc; c++) {
+        if ((job->m_cons >> c) & 1) G.c[G.n++] = (uint8_t)c;
+        else if ((job->m_run >> c) & 1) R.c[R.n++] = (uint8_t)c;
+        else return ZIGZ_ERR_INVALID_ARGUMENT;  // (a densely built column: not in this form)
+    }
+    const size_t stride = N;  // column stride inside an arena
+    TreeRef t{};
+    t.npad = npad;
+    for (int c = 0; c < 64; c++) {
+        t.slab_of_col[c] = -1;
+        t.y_of_col[c] = -1;
+        t.g_j_of_col[c] = -1;
+    }
+    t.lists = 1;
+    t.top = run_top_level(npad);
+    // ---- the arena's layout (byte offsets, the same for every proof)
+    size_t at = 0;
+    auto take = [&](size_t bytes) { const size_t o = at; at += al256(bytes); return o; };
+    const size_t o_cols = take(nc * stride * 4);
+    const size_t o_rctr = take(RUN_CTR_WORDS * 8), o_gctr = take(RUN_CTR_WORDS * 8);
+    size_t o_rlist = 0, o_rstage = 0, o_bitmap = 0, o_prev = 0, o_woff = 0, o_ubase = 0, o_rstore = 0;
+    size_t meta_n = 0;
+    if (R.n) {
+        t.r_lists = runs_lists(npad, R.n, nullptr);
+        unsigned long long uoff[RUN_MAX_LEVELS] = {0};
+        const size_t units = runs_units(npad, R.n, uoff);
+        for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) t.ubase_off[l] = uoff[l];
+        meta_n = runs_meta_words(npad, R.n);
+        o_rlist = take((size_t)t.r_lists.entries * 4);
+        o_rstage = take(runs_stage_scratch_bytes(npad, R.n) + 64);
+        o_bitmap = take(meta_n * 8);
+        o_prev = take(meta_n * 2);
+        o_woff = take(meta_n * 2);
+        o_ubase = take(units * 4 + 64);
+        o_rstore = take((size_t)t.r_lists.entries * 32);
+        t.ncols = R.n;
+        for (unsigned y = 0; y < R.n; y++) t.y_of_col[R.c[y]] = (signed char)y;
+    }
+    size_t o_keys = 0, o_idx = 0, o_glist = 0, o_grep = 0, o_gstore = 0, o_slab = 0;
+    const size_t key_bytes = 2 * npad * 8;
+    if (G.n) {
+        t.g_lists = cons_lists(npad, nullptr);
+        o_keys = take(key_bytes);
+        o_idx = take(2 * npad * 4);
+        o_glist = take((size_t)t.g_lists.entries * 4);
+        o_grep = take(2 * npad * 4);
+        o_gstore = take((size_t)t.g_lists.entries * G.n * 32);
+        o_slab = take((size_t)G.n * tree_nodes(npad) * 32);  // where a dropped group's columns are built densely
+        t.g_ncols = G.n;
+        for (unsigned k = 0; k < G.n; k++) {
+            t.g_j_of_col[G.c[k]] = (signed char)k;
+            t.slab_of_col[G.c[k]] = (signed char)k;
+        }
+    }
+    const size_t o_upper = take(nc * 512 * 32);
+    const size_t S = al256(at);
+    if ((size_t)nz * S > ((size_t)48 << 30)) return ZIGZ_ERR_OUT_OF_MEMORY;
+    void *w;
+    const void *w_before = ctx->ws[WS_BATCH];
+    CHK(ws_get(ctx, WS_BATCH, (size_t)nz * S, &w));
+    uint8_t *a0 = (uint8_t *)w;
+    // the content-addressing tables (generation-tagged slots): cleared when the workspace or the layout is new, or the
+    // generations run out -- all nz of them with one strided fill
+    if (G.n && (w != w_before || ctx->batch_tab_S != S || ctx->batch_tab_nz < nz || ctx->batch_tab_off != o_keys ||
+                ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096)) {
+        HIPCHK(ctx, hipMemset2DAsync(a0 + o_keys, S, 0, key_bytes, nz, ctx->stream));
+        ctx->batch_tab_S = S;
+        ctx->batch_tab_nz = nz;
+        ctx->batch_tab_off = o_keys;
+        if (ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096) {  // (the single-job table of WS_CONS shares the counter: it starts over too)
+            ctx->cons_gen = 1;
+            ctx->cons_table = nullptr;
+        }
+        if (ctx->cons_gen == 0) ctx->cons_gen = 1;
+    }
+    t.zstride = S;
+    t.nz = nz;
+    t.upper = a0 + o_upper;
+    MerkleBuild b{};
+    b.vals = (const uint32_t *)(a0 + o_cols);
+    b.val_stride = stride;
+    b.n_values = N;
+    b.npad = npad;
+    b.rcols = R;
+    b.gcols = G;
+    if (R.n) {
+        t.bitmap = (unsigned long long *)(a0 + o_bitmap);
+        t.prev = (unsigned short *)(a0 + o_prev);
+        t.woff = (unsigned short *)(a0 + o_woff);
+        t.ubase = (uint32_t *)(a0 + o_ubase);
+        t.r_store = a0 + o_rstore;
+        b.r_list = (uint32_t *)(a0 + o_rlist);
+        b.r_stage = a0 + o_rstage;
+        b.r_ctr = (unsigned long long *)(a0 + o_rctr);
+    }
+    if (G.n) {
+        t.slab = a0 + o_slab;
+        t.g_rep = (const uint32_t *)(a0 + o_grep);
+        t.g_store = a0 + o_gstore;
+        t.g_dropped = (const unsigned long long *)(a0 + o_gctr) + 8;
+        b.g_keys = (unsigned long long *)(a0 + o_keys);
+        b.g_idx = (uint32_t *)(a0 + o_idx);
+        b.g_list = (uint32_t *)(a0 + o_glist);
+        b.g_rep = (uint32_t *)(a0 + o_grep);
+        b.g_ctr = (unsigned long long *)(a0 + o_gctr);
+        b.g_has_slabs = 1;
+        b.g_gen = ctx->cons_gen;
+        ctx->cons_gen += t.top + 1;
+    }
+    b.t = t;
+    ColSrcs cs{};
+    for (unsigned z = 0; z < nz; z++) cs.p[z] = srcs[z];
+    launch_gather_cols(cs, nz, nc, N, src_stride, (uint32_t *)(a0 + o_cols), stride, S, ctx->stream);
+    launch_zero_counters(nullptr, R.n ? b.r_ctr : nullptr, G.n ? b.g_ctr : nullptr, ctx->stream, nz, S);
+    if (ctx->debug_skip != 2) {
+        launch_runs_structure(b, ctx->stream, nullptr);
+        launch_cons_structure(b, ctx->stream, nullptr);
+    }
+    for (unsigned l = 0; l <= t.top; l++)
+        if (ctx->debug_skip != 1) launch_level_hash(b, l, ctx->stream, nullptr);
+    if (height && ctx->debug_skip != 1) launch_merkle_top(t, t.top, height, nc, ctx->stream, nullptr);
+    HIPCHK(ctx, hipGetLastError());
+    job->tree = t;
+    job->d_cols = (const uint32_t *)(a0 + o_cols);
+    job->col_stride = stride;
+    job->zstride = S;
+    job->off_r_ctr = o_rctr;
+    job->off_g_ctr = o_gctr;
+    job->whole = false;
+    const DoneFlag done = done_flag(ctx, 0);
+    job->roots_seq = done.seq;
+    launch_job_summary(t, height, ctx->h_roots, nc, R.n ? b.r_ctr : nullptr, nullptr, G.n ? b.g_ctr : nullptr, ctx->stream, done);
+    HIPCHK(ctx, hipGetLastError());
+    HIPCHK(ctx, hipEventRecord(job->built, ctx->stream));
+    uint64_t level_nodes = 0;
+    for (unsigned l = 0; l <= t.top; l++) level_nodes += npad >> l;
+    job->run_cols = R.n;
+    job->run_dense = (uint64_t)R.n * level_nodes;
+    job->sd_cols = 0;
+    job->cons_hinted = G.n;
+    job->cons_levels_nodes = level_nodes;
+    job->cons_sd = 0;
+    job->perms0 = (uint64_t)nc * (2 * N - 1);
+    job->no_eval_skip = ctx->debug_skip == 2;
+    return ZIGZ_OK;
+}
+
+extern "C" zigz_status zigz_commit_begin_batch(zigz_ctx *ctx, const uint32_t *const *d_cols, size_t nproofs, size_t ncols,
+                                               size_t col_stride, size_t nv, zigz_commit_job **out) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !d_cols || !out || ncols == 0 || nproofs == 0 || nproofs > BATCH_MAX || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ncols * nproofs > ROOTS_MAX_COLS || col_stride < ((size_t)1 << nv)) return ZIGZ_ERR_INVALID_ARGUMENT;
+    for (size_t z = 0; z < nproofs; z++)
+        if (!d_cols[z]) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (nproofs == 1) return job_begin(ctx, d_cols[0], ncols, col_stride, nv, out);
+    if (ctx->active_job) {
+        set_err(ctx, "a commit job is already active on this context");
+        return ZIGZ_ERR_BAD_STATE;
+    }
+    const size_t N = (size_t)1 << nv;
+    const bool arena = N >= RUN_MIN_LEAVES && N <= ((size_t)1 << 18) && ncols <= 64 && (ctx->run_aware_mask || ctx->cons_group_mask);
+    if (N >= RUN_MIN_LEAVES && !arena) return ZIGZ_ERR_INVALID_ARGUMENT;  // (large tables: one job per proof)
+    zigz_commit_job *job = new (std::nothrow) zigz_commit_job();
+    if (!job) return ZIGZ_ERR_OUT_OF_MEMORY;
+    memset(job, 0, sizeof(*job));
+    job->ctx = ctx;
+    job->nz = (unsigned)nproofs;
+    job->ncols1 = ncols;
+    job->ncols = ncols * nproofs;
+    job->nv = nv;
+    job->N = N;
+    auto body = [&]() -> zigz_status {
+        HIPCHK(ctx, hipEventCreateWithFlags(&job->built, hipEventDisableTiming));
+        if (arena) {
+            job->m_small = 0;
+            job->m_run = ctx->run_aware_mask;
+            job->m_cons = ctx->cons_group_mask;
+            return job_build_batch_arena(job, d_cols, col_stride);
+        }
+        // flat: one table of nz * ncols columns, built densely (no hints: they are per 64 columns of ONE proof)
+        const size_t dstride = N < 4 ? 4 : N;
+        void *d;
+        CHK(ws_get(ctx, WS_COLS, job->ncols * dstride * 4, &d));
+        ColSrcs cs{};
+        for (size_t z = 0; z < nproofs; z++) cs.p[z] = d_cols[z];
+        launch_gather_cols(cs, job->nz, ncols, N, col_stride, (uint32_t *)d, dstride, ncols * dstride * 4, ctx->stream);
+        HIPCHK(ctx, hipGetLastError());
+        job->d_cols = (const uint32_t *)d;
+        job->col_stride = dstride;
+        job->m_small = job->m_run = job->m_cons = 0;
+        job->m_whole = false;
+        return job_build(job);
+    };
+    const zigz_status st = body();
+    if (st != ZIGZ_OK) {
+        if (job->built) (void)hipEventDestroy(job->built);
+        delete job;
+        return st;
+    }
+    ctx->active_job = job;
+    *out = job;
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t ncols, size_t col_stride,
                                              size_t nv, zigz_commit_job **out) {
     ZIGZ_ENTER(ctx);
@@ -2006,7 +2236,13 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
         const bool dropped = h_cnt[4] != 0;
         ListCaps &c = ctx->caps;
         bool again = false;
-        if (job->tree.lists && c.npad == job->N) {
+        if (job->zstride) {  // a batched job's lists have their worst-case room: nothing to learn, nothing can have run out
+            for (unsigned z = 0; z < job->nz; z++)
+                if (h_cnt[(size_t)z * JOB_SUMMARY_WORDS + 6]) {
+                    set_err(ctx, "batched commit job: a list ran out of its worst-case room (proof %u)", z);
+                    return ZIGZ_ERR_BAD_STATE;
+                }
+        } else if (job->tree.lists && c.npad == job->N) {
             for (unsigned l = 0; l <= job->tree.top; l++) {
                 const unsigned long long ru = h_cnt[8 + l], gu = h_cnt[8 + RUN_MAX_LEVELS + l];
                 if (job->run_cols && (r_over ? ru > c.r[l] : ru * 10 > (unsigned long long)c.r[l] * 8))
@@ -2030,6 +2266,35 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
         CHK(job_build(job));
     }
     memcpy(roots, ctx->h_roots, job->ncols * 32);
+    if (job->zstride) {  // a batched job: the sums over its proofs
+        const uint64_t nz = job->nz;
+        uint64_t r_hashed = 0, g_hashed = 0, g_kept = 0, g_distinct = 0, constant = 0, dense_g = 0;
+        for (unsigned z = 0; z < job->nz; z++) {
+            const unsigned long long *h = h_cnt + (size_t)z * JOB_SUMMARY_WORDS;
+            r_hashed += job->run_cols ? h[0] : 0;
+            constant += job->run_cols ? h[7] : 0;
+            if (job->cons_hinted) {
+                g_distinct += h[5];
+                if (!h[4]) { g_kept++; g_hashed += h[3]; }
+                else dense_g += job->cons_hinted * job->cons_levels_nodes;  // dropped: its columns were hashed densely
+            }
+        }
+        ctx->stats.run_aware_columns = job->run_cols;
+        ctx->stats.run_aware_dense_nodes = job->run_dense * nz;
+        ctx->stats.run_aware_hashed = r_hashed;
+        ctx->stats.small_domain_columns = 0;
+        ctx->stats.small_domain_fallback_waves = 0;
+        ctx->stats.cons_columns = g_kept ? job->cons_hinted : 0;
+        ctx->stats.cons_dense_nodes = job->cons_hinted * job->cons_levels_nodes * g_kept;
+        ctx->stats.cons_hashed = g_hashed;
+        ctx->stats.cons_probe_distinct = g_distinct;
+        ctx->stats.list_hash_perms = r_hashed + g_hashed + dense_g;
+        ctx->stats.keccak_permutations = job->perms0 * nz - (job->run_dense * nz - r_hashed) - (ctx->stats.cons_dense_nodes - g_hashed);
+        job->const_cols = constant;
+        ctx->stats.eval_constant_columns = constant;
+        job->state = 1;
+        return ZIGZ_OK;
+    }
     // the run-aware levels hashed h_cnt[0] of their run_dense nodes
     const uint64_t N = job->N;
     ctx->stats.run_aware_columns = job->run_cols;
@@ -2099,17 +2364,33 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         // columns the run-aware structure pass of THIS job found constant are not read again (EvalSkip, kernels.hpp): of the 43
         // witness columns of a program that uses a handful of registers, most
         EvalSkip skip;
-        if (job->tree.lists && job->run_cols && job->col_stride >= job->N && !job->no_eval_skip) {
-            skip.changed = ctx->d_run_count + RUN_CHANGED;  // (the job's own counters: no other build on the context adds to them)
-            ctx->stats.eval_constant_columns = job->const_cols;  // (what dev_eval_radix sizes its launch by: this job's count)
+        if (job->zstride) {  // a batched job in arenas: column c = column c % ncols1 of proof c / ncols1 (kernels.hpp: EvalSkip)
+            skip.ncols1 = (unsigned)job->ncols1;
+            skip.z_in = job->zstride / 4;
+            skip.z_changed = job->zstride / 8;
             memcpy(skip.y_of_col, job->tree.y_of_col, sizeof(skip.y_of_col));
+            if (job->run_cols && !job->no_eval_skip) {
+                skip.changed = (const unsigned long long *)((const uint8_t *)ctx->ws[WS_BATCH] + job->off_r_ctr) + RUN_CHANGED;
+                ctx->stats.eval_constant_columns = job->const_cols;
+            } else {
+                ctx->stats.eval_constant_columns = 0;
+            }
+            CHK(timed_begin(ctx, 4));
+            CHK(dev_eval_radix(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val, &skip));
+            CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
+        } else {
+            if (job->tree.lists && job->run_cols && job->col_stride >= job->N && !job->no_eval_skip) {
+                skip.changed = ctx->d_run_count + RUN_CHANGED;  // (the job's own counters: no other build on the context adds to them)
+                ctx->stats.eval_constant_columns = job->const_cols;  // (what dev_eval_radix sizes its launch by: this job's count)
+                memcpy(skip.y_of_col, job->tree.y_of_col, sizeof(skip.y_of_col));
+            }
+            CHK(timed_begin(ctx, 4));
+            CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val, skip.changed ? &skip : nullptr));
+            CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
         }
-        CHK(timed_begin(ctx, 4));
-        CHK(dev_eval_folds(ctx, job->d_cols, job->col_stride, ncols, nv, points, z_val, skip.changed ? &skip : nullptr));
-        CHK(timed_end(ctx, 4, &ctx->stats.eval_us));
         const DoneFlag done = done_flag(ctx, 1);
-        launch_paths(job->tree, job->tree.npad, (unsigned)nv, job->d_cols, job->col_stride, h_idx, z_sib, z_dirs, z_leaf, ncols,
-                     ctx->stream, done);
+        launch_paths(job->tree, job->tree.npad, (unsigned)nv, job->d_cols, job->col_stride, h_idx, z_sib, z_dirs, z_leaf,
+                     job->zstride ? job->ncols1 : ncols, ctx->stream, done);
         HIPCHK(ctx, hipGetLastError());
         if (!(g_sleep_wait.load() && !ctx->timing && sleep_wait(done.flag, done.seq)))
             HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -2122,6 +2403,10 @@ extern "C" zigz_status zigz_commit_open_all(zigz_commit_job *job, const uint64_t
         CHK(bind_pool_collect(ctx));
         job->state = 2;
         return ZIGZ_OK;
+    }
+    if (job->zstride) {
+        set_err(ctx, "batched commit job: the openings do not fit the staging buffer");
+        return ZIGZ_ERR_INVALID_ARGUMENT;
     }
     void *dv;
     CHK(ws_get(ctx, WS_SCRATCH, ncols * 4 + 64, &dv));

@@ -174,8 +174,16 @@ extern "C" int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint
 // ---------------------------------------------------------------- GPU slots of a proving service (zigz_host.hpp: GpuSlots)
 struct zigzh_slots {
     GpuSlots slots;
+    std::unique_ptr<GpuBatcher> batcher;  // small traces share commit jobs (zigzh_slots_set_batching)
     zigzh_slots(int device, size_t k) : slots(device, k) {}
 };
+extern "C" int zigzh_slots_set_batching(zigzh_slots *s, unsigned max_batch, double linger_us, size_t max_nv) {
+    return guard([&] {
+        if (!s || max_batch > 32) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "zigzh_slots_set_batching: bad argument");
+        if (max_batch <= 1) s->batcher.reset();
+        else s->batcher.reset(new GpuBatcher(&s->slots, max_batch, linger_us * 1e-6, max_nv < 18 ? max_nv : 18));
+    });
+}
 extern "C" int zigzh_slots_create(int device, size_t k, zigzh_slots **out) {
     return guard([&] { *out = new zigzh_slots(device, k); });
 }
@@ -193,7 +201,7 @@ extern "C" int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, con
     return guard([&] {
         if (!t || !s || !proof_out || !proof_len) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "null argument");
         if (t->trace.stepCount() == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
-        Prover prover(&s->slots, 0);
+        Prover prover(&s->slots, 0, s->batcher.get());
         const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
         if (d_cols) prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
         else prover.proveStepsToBytes(t->io, t->num_lookups, t->trace.steps.data(), t->trace.initial_regs, t->num_vars, ir, g_proof);

@@ -191,7 +191,7 @@ void Prover::generateLassoProofs(Proof &proof, size_t num_lookups) {  // :292-36
     (void)proof;
 }
 
-void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) {  // :366-467
+void Prover::generateCommitments(Proof &proof, const CommitSteps &gpu, size_t nv) {  // :366-467
     const size_t NC = ZIGZ_NUM_COLUMNS;
     const int world = shard_.world > 1 ? shard_.world : 1;
     size_t c0 = 0, c1 = NC;
@@ -212,10 +212,10 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
     std::vector<uint8_t> roots(NC * 32);
     double t0 = now_s();
     if (world == 1) {
-        check(ctx_, zigz_commit_roots(job, roots.data()));             // PHASE 1 results
+        gpu.roots(roots.data());                                       // PHASE 1 results
     } else {
         std::vector<uint8_t> mine(nmax * 32, 0);
-        check(ctx_, zigz_commit_roots(job, mine.data()));
+        gpu.roots(mine.data());
         exchange(mine, 32, roots);                                     // exchange 1: 43 x 32 B
     }
     timings[3] = now_s() - t0;
@@ -232,8 +232,8 @@ void Prover::generateCommitments(Proof &proof, zigz_commit_job *job, size_t nv) 
     std::vector<uint8_t> sib(NC * nv * 32 + 1), dirs(NC * nv + 1);
     timings[4] = now_s() - t0;
     t0 = now_s();
-    check(ctx_, zigz_commit_open_all(job, points.data() + c0 * nv, values.data() + c0, indices.data() + c0, leaves.data() + c0,
-                                     sib.data() + c0 * nv * 32, dirs.data() + c0 * nv));  // :427-431
+    gpu.open_all(points.data() + c0 * nv, values.data() + c0, indices.data() + c0, leaves.data() + c0, sib.data() + c0 * nv * 32,
+                 dirs.data() + c0 * nv);                                                     // :427-431
     if (world > 1) {                                                   // exchange 2: value, index, leaf, path per column
         const size_t rec = 24 + 33 * nv;
         std::vector<uint8_t> mine(nmax * rec, 0), all;
@@ -329,6 +329,190 @@ void GpuSlots::release(zigz_ctx *ctx) {
     cv_.notify_all();
 }
 
+// ---------------------------------------------------------------- GpuBatcher
+struct GpuBatcher::Group {
+    size_t nv = 0, stride = 0;
+    uint64_t m_small = 0, m_run = 0, m_cons = 0;
+    std::vector<const uint32_t *> cols;
+    int phase = 0;  // 0 collecting, 1 building, 2 roots there, 3 opening, 4 done, -1 failed
+    double deadline = 0;
+    std::condition_variable cv;
+    zigz_ctx *ctx = nullptr;
+    zigz_commit_job *job = nullptr;
+    GpuSlots::Lease lease;
+    int64_t sd0 = 0, ra0 = 0, cg0 = 0;  // the slot context's own hint masks, put back when the group is done
+    std::vector<uint8_t> roots, sib, dirs;
+    std::vector<F> points, values, indices, leaves;
+    unsigned handed_in = 0;
+    std::vector<uint8_t> present;  // members still taking part (abandon clears)
+    std::exception_ptr err;
+    zigz_kernel_stats stats{};
+};
+
+// begin + roots for a closed group (any member's thread; the lock is NOT held)
+void GpuBatcher::build(const std::shared_ptr<Group> &g) {
+    try {
+        g->lease.slots = slots_;
+        g->lease.ctx = g->ctx = slots_->acquire();
+        zigz_ctx *c = g->ctx;
+        (void)zigz_ctx_get_option(c, "small_domain_mask", &g->sd0);
+        (void)zigz_ctx_get_option(c, "run_aware_mask", &g->ra0);
+        (void)zigz_ctx_get_option(c, "cons_group_mask", &g->cg0);
+        check(c, zigz_ctx_set_option(c, "small_domain_mask", (int64_t)g->m_small));
+        check(c, zigz_ctx_set_option(c, "run_aware_mask", (int64_t)g->m_run));
+        check(c, zigz_ctx_set_option(c, "cons_group_mask", (int64_t)g->m_cons));
+        const size_t k = g->cols.size();
+        g->roots.resize(k * ZIGZ_NUM_COLUMNS * 32);
+        check(c, zigz_commit_begin_batch(c, g->cols.data(), k, ZIGZ_NUM_COLUMNS, g->stride, g->nv, &g->job));
+        check(c, zigz_commit_roots(g->job, g->roots.data()));
+        g->points.assign(k * ZIGZ_NUM_COLUMNS * g->nv + 1, 0);
+    } catch (...) {
+        g->err = std::current_exception();
+    }
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        g->phase = g->err ? -1 : 2;
+        if (g->err) finish(g);
+    }
+    g->cv.notify_all();
+}
+// gives the job, the masks and the slot back (lock held or not: touches only the group)
+void GpuBatcher::finish(const std::shared_ptr<Group> &g) {
+    if (g->job) zigz_commit_end(g->job);
+    g->job = nullptr;
+    if (g->ctx) {
+        (void)zigz_ctx_set_option(g->ctx, "small_domain_mask", g->sd0);
+        (void)zigz_ctx_set_option(g->ctx, "run_aware_mask", g->ra0);
+        (void)zigz_ctx_set_option(g->ctx, "cons_group_mask", g->cg0);
+    }
+    g->ctx = nullptr;
+    g->lease.drop();
+}
+
+// open_all + end for a group whose members have all handed in their points (or given up); the lock is NOT held
+void GpuBatcher::run_open_all(const std::shared_ptr<Group> &g) {
+    const size_t nc = ZIGZ_NUM_COLUMNS, nv = g->nv, k = g->cols.size();
+    try {
+        g->values.resize(k * nc);
+        g->indices.resize(k * nc);
+        g->leaves.resize(k * nc);
+        g->sib.resize(k * nc * nv * 32 + 1);
+        g->dirs.resize(k * nc * nv + 1);
+        check(g->ctx, zigz_commit_open_all(g->job, g->points.data(), g->values.data(), g->indices.data(), g->leaves.data(),
+                                           g->sib.data(), g->dirs.data()));
+        (void)zigz_ctx_get_stats(g->ctx, &g->stats);
+    } catch (...) {
+        g->err = std::current_exception();
+    }
+    finish(g);
+    {
+        std::lock_guard<std::mutex> lk(m_);
+        g->phase = g->err ? -1 : 4;
+    }
+    g->cv.notify_all();
+}
+
+std::shared_ptr<GpuBatcher::Group> GpuBatcher::join(const uint32_t *d_cols, size_t stride, size_t nv, uint64_t m_small, uint64_t m_run,
+                                                     uint64_t m_cons, unsigned *idx, uint8_t *roots43) {
+    const std::array<uint64_t, 5> key{(uint64_t)nv, (uint64_t)stride, m_small, m_run, m_cons};
+    std::shared_ptr<Group> g;
+    bool run_build = false;
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        auto it = open_.find(key);
+        if (it == open_.end()) {
+            g = std::make_shared<Group>();
+            g->nv = nv;
+            g->stride = stride;
+            g->m_small = m_small;
+            g->m_run = m_run;
+            g->m_cons = m_cons;
+            g->deadline = now_s() + linger_s_;
+            open_[key] = g;
+        } else {
+            g = it->second;
+        }
+        *idx = (unsigned)g->cols.size();
+        g->cols.push_back(d_cols);
+        g->present.push_back(1);
+        if (g->cols.size() >= max_batch_) {  // full: this member closes it
+            open_.erase(key);
+            g->phase = 1;
+            run_build = true;
+        } else {
+            while (g->phase == 0) {
+                const double left = g->deadline - now_s();
+                if (left <= 0) {  // nobody else came in time: whoever notices first closes it
+                    auto it2 = open_.find(key);
+                    if (it2 != open_.end() && it2->second == g) open_.erase(it2);
+                    g->phase = 1;
+                    run_build = true;
+                    break;
+                }
+                g->cv.wait_for(lk, std::chrono::duration<double>(left));
+            }
+        }
+    }
+    if (run_build) build(g);
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        g->cv.wait(lk, [&] { return g->phase >= 2 || g->phase < 0; });
+        if (g->phase < 0) std::rethrow_exception(g->err);
+    }
+    memcpy(roots43, g->roots.data() + (size_t)*idx * ZIGZ_NUM_COLUMNS * 32, ZIGZ_NUM_COLUMNS * 32);
+    return g;
+}
+
+void GpuBatcher::open(const std::shared_ptr<Group> &g, unsigned idx, const F *points, F *values, F *indices, F *leaves,
+                      uint8_t *sib, uint8_t *dirs, zigz_kernel_stats *stats) {
+    const size_t nc = ZIGZ_NUM_COLUMNS, nv = g->nv, k = g->cols.size();
+    bool run_open = false;
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (g->phase < 0) std::rethrow_exception(g->err);
+        memcpy(g->points.data() + (size_t)idx * nc * nv, points, nc * nv * sizeof(F));
+        if (++g->handed_in == k) {
+            g->phase = 3;
+            run_open = true;
+        }
+    }
+    if (run_open) run_open_all(g);
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        g->cv.wait(lk, [&] { return g->phase == 4 || g->phase < 0; });
+        if (g->phase < 0) std::rethrow_exception(g->err);
+    }
+    memcpy(values, g->values.data() + (size_t)idx * nc, nc * sizeof(F));
+    memcpy(indices, g->indices.data() + (size_t)idx * nc, nc * sizeof(F));
+    memcpy(leaves, g->leaves.data() + (size_t)idx * nc, nc * sizeof(F));
+    if (nv) {
+        memcpy(sib, g->sib.data() + (size_t)idx * nc * nv * 32, nc * nv * 32);
+        memcpy(dirs, g->dirs.data() + (size_t)idx * nc * nv, nc * nv);
+    }
+    if (stats) {  // the group's statistics, this proof's share of the counts
+        *stats = g->stats;
+        stats->keccak_permutations /= k;
+        stats->list_hash_perms /= k;
+        stats->run_aware_hashed /= k;
+        stats->cons_hashed /= k;
+    }
+}
+
+void GpuBatcher::abandon(const std::shared_ptr<Group> &g, unsigned idx) {
+    // the member's points stay zero (valid field elements): the group completes, the abandoned results are nobody's
+    bool run_open = false;
+    {
+        std::unique_lock<std::mutex> lk(m_);
+        if (idx >= g->present.size() || !g->present[idx] || g->phase < 2 || g->phase >= 3) return;
+        g->present[idx] = 0;
+        if (++g->handed_in == g->cols.size()) {
+            g->phase = 3;
+            run_open = true;
+        }
+    }
+    if (run_open) run_open_all(g);  // (the last one: the members that did hand in their points are waiting for their openings)
+}
+
 Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                                size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
                                std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps, const uint64_t *regs_before) {
@@ -376,16 +560,26 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
     // [6/6 phase 1] Merkle builds do not depend on the transcript (prover.zig:405-416).  A prover with a context of its own
     // starts them first, asynchronously on the GPU, so that they run underneath its sequential host absorption of steps 4 and
     // 5; a prover of a service takes a GPU slot only after step 5 and starts them then (GpuSlots, zigz_host.hpp).
+    // the hint masks of this proof's columns (the comments at begin_job say what they are)
+    uint64_t m_small = 0, m_run = 0, m_cons = 0;
+    {
+        const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42), sel = (1ull << (c1 - c0)) - 1;
+        if (small_domain_tables) m_small = (structural >> c0) & sel;
+        if (run_aware) {
+            const uint64_t small = small_domain_tables ? structural : 0;
+            const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
+            const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware >= 3 ? regs | mem : regs;
+            if (run_aware == 4) m_cons = ((1ull | (1ull << 1) | (0x7full << 33) | (1ull << 42)) >> c0) & sel;
+            m_run = (hinted >> c0) & sel;
+        }
+    }
     auto begin_job = [&]() {
         double t0 = now_s();
         mask_restore.arm(ctx_);
         // Columns that hold values < 128 by construction (x0; opcode, rd, rs1, rs2, funct3, funct7; mem.is_read --
         // witness.zig:164-169,239, registers.zig:38-48): their leaf and level-1 digests come from constant tables
         // (zigz_hip.h, option "small_domain_mask"; checked on the device, identical trees for any input).
-        if (small_domain_tables) {
-            const uint64_t structural = (1ull << 1) | (0x3full << 33) | (1ull << 42);
-            check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)((structural >> c0) & ((1ull << (c1 - c0)) - 1))));
-        }
+        if (small_domain_tables) check(ctx_, zigz_ctx_set_option(ctx_, "small_domain_mask", (int64_t)m_small));
         // The register columns x1..x31 are piecewise constant by construction: a step writes at most one register
         // (VMState.writeReg, src/vm/state.zig), so together they change at most once per step.  Their large Merkle levels are
         // built run-aware (zigz_hip.h, option "run_aware_mask": a node that repeats its left neighbour is copied, decided from
@@ -396,14 +590,8 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         // rs2, funct3, funct7, imm, is_read -- as a content-addressed group (zigz_hip.h, option "cons_group_mask": wherever the
         // program loops the same nodes recur in all ten; probed first, dropped for a trace that does not repeat).
         if (run_aware) {
-            const uint64_t small = small_domain_tables ? (1ull << 1) | (0x3full << 33) | (1ull << 42) : 0;
-            const uint64_t regs = 0x7fffffffull << 2, mem = 3ull << 40;
-            const uint64_t hinted = run_aware == 2 ? ((1ull << ZIGZ_NUM_COLUMNS) - 1) & ~small : run_aware >= 3 ? regs | mem : regs;
-            if (run_aware == 4) {
-                const uint64_t group = 1ull | (1ull << 1) | (0x7full << 33) | (1ull << 42);
-                check(ctx_, zigz_ctx_set_option(ctx_, "cons_group_mask", (int64_t)((group >> c0) & ((1ull << (c1 - c0)) - 1))));
-            }
-            check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)((hinted >> c0) & ((1ull << (c1 - c0)) - 1))));
+            if (run_aware == 4) check(ctx_, zigz_ctx_set_option(ctx_, "cons_group_mask", (int64_t)m_cons));
+            check(ctx_, zigz_ctx_set_option(ctx_, "run_aware_mask", (int64_t)m_run));
         }
         if (steps) {  // the witness from the compact trace, inside the slot: upload + expansion + builds on one stream
             const uint32_t *wc = nullptr;
@@ -442,23 +630,55 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         t0 = now_s();
         generateLassoProofs(proof, num_lookups);            // [5/6]
         timings[2] = now_s() - t0;
-        if (slots_) {
-            t0 = now_s();
-            lease.slots = slots_;
-            lease.ctx = ctx_ = slots_->acquire();
-            t_slot = now_s();
-            timings[8] = t_slot - t0;
-            begin_job();
+        // small traces of a service: this proof's GPU steps as a member of a batch (GpuBatcher) -- resident columns, the whole
+        // witness, a size at which a proof's launches are mostly latency
+        const bool batched = slots_ && batcher_ && d_cols && !witness && !steps && shard_.world <= 1 && num_vars <= batcher_->maxNv() &&
+                             (num_vars < 15 || (((m_run | m_cons) & ((1ull << ZIGZ_NUM_COLUMNS) - 1)) == (1ull << ZIGZ_NUM_COLUMNS) - 1));
+        CommitSteps gpu;
+        std::shared_ptr<GpuBatcher::Group> grp;
+        unsigned gidx = 0;
+        if (batched) {
+            gpu.roots = [&](uint8_t *roots43) {
+                const double tb = now_s();
+                grp = batcher_->join(d_cols, d_col_stride, num_vars, m_small, m_run, m_cons, &gidx, roots43);
+                timings[8] = now_s() - tb;
+            };
+            gpu.open_all = [&](const F *pts, F *values, F *indices, F *leaves, uint8_t *sib, uint8_t *dirs) {
+                batcher_->open(grp, gidx, pts, values, indices, leaves, sib, dirs, &last_stats);
+            };
+        } else {
+            if (slots_) {
+                t0 = now_s();
+                lease.slots = slots_;
+                lease.ctx = ctx_ = slots_->acquire();
+                t_slot = now_s();
+                timings[8] = t_slot - t0;
+                begin_job();
+            }
+            gpu.roots = [&](uint8_t *roots43) { check(ctx_, zigz_commit_roots(guard.job, roots43)); };
+            gpu.open_all = [&](const F *pts, F *values, F *indices, F *leaves, uint8_t *sib, uint8_t *dirs) {
+                check(ctx_, zigz_commit_open_all(guard.job, pts, values, indices, leaves, sib, dirs));
+            };
         }
-        generateCommitments(proof, guard.job, num_vars);    // [6/6]
+        try {
+            generateCommitments(proof, gpu, num_vars);      // [6/6]
+        } catch (...) {
+            if (grp) batcher_->abandon(grp, gidx);  // (the other members of the batch must not wait for this proof's points)
+            throw;
+        }
+        if (batched) {
+            last_log.clear();
+            timings[9] = timings[3] + timings[4] + timings[5];
+            ctx_ = nullptr;
+        }
     } catch (...) {
         if (writing) try { t_helper.wait(); } catch (...) {}  // (the helper reads `proof`: it must be done before the unwind)
         if (slots_) ctx_ = nullptr;  // (the guards release the job, the masks and the slot, in that order)
         throw;
     }
-    zigz_commit_end(guard.job);
+    if (guard.job) zigz_commit_end(guard.job);
     guard.job = nullptr;
-    if (slots_) {  // what the caller may want to know about the context this proof ran on, before somebody else has it
+    if (slots_ && lease.ctx) {  // what the caller may want to know about the context this proof ran on, before somebody else has it
         (void)zigz_ctx_get_stats(ctx_, &last_stats);
         size_t n = 0;
         last_log.resize(80);

@@ -10,6 +10,10 @@
 #include <array>
 #include <condition_variable>
 #include <cstdint>
+#include <exception>
+#include <functional>
+#include <map>
+#include <memory>
 #include <mutex>
 #include <optional>
 #include <stdexcept>
@@ -314,11 +318,46 @@ class GpuSlots {
     uint64_t next_ticket_ = 0, serving_ = 0;
 };
 
+// Small traces: proofs that arrive at their GPU phase within a short while of each other share ONE commit job
+// (zigz_commit_begin_batch: one structure pass, one hash launch per level, one eval, one path launch for all of them) --
+// at 2^16 and below a proof's ~35 launches are mostly latency, and a service's small proofs arrive in bursts anyway (the
+// lanes of one sponge server leave their transcripts together).  A group forms per (size, hints); it closes when it is full
+// or `linger` after its first member arrived; whoever closes it takes a GPU slot and runs begin + roots for all; each
+// member then absorbs ITS roots and draws ITS challenges on its own thread (the transcripts stay per proof: the bytes of a
+// proof do not depend on whom it shared a launch with), and the last member to hand in its points runs open_all + end for
+// all.  Results are per proof exactly what a job of its own gives (tests/test_gpu_parity.py: batch == single jobs).
+class GpuBatcher {
+  public:
+    struct Group;
+    GpuBatcher(GpuSlots *slots, unsigned max_batch, double linger_s, size_t max_nv)
+        : slots_(slots), max_batch_(max_batch), linger_s_(linger_s), max_nv_(max_nv) {}
+    size_t maxNv() const { return max_nv_; }
+    // joins (or opens) a group; returns when the group's roots are there: *idx = this proof's position, roots43 = its 43 roots
+    std::shared_ptr<Group> join(const uint32_t *d_cols, size_t stride, size_t nv, uint64_t m_small, uint64_t m_run, uint64_t m_cons,
+                                unsigned *idx, uint8_t *roots43);
+    // hands in this proof's 43 * nv points; returns with its openings when the group's open_all has run
+    void open(const std::shared_ptr<Group> &g, unsigned idx, const F *points, F *values, F *indices, F *leaves, uint8_t *sib,
+              uint8_t *dirs, zigz_kernel_stats *stats);
+    // a member that cannot go on (its transcript work threw) must still let the others finish
+    void abandon(const std::shared_ptr<Group> &g, unsigned idx);
+
+  private:
+    void build(const std::shared_ptr<Group> &g);      // (called without the lock held)
+    void finish(const std::shared_ptr<Group> &g);
+    void run_open_all(const std::shared_ptr<Group> &g);
+    GpuSlots *slots_;
+    unsigned max_batch_;
+    double linger_s_;
+    size_t max_nv_;
+    std::mutex m_;
+    std::map<std::array<uint64_t, 5>, std::shared_ptr<Group>> open_;
+};
+
 class Prover {  // src/prover/prover.zig
   public:
     Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
     // a prover of a service: the context is taken from `slots` for the GPU phases of each proof only (see GpuSlots)
-    Prover(GpuSlots *slots, uint64_t seed) : ctx_(nullptr), seed_(seed), slots_(slots) {}
+    Prover(GpuSlots *slots, uint64_t seed, GpuBatcher *batcher = nullptr) : ctx_(nullptr), seed_(seed), slots_(slots), batcher_(batcher) {}
     void setShard(const ShardSpec &s) { shard_ = s; }
     // prove(program, entry_pc, initial_regs, max_steps, segments, input), :73-226
     // serialized (optional): also BinarySerializer.serialize, with the early sections written underneath the transcript
@@ -364,13 +403,20 @@ class Prover {  // src/prover/prover.zig
     void bindPublicInputs(const Hash &program_hash, uint64_t entry_pc, const std::vector<uint64_t> *initial_regs);  // :91-110
     void generateSumcheckProof(Proof &proof, size_t num_steps, size_t num_vars);                                     // :229-289
     void generateLassoProofs(Proof &proof, size_t num_lookups);                                                      // :292-363
-    void generateCommitments(Proof &proof, zigz_commit_job *job, size_t num_vars);                                   // :366-467
+    // the two GPU steps of generateCommitments: the 43 roots of this proof; its openings at the 43 points.  Bound to a commit
+    // job of this proof's own, or to its place in a batch (GpuBatcher)
+    struct CommitSteps {
+        std::function<void(uint8_t *roots43)> roots;
+        std::function<void(const F *points, F *values, F *indices, F *leaves, uint8_t *sib, uint8_t *dirs)> open_all;
+    };
+    void generateCommitments(Proof &proof, const CommitSteps &gpu, size_t num_vars);                                 // :366-467
     Proof proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                            size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
                            std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps = nullptr, const uint64_t *regs_before = nullptr);
     zigz_ctx *ctx_;
     uint64_t seed_;
     GpuSlots *slots_ = nullptr;
+    GpuBatcher *batcher_ = nullptr;
     FiatShamirTranscript transcript_;
     ShardSpec shard_;
 };

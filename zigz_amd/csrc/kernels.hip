@@ -268,9 +268,21 @@ constexpr int RLOOPS = 4;  // RB-chunks per thread: accumulators stay in registe
 // and the RB loads of a chunk are issued back to back.  Otherwise rows past nb are clamped to a valid row and given
 // weight 0 (per-row branches would make the compiler serialise the loads behind s_waitcnt vmcnt(0)).
 __device__ __forceinline__ bool eval_skips(const EvalSkip &skip, size_t col) {
-    if (!skip.changed || col >= 64) return false;
+    if (!skip.changed) return false;
+    size_t z = 0;
+    if (skip.ncols1) {  // a batched job: column col % ncols1 of proof col / ncols1
+        z = col / skip.ncols1;
+        col -= z * skip.ncols1;
+    }
+    if (col >= 64) return false;
     const int y = skip.y_of_col[col];
-    return y >= 0 && skip.changed[y] == 0;
+    return y >= 0 && skip.changed[z * skip.z_changed + y] == 0;
+}
+// first element of column `col` of the committed table (batched jobs: kernels.hpp EvalSkip)
+__device__ __forceinline__ size_t eval_col_off(const EvalSkip &skip, size_t col, size_t stride) {
+    if (!skip.ncols1) return col * stride;
+    const size_t z = col / skip.ncols1;
+    return z * skip.z_in + (col - z * skip.ncols1) * stride;
 }
 template <bool FULL>
 __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__ in, size_t in_stride, size_t m, size_t nb,
@@ -281,7 +293,7 @@ __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__
     if (q * 4 >= m) return;
     const size_t col = blockIdx.z;
     if (eval_skips(skip, col)) return;  // a constant column: k_weighted_dot writes its value, its partial sums are never used
-    const uint4 *p = reinterpret_cast<const uint4 *>(in + col * in_stride) + q;
+    const uint4 *p = reinterpret_cast<const uint4 *>(in + eval_col_off(skip, col, in_stride)) + q;
     const uint32_t *w = w_m + col * w_stride;
     const size_t mq = m / 4;
     unsigned long long lo[4] = {0, 0, 0, 0}, hi[4] = {0, 0, 0, 0};
@@ -441,7 +453,7 @@ __global__ __launch_bounds__(TPB) void k_weighted_dot(const uint32_t *__restrict
     __shared__ unsigned long long red[TPB / 64];
     const size_t col = blockIdx.x;
     if (cols && eval_skips(skip, col)) {  // (workgroup-uniform) the extension of a constant column is the constant
-        if (threadIdx.x == 0) out[col] = cols[col * col_stride];
+        if (threadIdx.x == 0) out[col] = cols[eval_col_off(skip, col, col_stride)];
         return;
     }
     unsigned long long acc = 0;
@@ -935,9 +947,12 @@ __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsign
                                               size_t val_stride, const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
                                               uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, DoneFlag done) {
     const size_t col = blockIdx.x;
-    const size_t index = idx[col];
+    const size_t fc = (size_t)blockIdx.y * gridDim.x + col;  // a batched job: proof blockIdx.y; results are numbered proof by proof
+    tree_at(t, blockIdx.y);
+    if (t.zstride) vals += (size_t)blockIdx.y * (t.zstride / 4);
+    const size_t index = idx[fc];
     const unsigned l = threadIdx.x;
-    if (l == 0) leaf[col] = vals[col * val_stride + index];
+    if (l == 0) leaf[fc] = vals[col * val_stride + index];
     if (l < height) {
         const size_t ci = index >> l;  // current_index at level l, merkle_tree.zig:335-352
         const size_t node = ci ^ 1;    // the sibling: a copy / non-representative resolves to where its digest is stored (node_ptr)
@@ -947,19 +962,19 @@ __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsign
         if (virt_leaf) d = sha3_leaf<false>(node < n_values ? (uint64_t)vals[col * val_stride + node] : 0);
         else d = load_digest_at(node_ptr(t, col, l, node));
         d = canonical_digest(d);  // tree form -> SHA3 bytes at the boundary
-        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (col * height + l) * 32);
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(sib + (fc * height + l) * 32);
         q[0] = make_ulonglong2(d.w[0], d.w[1]);
         q[1] = make_ulonglong2(d.w[2], d.w[3]);
-        dirs[col * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
+        dirs[fc * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
     }
-    signal_done(done, gridDim.x);
+    signal_done(done, gridDim.x * gridDim.y);
 }
 
 void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
                   const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s,
                   DoneFlag done) {
-    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx, d_sib, d_dirs,
-                       d_leaf, done);
+    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols, t.nz ? t.nz : 1), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx,
+                       d_sib, d_dirs, d_leaf, done);
 }
 TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad) {
     TreeRef t{};
@@ -987,13 +1002,21 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
 __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ out, size_t ncols, const unsigned long long *r_ctr,
                               const unsigned long long *sd_ctr, const unsigned long long *g_ctr, DoneFlag done) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    // a batched job (proof blockIdx.y of gridDim.y): the roots of all proofs one after the other, then every proof's counters
+    const unsigned z = blockIdx.y, nz = gridDim.y;
+    tree_at(t, z);
+    if (t.zstride && z) {
+        zmove(r_ctr, (size_t)z * t.zstride);
+        zmove(sd_ctr, (size_t)z * t.zstride);
+        zmove(g_ctr, (size_t)z * t.zstride);
+    }
     if (c < ncols) {
         const Digest d = canonical_digest(load_digest_at(node_ptr(t, c, height, 0)));  // tree form -> SHA3 bytes
-        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + c * 32);
+        ulonglong2 *q = reinterpret_cast<ulonglong2 *>(out + ((size_t)z * ncols + c) * 32);
         q[0] = make_ulonglong2(d.w[0], d.w[1]);
         q[1] = make_ulonglong2(d.w[2], d.w[3]);
     }
-    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(out + ncols * 32);
+    unsigned long long *cnt = reinterpret_cast<unsigned long long *>(out + (size_t)nz * ncols * 32) + (size_t)z * JOB_SUMMARY_WORDS;
     if (c == 0) {
         cnt[0] = r_ctr ? r_ctr[0] : 0;
         cnt[1] = sd_ctr ? sd_ctr[0] : 0;
@@ -1018,23 +1041,54 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
             }
         cnt[8 + threadIdx.x] = mx;
     }
-    signal_done(done, gridDim.x);
+    signal_done(done, gridDim.x * gridDim.y);
 }
-__global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g) {
+__global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g, size_t zstride) {
     const unsigned i = blockIdx.x * TPB + threadIdx.x;
+    if (zstride && blockIdx.y) {
+        zmove(sd, (size_t)blockIdx.y * zstride);
+        zmove(r, (size_t)blockIdx.y * zstride);
+        zmove(g, (size_t)blockIdx.y * zstride);
+    }
     if (i < RUN_CTR_WORDS) {
         if (r) r[i] = 0;
         if (g) g[i] = 0;
     }
     if (sd && i < 2) sd[i] = 0;
 }
-void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s) {
-    hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTR_WORDS + TPB - 1) / TPB), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr);
+void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s,
+                          unsigned nz, size_t zstride) {
+    hipLaunchKernelGGL(k_zero_counters, dim3((RUN_CTR_WORDS + TPB - 1) / TPB, nz ? nz : 1), dim3(TPB), 0, s, d_sd_ctr, d_r_ctr, d_g_ctr,
+                       nz > 1 ? zstride : (size_t)0);
+}
+// the columns of the proofs of a batched job into their arenas / their common table (VEC: 16-byte copies)
+template <bool VEC>
+__global__ __launch_bounds__(TPB) void k_gather_cols(ColSrcs srcs, size_t n, size_t src_stride, uint32_t *__restrict__ dst, size_t dst_stride,
+                                                     size_t zstride) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    const uint32_t *sp = srcs.p[blockIdx.z] + (size_t)blockIdx.y * src_stride;
+    uint32_t *dp = reinterpret_cast<uint32_t *>(reinterpret_cast<uint8_t *>(dst) + (size_t)blockIdx.z * zstride) + (size_t)blockIdx.y * dst_stride;
+    if (VEC) {
+        if (i < n / 4) reinterpret_cast<uint4 *>(dp)[i] = reinterpret_cast<const uint4 *>(sp)[i];
+    } else if (i < n) {
+        dp[i] = sp[i];
+    }
+}
+void launch_gather_cols(const ColSrcs &srcs, unsigned nz, size_t ncols, size_t n, size_t src_stride, uint32_t *d_dst,
+                        size_t dst_stride, size_t zstride, hipStream_t s) {
+    bool vec = n % 4 == 0 && src_stride % 4 == 0 && dst_stride % 4 == 0 && zstride % 16 == 0 && aligned16(d_dst);
+    for (unsigned z = 0; z < nz; z++) vec = vec && aligned16(srcs.p[z]);
+    if (vec)
+        hipLaunchKernelGGL(k_gather_cols<true>, dim3((unsigned)((n / 4 + TPB - 1) / TPB), (unsigned)ncols, nz), dim3(TPB), 0, s, srcs, n,
+                           src_stride, d_dst, dst_stride, zstride);
+    else
+        hipLaunchKernelGGL(k_gather_cols<false>, dim3((unsigned)((n + TPB - 1) / TPB), (unsigned)ncols, nz), dim3(TPB), 0, s, srcs, n,
+                           src_stride, d_dst, dst_stride, zstride);
 }
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s, DoneFlag done) {
-    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64)), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr, d_sd_ctr,
-                       d_g_ctr, done);
+    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64), t.nz ? t.nz : 1), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr,
+                       d_sd_ctr, d_g_ctr, done);
 }
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,
                          hipStream_t s) {

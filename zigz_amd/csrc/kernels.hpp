@@ -89,9 +89,14 @@ size_t radix_fold_groups(size_t nb, int rloops = 0);  // rloops: 16-row chunks p
 // values by the run-aware structure pass of the same commit job), and the multilinear extension of a constant is that
 // constant -- the eq weights of a point sum to 1 -- so its 4 N bytes are not read: k_radix_fold returns at once for it and
 // k_weighted_dot writes the column's first value.  changed == nullptr: nothing is skipped.
+// A batched commit job (several proofs' columns in one job, MerkleBuild below: zstride) numbers its columns proof by proof:
+// column c is column c % ncols1 of proof c / ncols1, whose data starts z_in elements / whose `changed` words z_changed words
+// behind the previous proof's.  ncols1 == 0: one proof, plain column stride.
 struct EvalSkip {
     const unsigned long long *changed = nullptr;
     signed char y_of_col[64];
+    unsigned ncols1 = 0;
+    size_t z_in = 0, z_changed = 0;
 };
 void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t nb, const uint32_t *d_w_m,
                        size_t w_stride, unsigned long long *d_part, size_t part_col_stride, size_t ncols, hipStream_t s,
@@ -206,6 +211,12 @@ struct TreeRef {
     unsigned long long g_sd_mask;         // columns of the group whose leaf digests are virtual when the group was dropped
     unsigned long long virtual_leaves;    // bit c: the leaf digests of column c were not written (small-domain columns of a
                                           // commit job): an opening hashes the sibling value itself
+    // A BATCHED job -- nz > 1 proofs of the same shape built by the same launches (gridDim.z / .y = proof), for traces so small
+    // that one proof's launches are mostly latency: everything a proof's build reads or writes lives in ONE arena of zstride
+    // bytes with the same layout for every proof, so that EVERY device pointer of this struct (and of MerkleBuild) moves by
+    // proof * zstride; the pointers stored here are proof 0's (tree_dev.hpp: tree_at / build_at).  nz == 0: one proof.
+    size_t zstride;
+    unsigned nz;
 };
 // first entry of level l in TreeRef::bitmap / ::prev / ::woff (one entry per 64 nodes, levels stored one after the other)
 __host__ __device__ inline size_t run_meta_base(size_t npad, unsigned ncols, unsigned l) {
@@ -305,7 +316,15 @@ void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t
 constexpr unsigned JOB_SUMMARY_WORDS = 8 + 2 * RUN_MAX_LEVELS;
 // the counters a build's kernels add to (2 words of small-domain fall-backs, RUN_CTR_WORDS words each of the R and G lists; null =
 // not used by this build), zeroed by one launch
-void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s);
+void launch_zero_counters(unsigned long long *d_sd_ctr, unsigned long long *d_r_ctr, unsigned long long *d_g_ctr, hipStream_t s,
+                          unsigned nz = 0, size_t zstride = 0);
+// the columns of the nz proofs of a batched job, gathered into their arenas: proof z's ncols columns of n elements (column
+// stride src_stride) -> d_dst + z * zstride bytes, column stride dst_stride (n % 4 == 0, everything 16-byte aligned)
+struct ColSrcs {
+    const uint32_t *p[32];
+};
+void launch_gather_cols(const ColSrcs &srcs, unsigned nz, size_t ncols, size_t n, size_t src_stride, uint32_t *d_dst,
+                        size_t dst_stride, size_t zstride, hipStream_t s);
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s,
                         DoneFlag done = DoneFlag());

@@ -142,6 +142,7 @@ constexpr int RUNS_WAVES = TPB / 64;
 template <bool STAGE0>
 __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax, unsigned nseg,
                                                     size_t in_off /*bytes, stage >= 1*/, size_t out_off /*bytes, next stage or ~0*/) {
+    build_at(b, blockIdx.z);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned y = blockIdx.y, segi = blockIdx.x * RUNS_WAVES + wave;
     if (segi >= nseg) return;  // (wave-uniform; the waves of a workgroup never meet)
@@ -293,7 +294,7 @@ void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
         const size_t in_off = st ? stage_off(b.npad, b.rcols.n, st) : 0;
         const size_t out_off = has_next ? stage_off(b.npad, b.rcols.n, st + 1) : ~(size_t)0;
         const unsigned nseg = (unsigned)(n_in / seg);
-        const dim3 grid((nseg + RUNS_WAVES - 1) / RUNS_WAVES, b.rcols.n);
+        const dim3 grid((nseg + RUNS_WAVES - 1) / RUNS_WAVES, b.rcols.n, b.t.nz ? b.t.nz : 1);
         hipEvent_t e0 = kt && st == 0 ? kt->start : nullptr, e1 = kt && st + 1 == nstages ? kt->stop : nullptr;
         if (st == 0) {
             if (e0 || e1) hipExtLaunchKernelGGL(k_runs_stage<true>, grid, dim3(TPB), 0, s, e0, e1, 0, b, st, log2u(seg), rmax, nseg, in_off, out_off);
@@ -433,6 +434,7 @@ __device__ __forceinline__ void cons_insert_level(const MerkleBuild &b, unsigned
 
 __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
     __shared__ unsigned long long s_set[CONS_SET];
+    build_at(b, blockIdx.z);
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
     __syncthreads();
     const size_t k = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
@@ -448,6 +450,7 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
 template <bool LEAF>
 __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
     __shared__ unsigned long long s_set[CONS_SET];
+    build_at(b, blockIdx.z);
     if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
     __syncthreads();
@@ -505,6 +508,7 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
 
 // keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing
 __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
+    build_at(b, blockIdx.z);
     unsigned long long c = threadIdx.x < RUN_SUBS ? b.g_ctr[run_ctr_index(0, threadIdx.x)] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -519,13 +523,14 @@ __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
 void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt) {
     if (b.gcols.n == 0) return;
     const unsigned top = b.t.g_lists.top;
-    const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB));
+    const unsigned nz = b.t.nz ? b.t.nz : 1;
+    const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB), 1, nz);
     if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b);
     else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b);
     hipLaunchKernelGGL(k_cons_pass<true>, g0, dim3(CONS_TPB), 0, s, b, 0u, top >= 1 ? 1 : 0);
-    hipLaunchKernelGGL(k_cons_decide, dim3(1), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_cons_decide, dim3(1, 1, nz), dim3(64), 0, s, b);
     for (unsigned lr = 1; lr <= top; lr++) {
-        const dim3 g((unsigned)(((b.npad >> lr) + CONS_TPB - 1) / CONS_TPB));
+        const dim3 g((unsigned)(((b.npad >> lr) + CONS_TPB - 1) / CONS_TPB), 1, nz);
         const int ins = lr < top ? 1 : 0;
         if (kt && lr == top) hipExtLaunchKernelGGL(k_cons_pass<false>, g, dim3(CONS_TPB), 0, s, nullptr, kt->stop, 0, b, lr, ins);
         else hipLaunchKernelGGL(k_cons_pass<false>, g, dim3(CONS_TPB), 0, s, b, lr, ins);
@@ -548,6 +553,7 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
     __shared__ unsigned s_pad[ZK_LEVEL_HASH_LDS_PAD / 4];
     if (b.npad == 3) s_pad[threadIdx.x] = L;  // (never true: keeps the array)
 #endif
+    build_at(b, blockIdx.z);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
     if (wave < 2) {
@@ -663,9 +669,13 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
     if (wgs > 2048) wgs = 2048;                                            // there is (8 workgroups per CU stride over it)
     // fewer than two waves per SIMD even if every node were hashed: the re-arm pauses would only add latency
     const bool small = (size_t)(b.rcols.n + b.gcols.n) * n_L <= (size_t)256 * 4 * 2 * 64;
-    if (L == 0) ZK_LAUNCH(kt, (k_level_hash<true, true>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
-    else if (small) ZK_LAUNCH(kt, (k_level_hash<false, false>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
-    else ZK_LAUNCH(kt, (k_level_hash<false, true>), dim3((unsigned)wgs), dim3(TPB), 0, s, b, L, gd);
+    // a batched job: the proofs share the launch (gridDim.z), and with them the chip -- the grid is per proof
+    const unsigned nz = b.t.nz ? b.t.nz : 1;
+    if (nz > 1 && wgs > (2048 + nz - 1) / nz) wgs = (2048 + nz - 1) / nz;
+    const bool pause = !small || (size_t)nz * (b.rcols.n + b.gcols.n) * n_L > (size_t)256 * 4 * 2 * 64;
+    if (L == 0) ZK_LAUNCH(kt, (k_level_hash<true, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
+    else if (!pause) ZK_LAUNCH(kt, (k_level_hash<false, false>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
+    else ZK_LAUNCH(kt, (k_level_hash<false, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
 }
 
 // ------------------------------------------------------------------ the top of the trees
@@ -674,6 +684,7 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
 // re-arm pauses.  The levels it computes go to TreeRef::upper (a build with lists) or into the slabs.
 __global__ __launch_bounds__(TPB) void k_merkle_top(TreeRef t, unsigned first_level, unsigned height) {
     __shared__ Digest s_d[TPB];  // the level just computed: the next one reads its children here, not from global memory
+    tree_at(t, blockIdx.z);
     const size_t col = blockIdx.y;
     for (unsigned l = first_level; l < height; l++) {
         const size_t n_out = t.npad >> (l + 1);
@@ -696,7 +707,7 @@ __global__ __launch_bounds__(TPB) void k_merkle_top(TreeRef t, unsigned first_le
     }
 }
 void launch_merkle_top(const TreeRef &t, unsigned first_level, unsigned height, size_t ncols, hipStream_t s, const KTime *kt) {
-    ZK_LAUNCH(kt, k_merkle_top, dim3(1, (unsigned)ncols), dim3(TPB), 0, s, t, first_level, height);
+    ZK_LAUNCH(kt, k_merkle_top, dim3(1, (unsigned)ncols, t.nz ? t.nz : 1), dim3(TPB), 0, s, t, first_level, height);
 }
 
 // ------------------------------------------------------------------ materialising whole trees

@@ -372,10 +372,15 @@ class CommitmentScheme:
 class CommitJob:
     """Prover.generateCommitments split at its transcript dependencies (prover.zig:366-467)."""
 
-    def __init__(self, ctx, cols=None, d_cols=None, ncols=NUM_COLUMNS, nv=None, col_stride=None):
+    def __init__(self, ctx, cols=None, d_cols=None, ncols=NUM_COLUMNS, nv=None, col_stride=None, d_cols_list=None):
         self.ctx = ctx
         j = vp()
-        if cols is not None:
+        if d_cols_list is not None:  # zigz_commit_begin_batch: several proofs' resident columns in one job
+            k = len(d_cols_list)
+            arr = (vp * k)(*[vp(d) for d in d_cols_list])
+            ctx.check(lib.zigz_commit_begin_batch(ctx.h, arr, k, ncols, col_stride or (1 << nv), nv, C.byref(j)))
+            ncols = ncols * k
+        elif cols is not None:
             cols = np.ascontiguousarray(cols, dtype=np.uint64)
             ncols, N = cols.shape
             nv = N.bit_length() - 1

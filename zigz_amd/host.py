@@ -41,6 +41,7 @@ SIGNATURES = {
     "zigzh_prove_trace": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.POINTER(u8p), szp]),
     "zigzh_slots_create": (C.c_int, [C.c_int, C.c_size_t, C.POINTER(vp)]),
     "zigzh_slots_destroy": (None, [vp]),
+    "zigzh_slots_set_batching": (C.c_int, [vp, C.c_uint, C.c_double, C.c_size_t]),
     "zigzh_slots_size": (C.c_size_t, [vp]),
     "zigzh_slots_ctx": (vp, [vp, C.c_size_t]),
     "zigzh_slots_acquire": (vp, [vp]),
@@ -227,6 +228,10 @@ class Slots:
         h = vp()
         _check(lib.zigzh_slots_create(device, k, C.byref(h)))
         self.h, self.k, self.device = h, k, device
+
+    def set_batching(self, max_batch, linger_us=150.0, max_nv=17):
+        """small traces share commit jobs (GpuBatcher): up to max_batch proofs that arrive within linger_us of each other"""
+        _check(lib.zigzh_slots_set_batching(self.h, max_batch, linger_us, max_nv))
 
     def ctx(self, i):
         from .hip import Context
