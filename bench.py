@@ -518,8 +518,12 @@ def main():
     slots = None
     setup_ctx = zigz_amd.Context(local_rank)  # allocations, witness uploads (set-up; its workspaces are given back after it)
 
-    def make_slots(k):
+    def make_slots(k, nv_l):
         sl = host.Slots(local_rank, k)
+        if nv_l <= 17 and os.environ.get("ZIGZ_BENCH_NO_BATCHING") != "1":
+            # small traces: proofs that reach their GPU phase together share one commit job (GpuBatcher): at 2^16 a proof's ~35
+            # launches are 13 us of work each; the lanes of a sponge server leave their transcripts together anyway
+            sl.set_batching(int(os.environ.get("ZIGZ_BENCH_BATCH_MAX", "16")), float(os.environ.get("ZIGZ_BENCH_BATCH_LINGER_US", "200")), 17)
         return sl
 
     def slot_count(nl, nv_l):
@@ -657,7 +661,7 @@ def main():
         else:
             allgather_hook = make_comm("shard", 120.0)
     if use_slots:
-        slots = make_slots(slot_count(B, nv))
+        slots = make_slots(slot_count(B, nv), nv)
     lanes = [Lane(k) for k in range(B)]
     setup_ctx.release_workspaces()
     pool = ThreadPoolExecutor(max_workers=B)
@@ -1111,7 +1115,7 @@ def main():
             def leg_size(nv_s=nv_s, steps_s=steps_s, nl=nl, ls=ls, k_s=k_s):
                 nonlocal slots
                 if use_slots:
-                    slots = make_slots(k_s)
+                    slots = make_slots(k_s, nv_s)
                 ls.extend(Lane(k, nv_s, pin=False) for k in range(nl))
                 setup_ctx.release_workspaces()
                 run_step(which=ls)

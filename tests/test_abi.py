@@ -126,7 +126,21 @@ def test_zig_binding_is_in_step_with_the_header():
             continue
         assert ('pub extern "c" fn %s(' % n) in committed, n
     for t in ("Ctx", "Merkle", "CommitJob", "Transcript", "ShmComm", "TraceStep", "RadixOps", "KernelStats", "BenchResult",
-              "AllgatherFn"):
+              "AllgatherFn", "LaunchRec"):
         assert ("pub const %s = " % t) in committed, t
     # the value structs have the C layout sizes the header's consumers rely on
-    assert committed.count("extern struct") == 4
+    assert committed.count("extern struct") == 5
+    # ... and the layout the ZIG side gives them is the C compiler's (VERDICT r3 #8a: what can be checked without a Zig compiler):
+    # offsetof / sizeof _Static_asserts generated from the Zig field lists, compiled against the header
+    layout = os.path.join(ROOT, "bindings", "zig", "zigz_hip_layout_check.c")
+    assert gen_zig_binding.layout_check(committed) == open(layout).read(), "regenerate: python tools/gen_zig_binding.py --write"
+    assert open(layout).read().count("_Static_assert(offsetof") >= 60
+    import subprocess
+    subprocess.check_call(["gcc", "-std=c11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), layout])
+    # (a deliberately wrong Zig-side type must fail that compile: the check checks something)
+    broken = committed.replace("    opcode: u8,", "    opcode: u32,", 1)
+    assert broken != committed
+    bad = gen_zig_binding.layout_check(broken)
+    r = subprocess.run(["gcc", "-std=c11", "-fsyntax-only", "-I", os.path.join(ROOT, "include"), "-x", "c", "-"], input=bad.encode(),
+                       capture_output=True)
+    assert r.returncode != 0 and b"Zig-side" in r.stderr

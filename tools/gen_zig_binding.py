@@ -193,12 +193,56 @@ def generate():
     return "\n".join(out) + "\n"
 
 
+LAYOUT_OUT = os.path.join(ROOT, "bindings", "zig", "zigz_hip_layout_check.c")
+ZIG_SIZES = {"u8": 1, "i8": 1, "u16": 2, "i16": 2, "u32": 4, "i32": 4, "c_int": 4, "c_uint": 4, "u64": 8, "i64": 8, "f64": 8, "f32": 4,
+             "usize": 8, "isize": 8, "Status": 4}
+
+
+def layout_check(zig_text=None):
+    """No Zig compiler here, so what CAN be checked without one: the layout of every `extern struct` of the generated binding.
+    Parsed from the ZIG side (field names and Zig types of bindings/zig/zigz_hip.zig), laid out by the C ABI rules an
+    `extern struct` follows on x86-64 (natural alignment, size rounded up to the largest member's), and written as C
+    _Static_asserts on offsetof / sizeof of the header's own struct: tests/test_c_driver.py compiles the file against
+    include/zigz_hip.h.  A field the generator mistyped (a u32 where the header has a size_t), dropped or reordered fails
+    the compile."""
+    zig_text = zig_text if zig_text is not None else generate()
+    out = ["/* GENERATED by tools/gen_zig_binding.py from the ZIG-side field lists of bindings/zig/zigz_hip.zig -- do not edit.",
+           " * The layout Zig gives every `extern struct` of the binding (C ABI, x86-64) must be the layout the C compiler gives the",
+           " * header's struct of the same name. */", "#include <stddef.h>", '#include "zigz_hip.h"', ""]
+    names = {}
+    for cname in re.findall(r"typedef struct (\w+) \{", strip_comments(open(HEADER).read())):
+        names[zig_name(cname)] = cname
+    for m in re.finditer(r"pub const (\w+) = extern struct \{(.*?)\n\};", zig_text, flags=re.S):
+        zname, body = m.group(1), m.group(2)
+        cname = names[zname]
+        off, maxal = 0, 1
+        for fm in re.finditer(r"^\s*(@\"\w+\"|\w+): (.*),$", body, flags=re.M):
+            fname, ztype = fm.group(1).strip('@"'), fm.group(2).strip()
+            if ztype in ZIG_SIZES:
+                size = ZIG_SIZES[ztype]
+            elif ztype.startswith(("?*", "[*c]", "*")):
+                size = 8  # pointers, optional pointers, function pointers
+            else:
+                raise ValueError("layout_check: no size for Zig type %r (%s.%s)" % (ztype, zname, fname))
+            al = size
+            off = (off + al - 1) // al * al
+            out.append("_Static_assert(offsetof(%s, %s) == %d, \"%s.%s: Zig-side offset %d\");" % (cname, fname, off, zname, fname, off))
+            off += size
+            maxal = max(maxal, al)
+        total = (off + maxal - 1) // maxal * maxal
+        out.append("_Static_assert(sizeof(%s) == %d, \"%s: Zig-side size %d\");" % (cname, total, zname, total))
+        out.append("")
+    return "\n".join(out)
+
+
 def main():
     txt = generate()
     if "--write" in sys.argv:
         os.makedirs(os.path.dirname(OUT), exist_ok=True)
         open(OUT, "w").write(txt)
         print("wrote", OUT, "(%d lines)" % txt.count("\n"))
+        open(LAYOUT_OUT, "w").write(layout_check(txt))
+        print("wrote", LAYOUT_OUT)
     else:
         sys.stdout.write(txt)
 

@@ -90,7 +90,7 @@ struct zigz_ctx {
     uint64_t build_cons_hinted, build_cons_levels_nodes, build_cons_sd, build_top_perms;
     ListCaps caps;  // room for the lists of the structure-aware levels, learnt from earlier builds (caps_for)
     size_t batch_tab_S, batch_tab_off;  // the content-addressing tables of the batched jobs' arenas (WS_BATCH) as last cleared
-    unsigned batch_tab_nz;
+    unsigned batch_tab_nz, batch_gen;
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
@@ -2048,17 +2048,14 @@ static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *c
     uint8_t *a0 = (uint8_t *)w;
     // the content-addressing tables (generation-tagged slots): cleared when the workspace or the layout is new, or the
     // generations run out -- all nz of them with one strided fill
+    // (generations of their own -- batch_gen --: the single jobs' table in WS_CONS starts its count over whenever IT is new)
     if (G.n && (w != w_before || ctx->batch_tab_S != S || ctx->batch_tab_nz < nz || ctx->batch_tab_off != o_keys ||
-                ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096)) {
+                ctx->batch_gen == 0 || ctx->batch_gen + RUN_MAX_LEVELS + 1 >= 4096)) {
         HIPCHK(ctx, hipMemset2DAsync(a0 + o_keys, S, 0, key_bytes, nz, ctx->stream));
         ctx->batch_tab_S = S;
         ctx->batch_tab_nz = nz;
         ctx->batch_tab_off = o_keys;
-        if (ctx->cons_gen + RUN_MAX_LEVELS + 1 >= 4096) {  // (the single-job table of WS_CONS shares the counter: it starts over too)
-            ctx->cons_gen = 1;
-            ctx->cons_table = nullptr;
-        }
-        if (ctx->cons_gen == 0) ctx->cons_gen = 1;
+        ctx->batch_gen = 1;
     }
     t.zstride = S;
     t.nz = nz;
@@ -2091,8 +2088,8 @@ static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *c
         b.g_rep = (uint32_t *)(a0 + o_grep);
         b.g_ctr = (unsigned long long *)(a0 + o_gctr);
         b.g_has_slabs = 1;
-        b.g_gen = ctx->cons_gen;
-        ctx->cons_gen += t.top + 1;
+        b.g_gen = ctx->batch_gen;
+        ctx->batch_gen += t.top + 1;
     }
     b.t = t;
     ColSrcs cs{};
