@@ -2057,8 +2057,6 @@ static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *c
         ctx->batch_tab_off = o_keys;
         ctx->batch_gen = 1;
     }
-    t.zstride = S;
-    t.nz = nz;
     t.upper = a0 + o_upper;
     MerkleBuild b{};
     b.vals = (const uint32_t *)(a0 + o_cols);
@@ -2092,6 +2090,8 @@ static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *c
         ctx->batch_gen += t.top + 1;
     }
     b.t = t;
+    set_zstride(b, S, nz);
+    t = b.t;
     ColSrcs cs{};
     for (unsigned z = 0; z < nz; z++) cs.p[z] = srcs[z];
     launch_gather_cols(cs, nz, nc, N, src_stride, (uint32_t *)(a0 + o_cols), stride, S, ctx->stream);

@@ -947,9 +947,8 @@ __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsign
                                               size_t val_stride, const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
                                               uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, DoneFlag done) {
     const size_t col = blockIdx.x;
-    const size_t fc = (size_t)blockIdx.y * gridDim.x + col;  // a batched job: proof blockIdx.y; results are numbered proof by proof
-    tree_at(t, blockIdx.y);
-    if (t.zstride) vals += (size_t)blockIdx.y * (t.zstride / 4);
+    const size_t fc = (size_t)blockIdx.z * gridDim.x + col;  // a batched job: proof blockIdx.z; results are numbered proof by proof
+    if (t.zstride) vals += (size_t)blockIdx.z * (t.zstride / 4);
     const size_t index = idx[fc];
     const unsigned l = threadIdx.x;
     if (l == 0) leaf[fc] = vals[col * val_stride + index];
@@ -967,13 +966,13 @@ __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsign
         q[1] = make_ulonglong2(d.w[2], d.w[3]);
         dirs[fc * height + l] = (uint8_t)(ci & 1);  // directions[l] = is_right
     }
-    signal_done(done, gridDim.x * gridDim.y);
+    signal_done(done, gridDim.x * gridDim.z);
 }
 
 void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
                   const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s,
                   DoneFlag done) {
-    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols, t.nz ? t.nz : 1), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx,
+    hipLaunchKernelGGL(k_paths, dim3((unsigned)ncols, 1, t.nz ? t.nz : 1), dim3(64), 0, s, t, n_values, height, d_vals, val_stride, d_idx,
                        d_sib, d_dirs, d_leaf, done);
 }
 TreeRef slab_tree_ref(uint8_t *d_tree, size_t npad) {
@@ -1003,12 +1002,12 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
                               const unsigned long long *sd_ctr, const unsigned long long *g_ctr, DoneFlag done) {
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // a batched job (proof blockIdx.y of gridDim.y): the roots of all proofs one after the other, then every proof's counters
-    const unsigned z = blockIdx.y, nz = gridDim.y;
-    tree_at(t, z);
-    if (t.zstride && z) {
-        zmove(r_ctr, (size_t)z * t.zstride);
-        zmove(sd_ctr, (size_t)z * t.zstride);
-        zmove(g_ctr, (size_t)z * t.zstride);
+    const unsigned z = blockIdx.z, nz = gridDim.z;
+    if (t.zstride && z) {  // (plain pointers: this proof's counters sit z arenas further on)
+        const size_t o = (size_t)z * t.zstride;
+        if (r_ctr) r_ctr = reinterpret_cast<const unsigned long long *>(reinterpret_cast<uintptr_t>(r_ctr) + o);
+        if (sd_ctr) sd_ctr = reinterpret_cast<const unsigned long long *>(reinterpret_cast<uintptr_t>(sd_ctr) + o);
+        if (g_ctr) g_ctr = reinterpret_cast<const unsigned long long *>(reinterpret_cast<uintptr_t>(g_ctr) + o);
     }
     if (c < ncols) {
         const Digest d = canonical_digest(load_digest_at(node_ptr(t, c, height, 0)));  // tree form -> SHA3 bytes
@@ -1041,14 +1040,15 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
             }
         cnt[8 + threadIdx.x] = mx;
     }
-    signal_done(done, gridDim.x * gridDim.y);
+    signal_done(done, gridDim.x * gridDim.z);
 }
 __global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g, size_t zstride) {
     const unsigned i = blockIdx.x * TPB + threadIdx.x;
     if (zstride && blockIdx.y) {
-        zmove(sd, (size_t)blockIdx.y * zstride);
-        zmove(r, (size_t)blockIdx.y * zstride);
-        zmove(g, (size_t)blockIdx.y * zstride);
+        const size_t o = (size_t)blockIdx.y * zstride / 8;
+        if (sd) sd += o;
+        if (r) r += o;
+        if (g) g += o;
     }
     if (i < RUN_CTR_WORDS) {
         if (r) r[i] = 0;
@@ -1087,7 +1087,7 @@ void launch_gather_cols(const ColSrcs &srcs, unsigned nz, size_t ncols, size_t n
 }
 void launch_job_summary(const TreeRef &t, unsigned height, uint8_t *d_out, size_t ncols, const unsigned long long *d_r_ctr,
                         const unsigned long long *d_sd_ctr, const unsigned long long *d_g_ctr, hipStream_t s, DoneFlag done) {
-    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64), t.nz ? t.nz : 1), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr,
+    hipLaunchKernelGGL(k_job_summary, dim3((unsigned)((ncols + 63) / 64), 1, t.nz ? t.nz : 1), dim3(64), 0, s, t, height, d_out, ncols, d_r_ctr,
                        d_sd_ctr, d_g_ctr, done);
 }
 void launch_gather_nodes(const uint8_t *d_tree, size_t tree_stride_nodes, size_t node, uint8_t *d_out, size_t ncols,

@@ -176,6 +176,29 @@ struct LevelLists {
     unsigned cap[RUN_MAX_LEVELS];
     unsigned long long entries;                 // total
 };
+// A device pointer of a build that may be BATCHED (TreeRef::nz proofs built by the same launches, gridDim.z = proof): every
+// proof's data lives in an arena of the same layout, zs bytes after the previous proof's, and p is proof 0's.  On the device
+// the pointer reads as proof blockIdx.z's -- a scalar multiply-add where it is used; the structs that hold these stay
+// untouched kernel arguments (a kernel that ADJUSTED its by-value MerkleBuild made the compiler copy all 1.3 KB of it to
+// scratch memory: every k_level_hash launch four times slower).  On the host it is the plain pointer p.  zs == 0: one proof.
+template <class T>
+struct ZPtr {
+    T *p;
+    size_t zs;
+    __host__ __device__ ZPtr &operator=(T *q) {
+        p = q;
+        return *this;
+    }
+    __host__ __device__ operator T *() const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        // (a null pointer of a batched build does not stay null: nothing on the device tests these for null, they are
+        // dereferenced only where the build has the data they point to)
+        return reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + (size_t)blockIdx.z * zs);
+#else
+        return p;
+#endif
+    }
+};
 // Where the digest of (column, level, node) of a build lives (tree_dev.hpp: node_ptr).  Three kinds of storage:
 //   slab    node-addressed, 2 npad nodes per column (level l at node offset 2 npad - 2 (npad >> l)): the columns that are
 //           built densely -- and every column of a build that materialises whole trees (single trees, whole-tree tests);
@@ -186,35 +209,36 @@ struct LevelLists {
 //   upper   the levels above the list levels (255 nodes per column) of all columns of a build with lists.
 struct TreeRef {
     size_t npad;
-    uint8_t *slab;
+    ZPtr<uint8_t> slab;
     signed char slab_of_col[64];  // column -> index of its slab, -1 = none (columns >= 64: their own index)
     int lists;                    // != 0: levels 0..top of the R / G columns are list-built
     unsigned top;
-    uint8_t *upper;               // [column][512 nodes]: level l > top at node offset 512 - 2 (256 >> (l - top))
+    ZPtr<uint8_t> upper;          // [column][512 nodes]: level l > top at node offset 512 - 2 (256 >> (l - top))
     // R (run-aware)
-    unsigned long long *bitmap;   // per level l at word run_meta_base(l): [hinted column y][node / 64], bit = hashed
-    unsigned short *prev;         // same indexing: local index (in the tile) of the last hashed node before the chunk
-    unsigned short *woff;         // same indexing: list offset (within its unit) of the chunk's first hashed node
-    uint32_t *ubase;              // per level l at ubase_off[l]: [unit = y * (n_l / tile_l) + node / tile_l]: the list slot (within
+    ZPtr<unsigned long long> bitmap;  // per level l at word run_meta_base(l): [hinted column y][node / 64], bit = hashed
+    ZPtr<unsigned short> prev;    // same indexing: local index (in the tile) of the last hashed node before the chunk
+    ZPtr<unsigned short> woff;    // same indexing: list offset (within its unit) of the chunk's first hashed node
+    ZPtr<uint32_t> ubase;         // per level l at ubase_off[l]: [unit = y * (n_l / tile_l) + node / tile_l]: the list slot (within
     unsigned long long ubase_off[RUN_MAX_LEVELS];  // the level: sub-list * capacity + position) of the unit's first hashed node
     unsigned ncols;               // hinted (R) columns
     signed char y_of_col[64];     // column -> hinted index, -1 = not hinted
-    uint8_t *r_store;             // digest of list slot i of level l: r_store + (r_lists.base[l] + i) * 32
+    ZPtr<uint8_t> r_store;        // digest of list slot i of level l: r_store + (r_lists.base[l] + i) * 32
     LevelLists r_lists;
     // G (content-addressed group)
     signed char g_j_of_col[64];   // column -> index in the group, -1 = not a member
     unsigned g_ncols;
-    const uint32_t *g_rep;        // per level (tree_level_offset order): the list slot of the node's representative
-    uint8_t *g_store;             // digest of (list slot i, group column j) of level l: g_store + ((g_lists.base[l] + i) * g_ncols + j) * 32
+    ZPtr<const uint32_t> g_rep;   // per level (tree_level_offset order): the list slot of the node's representative
+    ZPtr<uint8_t> g_store;        // digest of (list slot i, group column j) of level l: g_store + ((g_lists.base[l] + i) * g_ncols + j) * 32
     LevelLists g_lists;
-    const unsigned long long *g_dropped;  // device word: != 0 -> the group did not repeat; its columns live in slabs
+    ZPtr<const unsigned long long> g_dropped;  // device word: != 0 -> the group did not repeat; its columns live in slabs
     unsigned long long g_sd_mask;         // columns of the group whose leaf digests are virtual when the group was dropped
     unsigned long long virtual_leaves;    // bit c: the leaf digests of column c were not written (small-domain columns of a
                                           // commit job): an opening hashes the sibling value itself
     // A BATCHED job -- nz > 1 proofs of the same shape built by the same launches (gridDim.z / .y = proof), for traces so small
     // that one proof's launches are mostly latency: everything a proof's build reads or writes lives in ONE arena of zstride
     // bytes with the same layout for every proof, so that EVERY device pointer of this struct (and of MerkleBuild) moves by
-    // proof * zstride; the pointers stored here are proof 0's (tree_dev.hpp: tree_at / build_at).  nz == 0: one proof.
+    // proof * zstride; the pointers stored here are proof 0's and carry the stride themselves (ZPtr; set_zstride below).
+    // nz == 0: one proof.
     size_t zstride;
     unsigned nz;
 };
@@ -234,26 +258,34 @@ size_t runs_units(size_t npad, size_t ncols, unsigned long long ubase_off[RUN_MA
 size_t runs_stage_scratch_bytes(size_t npad, size_t ncols);
 
 struct MerkleBuild {   // everything the structure-aware launches share (device pointers)
-    const uint32_t *vals;
+    ZPtr<const uint32_t> vals;
     size_t val_stride, n_values, npad;
     TreeRef t;                    // where digests go (and how copies / non-representatives resolve)
     // R
     ColMap rcols;
-    uint32_t *r_list;
-    unsigned long long *r_ctr;    // RUN_CTR_WORDS words, zeroed before the build; word 10: != 0 -> a list ran out of room
-    uint8_t *r_stage;             // runs_stage_scratch_bytes()
+    ZPtr<uint32_t> r_list;
+    ZPtr<unsigned long long> r_ctr;  // RUN_CTR_WORDS words, zeroed before the build; word 10: != 0 -> a list ran out of room
+    ZPtr<uint8_t> r_stage;        // runs_stage_scratch_bytes()
     // G
     ColMap gcols;                 // the group, ascending
     ColMap gcols_sd;              // its small-domain members (levels 0-1 from the tables when the group is dropped)
     int g_has_slabs;              // the group's columns have slabs to be built into when the group is dropped
-    unsigned long long *g_keys;   // 2 npad slots: generation << 52 | payload
-    uint32_t *g_idx;              // 2 npad: the list slot of the node that inserted the slot's key
-    uint32_t *g_rep;              // 2 npad: list slot of the representative of every node of the levels 0..top
-    uint32_t *g_list;             // list slot -> node
-    unsigned long long *g_ctr;    // RUN_CTRS words, zeroed before the build; word 10: bit 0 a list ran out of room, bit 1 the
+    ZPtr<unsigned long long> g_keys;  // 2 npad slots: generation << 52 | payload
+    ZPtr<uint32_t> g_idx;         // 2 npad: the list slot of the node that inserted the slot's key
+    ZPtr<uint32_t> g_rep;         // 2 npad: list slot of the representative of every node of the levels 0..top
+    ZPtr<uint32_t> g_list;        // list slot -> node
+    ZPtr<unsigned long long> g_ctr;  // RUN_CTRS words, zeroed before the build; word 10: bit 0 a list ran out of room, bit 1 the
                                   // group was dropped but its columns have no slabs
     unsigned g_gen;               // generation of level 0 (level l uses g_gen + l); < 4096 - RUN_MAX_LEVELS
 };
+// a batched build: the arena stride into every pointer of the build (after they have been set)
+inline void set_zstride(MerkleBuild &b, size_t zs, unsigned nz) {
+    TreeRef &t = b.t;
+    t.zstride = zs;
+    t.nz = nz;
+    t.slab.zs = t.upper.zs = t.bitmap.zs = t.prev.zs = t.woff.zs = t.ubase.zs = t.r_store.zs = t.g_rep.zs = t.g_store.zs = t.g_dropped.zs = zs;
+    b.vals.zs = b.r_list.zs = b.r_ctr.zs = b.r_stage.zs = b.g_keys.zs = b.g_idx.zs = b.g_rep.zs = b.g_list.zs = b.g_ctr.zs = zs;
+}
 // R: all lists, bitmaps and leader tables of the levels 0..top (two or three launches, no hashing)
 void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt = nullptr);
 // G: the table passes of the levels 0..top and the keep / drop decision (top + 3 launches, no hashing)

@@ -142,7 +142,6 @@ constexpr int RUNS_WAVES = TPB / 64;
 template <bool STAGE0>
 __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax, unsigned nseg,
                                                     size_t in_off /*bytes, stage >= 1*/, size_t out_off /*bytes, next stage or ~0*/) {
-    build_at(b, blockIdx.z);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned y = blockIdx.y, segi = blockIdx.x * RUNS_WAVES + wave;
     if (segi >= nseg) return;  // (wave-uniform; the waves of a workgroup never meet)
@@ -434,7 +433,6 @@ __device__ __forceinline__ void cons_insert_level(const MerkleBuild &b, unsigned
 
 __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
     __shared__ unsigned long long s_set[CONS_SET];
-    build_at(b, blockIdx.z);
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
     __syncthreads();
     const size_t k = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
@@ -450,7 +448,6 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
 template <bool LEAF>
 __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
     __shared__ unsigned long long s_set[CONS_SET];
-    build_at(b, blockIdx.z);
     if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
     __syncthreads();
@@ -508,7 +505,6 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
 
 // keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing
 __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
-    build_at(b, blockIdx.z);
     unsigned long long c = threadIdx.x < RUN_SUBS ? b.g_ctr[run_ctr_index(0, threadIdx.x)] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -553,7 +549,6 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
     __shared__ unsigned s_pad[ZK_LEVEL_HASH_LDS_PAD / 4];
     if (b.npad == 3) s_pad[threadIdx.x] = L;  // (never true: keeps the array)
 #endif
-    build_at(b, blockIdx.z);
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
     if (wave < 2) {
@@ -684,7 +679,6 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
 // re-arm pauses.  The levels it computes go to TreeRef::upper (a build with lists) or into the slabs.
 __global__ __launch_bounds__(TPB) void k_merkle_top(TreeRef t, unsigned first_level, unsigned height) {
     __shared__ Digest s_d[TPB];  // the level just computed: the next one reads its children here, not from global memory
-    tree_at(t, blockIdx.z);
     const size_t col = blockIdx.y;
     for (unsigned l = first_level; l < height; l++) {
         const size_t n_out = t.npad >> (l + 1);

@@ -46,25 +46,6 @@ __device__ __forceinline__ void store_digest_plain(uint8_t *tree, size_t node, c
     q[0] = d.w[0]; q[1] = d.w[1]; q[2] = d.w[2]; q[3] = d.w[3];
 }
 
-// ---- a batched job: proof z's view of the build (kernels.hpp: TreeRef::zstride).  Wave-uniform scalar adds at kernel entry.
-template <class T>
-__device__ __forceinline__ void zmove(T *&p, size_t off) {
-    if (p) p = reinterpret_cast<T *>(reinterpret_cast<uintptr_t>(p) + off);
-}
-__device__ __forceinline__ void tree_at(TreeRef &t, unsigned z) {
-    if (!t.zstride || !z) return;
-    const size_t o = (size_t)z * t.zstride;
-    zmove(t.slab, o); zmove(t.upper, o); zmove(t.bitmap, o); zmove(t.prev, o); zmove(t.woff, o); zmove(t.ubase, o);
-    zmove(t.r_store, o); zmove(t.g_rep, o); zmove(t.g_store, o); zmove(t.g_dropped, o);
-}
-__device__ __forceinline__ void build_at(MerkleBuild &b, unsigned z) {
-    if (!b.t.zstride || !z) return;
-    const size_t o = (size_t)z * b.t.zstride;
-    tree_at(b.t, z);
-    zmove(b.vals, o); zmove(b.r_list, o); zmove(b.r_ctr, o); zmove(b.r_stage, o);
-    zmove(b.g_keys, o); zmove(b.g_idx, o); zmove(b.g_rep, o); zmove(b.g_list, o); zmove(b.g_ctr, o);
-}
-
 // ---- where a digest lives (kernels.hpp: TreeRef)
 __device__ __host__ __forceinline__ size_t slab_level_offset(size_t npad, unsigned l) { return 2 * npad - 2 * (npad >> l); }
 // What r_slot needs to know about level l of the R columns -- all of it the same for every thread of a launch.  A kernel that
