@@ -707,6 +707,13 @@ def main():
         phases = {}
 
         def lane_loop(l):
+            if use_slots and fn is Lane.prove and not l.want_log:
+                # the lane's `steps` proofs back to back inside the library (zigzh_prove_trace_slots_repeat): ~70 us of
+                # interpreter time per proof x 93 lane threads behind one interpreter lock cap a process at ~14 k proofs/s, which
+                # the small traces exceed (2^16: 1.0 -> 1.3 G steps/s); sums of the statistics and phase timings come back
+                l.proof, st, tm = l.trace.prove_slots_repeat(slots, steps, l.d_cols, l.N)
+                st["_timed"] = 0
+                return [(st, tm)]
             out = []
             for _ in range(steps):
                 out.append(fn(l))

@@ -88,6 +88,12 @@ int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, const uint32_t
                             uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_out, zigz_launch_rec *log_out,
                             size_t log_cap, size_t *log_n);
 
+/* `reps` proofs of the same trace back to back on the calling thread (a lane of a service), without returning to the caller
+ * in between; stats_sum / timings_sum (optional): field-wise sums over the proofs; the proof is the last one's (borrowed). */
+int zigzh_prove_trace_slots_repeat(const zigzh_trace *t, zigzh_slots *s, const uint32_t *d_cols, size_t stride, size_t reps,
+                                   uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_sum, double timings_sum[10]);
+void zigzh_stats_add(zigz_kernel_stats *a, const zigz_kernel_stats *b);
+
 /* One proof over `world` GPUs, sharded by column: every rank calls this with the SAME trace and its own
  * context / resident copy of the 43 columns; rank r builds, commits and opens only its contiguous block of columns
  * (43 over 8 -> 6,6,6,5,5,5,5,5).  The two exchanges of Prover.generateCommitments (prover.zig:366-467) -- 43 roots

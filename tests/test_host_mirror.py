@@ -215,3 +215,17 @@ def test_sponge_service_absorbs_the_same_bytes():
             lib.zigz_host_sponge_servers(0)
         assert lib.zigz_host_sponge_batching() == 0
     assert run(jobs[1]) == want[1]
+
+
+def test_stats_add_covers_every_field():
+    """zigzh_stats_add (what zigzh_prove_trace_slots_repeat sums a lane's proofs with) adds EVERY field of zigz_kernel_stats."""
+    import ctypes as C
+    from zigz_amd import host
+    from zigz_amd._ffi import KernelStats
+    a, b = KernelStats(), KernelStats()
+    for i, (f, t) in enumerate(KernelStats._fields_):
+        setattr(a, f, t(i + 1).value)
+        setattr(b, f, t(100 + i).value)
+    host.lib.zigzh_stats_add(C.byref(a), C.byref(b))
+    for i, (f, _) in enumerate(KernelStats._fields_):
+        assert getattr(a, f) == 101 + 2 * i, f

@@ -217,6 +217,73 @@ extern "C" int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, con
     });
 }
 
+// field by field (tests/test_host_mirror.py checks that no field of zigz_kernel_stats is left out)
+static void stats_add(zigz_kernel_stats &a, const zigz_kernel_stats &b) {
+    a.merkle_build_us += b.merkle_build_us;
+    a.eval_us += b.eval_us;
+    a.path_us += b.path_us;
+    a.bind_us += b.bind_us;
+    a.bind_launches += b.bind_launches;
+    a.keccak_permutations += b.keccak_permutations;
+    a.bind_vec_us += b.bind_vec_us;
+    a.bind_vec_launches += b.bind_vec_launches;
+    a.bind_vec_bytes += b.bind_vec_bytes;
+    a.run_aware_columns += b.run_aware_columns;
+    a.run_aware_dense_nodes += b.run_aware_dense_nodes;
+    a.run_aware_hashed += b.run_aware_hashed;
+    a.run_aware_us += b.run_aware_us;
+    a.cons_columns += b.cons_columns;
+    a.cons_dense_nodes += b.cons_dense_nodes;
+    a.cons_hashed += b.cons_hashed;
+    a.cons_probe_distinct += b.cons_probe_distinct;
+    a.keccak_leaves_us += b.keccak_leaves_us;
+    a.keccak_leaves_perms += b.keccak_leaves_perms;
+    a.keccak_level_wide_us += b.keccak_level_wide_us;
+    a.keccak_level_wide_perms += b.keccak_level_wide_perms;
+    a.keccak_level_small_us += b.keccak_level_small_us;
+    a.keccak_level_small_perms += b.keccak_level_small_perms;
+    a.small_domain_columns += b.small_domain_columns;
+    a.small_domain_us += b.small_domain_us;
+    a.small_domain_fallback_waves += b.small_domain_fallback_waves;
+    a.structure_us += b.structure_us;
+    a.list_hash_us += b.list_hash_us;
+    a.list_hash_perms += b.list_hash_perms;
+    a.top_us += b.top_us;
+    a.top_perms += b.top_perms;
+    a.rebuilds += b.rebuilds;
+    a.eval_constant_columns += b.eval_constant_columns;
+}
+static_assert(sizeof(zigz_kernel_stats) == 33 * 8, "zigz_kernel_stats grew: add the new fields to stats_add");
+extern "C" void zigzh_stats_add(zigz_kernel_stats *a, const zigz_kernel_stats *b) { stats_add(*a, *b); }
+
+// `reps` proofs of the same trace back to back on the calling thread, without returning to the caller in between: a lane of a
+// proving service.  (A Python caller pays ~70 us of interpreter time per proof for the call and its result objects -- with
+// 93 lane threads behind one interpreter lock that caps the process at ~14 k proofs/s, which small traces exceed.)
+// stats_sum / timings_sum: field-wise sums over the proofs; the proof bytes are the last proof's (borrowed).
+extern "C" int zigzh_prove_trace_slots_repeat(const zigzh_trace *t, zigzh_slots *s, const uint32_t *d_cols, size_t stride, size_t reps,
+                                              uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_sum,
+                                              double timings_sum[10]) {
+    return guard([&] {
+        if (!t || !s || !proof_out || !proof_len || reps == 0) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "null argument");
+        if (t->trace.stepCount() == 0) throw Error(ZIGZ_ERR_EMPTY_TRACE, "error.EmptyTrace");
+        const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
+        zigz_kernel_stats sum{};
+        double tsum[10] = {0};
+        for (size_t r = 0; r < reps; r++) {
+            Prover prover(&s->slots, 0, s->batcher.get());
+            if (d_cols) prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
+            else prover.proveStepsToBytes(t->io, t->num_lookups, t->trace.steps.data(), t->trace.initial_regs, t->num_vars, ir, g_proof);
+            stats_add(sum, prover.last_stats);
+            for (int i = 0; i < 10; i++) tsum[i] += prover.timings[i];
+            memcpy(g_timings, prover.timings, sizeof(g_timings));
+        }
+        *proof_out = g_proof.data();
+        *proof_len = g_proof.size();
+        if (stats_sum) *stats_sum = sum;
+        if (timings_sum) memcpy(timings_sum, tsum, sizeof(tsum));
+    });
+}
+
 extern "C" int zigzh_prove(zigz_ctx *ctx, const uint8_t *program, size_t program_len, uint64_t entry_pc,
                            const uint64_t *initial_regs, size_t n_initial_regs, int has_initial_regs, size_t max_steps,
                            const uint64_t *input, size_t n_input, uint8_t **proof_out, size_t *proof_len, size_t *num_steps) {

@@ -47,6 +47,8 @@ SIGNATURES = {
     "zigzh_slots_acquire": (vp, [vp]),
     "zigzh_slots_release": (None, [vp, vp]),
     "zigzh_prove_trace_slots": (C.c_int, [vp, vp, vp, C.c_size_t, C.POINTER(u8p), szp, vp, vp, C.c_size_t, szp]),
+    "zigzh_prove_trace_slots_repeat": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_size_t, C.POINTER(u8p), szp, vp, C.POINTER(C.c_double)]),
+    "zigzh_stats_add": (None, [vp, vp]),
     "zigzh_prove_trace_sharded": (C.c_int, [vp, vp, vp, C.c_size_t, C.c_int, C.c_int, vp, vp, C.POINTER(u8p), szp]),
     "zigzh_vm_run": (C.c_int, [C.c_char_p, C.c_size_t, C.c_uint64, C.c_size_t, u64p, u64p, szp]),
     "zigzh_sumcheck_prove_bytes": (C.c_int, [vp, u64p, C.c_size_t, u8p, szp]),
@@ -198,6 +200,17 @@ class Trace:
         stats = {f: getattr(st, f) for f, _ in KernelStats._fields_}
         recs = [(log[i].cls, log[i].perms, log[i].start_us, log[i].end_us) for i in range(ln.value)] if want_log else None
         return BorrowedProof(out, n.value), stats, recs
+
+    def prove_slots_repeat(self, slots, reps, d_cols=None, stride=0):
+        """zigzh_prove_trace_slots_repeat: `reps` proofs back to back inside the library (a lane of a service) -> (BorrowedProof
+        of the last one, field-wise sum of the proofs' kernel statistics, sum of their phase timings)."""
+        from ._ffi import KernelStats
+        out, n = u8p(), C.c_size_t()
+        st = KernelStats()
+        tm = (C.c_double * 10)()
+        _check(lib.zigzh_prove_trace_slots_repeat(self.h, slots.h, vp(d_cols) if d_cols else None, stride, reps, C.byref(out),
+                                                  C.byref(n), C.byref(st), tm))
+        return BorrowedProof(out, n.value), {f: getattr(st, f) for f, _ in KernelStats._fields_}, dict(zip(TIMING_NAMES, list(tm)))
 
     def prove_sharded(self, ctx, d_cols, stride, dist, allgather=None):
         """ONE proof over dist.get_world_size() GPUs, sharded by column (zigzh_prove_trace_sharded): every rank holds
