@@ -411,6 +411,7 @@ def main():
 
     dist = None
     torch = None
+    gpu_share = 1  # ranks of this launch that share this rank's GPU (a rehearsal of N ranks on a 1-GPU box): HBM budgets are divided by it
     backend = os.environ.get("ZIGZ_BENCH_BACKEND", "nccl")  # "gloo": rehearsal of the N > 1 path on a 1-GPU box
     if world > 1 or os.environ.get("ZIGZ_BENCH_FORCE_DIST") == "1":  # (the env switch: the RCCL code path with one rank)
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -420,6 +421,7 @@ def main():
         if backend == "nccl" and ndev < world:
             backend = "gloo"  # fewer GPUs than ranks (rehearsal on a 1-GPU box): RCCL cannot put two ranks on one device
         local_rank = local_rank % max(ndev, 1)
+        gpu_share = max(1, (world + max(ndev, 1) - 1) // max(ndev, 1))
         if backend == "nccl":
             torch.cuda.set_device(local_rank)
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
@@ -490,7 +492,7 @@ def main():
     hbm_free = None
     if not shard and args.batch <= 0:
         probe = zigz_amd.Context(local_rank)
-        hbm_free = probe.mem_info()[0]
+        hbm_free = probe.mem_info()[0] // gpu_share
         probe.close()
         if use_slots_:
             k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 22 else 8)
@@ -1101,8 +1103,8 @@ def main():
                 pass
             slots = None
         setup_ctx.release_workspaces()
-        free_now = setup_ctx.mem_info()[0]
-        for nv_s, steps_s in ((16, 10), (22, 5), (24, 3)):
+        free_now = setup_ctx.mem_info()[0] // gpu_share
+        for nv_s, steps_s in ((16, 10), (22, 5), (24, 4)):
             if nv_s == nv:
                 continue
             if use_slots:

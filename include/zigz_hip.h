@@ -160,7 +160,8 @@ zigz_status zigz_commit_begin_dev(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
  * zigz_commit_roots / zigz_commit_open_all; every proof's results are the ones its own job would give.  The columns are
  * copied at begin (the callers' buffers are not needed after it returns ... after the stream has passed the copy:
  * zigz_commit_roots).  2^nv < 2^15: the proofs' trees are built densely like any table's; 2^15 <= 2^nv <= 2^18: with the
- * structure-aware levels, every column of a proof must then be hinted ("run_aware_mask" / "cons_group_mask" cover all of
+ * structure-aware levels (option "batch_reserve" = n sizes the context's workspace for n proofs from its first batched job on, so
+ * that a larger batch than any before does not reallocate gigabytes in the middle of a service's work), every column of a proof must then be hinted ("run_aware_mask" / "cons_group_mask" cover all of
  * them, as the witness's 43 are in host/prover.cpp), else ZIGZ_ERR_INVALID_ARGUMENT; larger tables: one job per proof. */
 zigz_status zigz_commit_begin_batch(zigz_ctx *ctx, const uint32_t *const *d_cols, size_t nproofs, size_t ncols,
                                     size_t col_stride, size_t nv, zigz_commit_job **out);

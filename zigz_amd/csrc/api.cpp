@@ -91,6 +91,8 @@ struct zigz_ctx {
     ListCaps caps;  // room for the lists of the structure-aware levels, learnt from earlier builds (caps_for)
     size_t batch_tab_S, batch_tab_off;  // the content-addressing tables of the batched jobs' arenas (WS_BATCH) as last cleared
     unsigned batch_tab_nz, batch_gen;
+    unsigned batch_reserve;  // option: proofs to size the batched jobs' workspaces for (a service's largest batch), so that they
+                             // are allocated once and not again when a larger batch than any before comes along
 };
 static const size_t FLUSH_BYTES = (size_t)1 << 30;
 static const size_t SUMS_SLOTS = 8192;  // [0, 4096): results of the API calls; [4096, 8192): scratch of the measurement hook
@@ -415,6 +417,7 @@ extern "C" zigz_status zigz_ctx_set_option(zigz_ctx *ctx, const char *name, int6
     if (strcmp(name, "cons_always") == 0) { ctx->cons_always = value != 0; return ZIGZ_OK; }
     if (strcmp(name, "debug_skip") == 0) { ctx->debug_skip = (int)value; return ZIGZ_OK; }
     if (strcmp(name, "small_domain_mask") == 0) { ctx->small_domain_mask = (uint64_t)value; return ZIGZ_OK; }
+    if (strcmp(name, "batch_reserve") == 0) { ctx->batch_reserve = value < 0 ? 0 : value > BATCH_MAX ? BATCH_MAX : (unsigned)value; return ZIGZ_OK; }
     return ZIGZ_ERR_INVALID_ARGUMENT;
 }
 extern "C" zigz_status zigz_ctx_get_option(zigz_ctx *ctx, const char *name, int64_t *value) {
@@ -2044,16 +2047,19 @@ static zigz_status job_build_batch_arena(zigz_commit_job *job, const uint32_t *c
     if ((size_t)nz * S > ((size_t)48 << 30)) return ZIGZ_ERR_OUT_OF_MEMORY;
     void *w;
     const void *w_before = ctx->ws[WS_BATCH];
-    CHK(ws_get(ctx, WS_BATCH, (size_t)nz * S, &w));
+    const size_t n_res = nz > ctx->batch_reserve ? nz : ctx->batch_reserve;
+    if ((size_t)n_res * S <= ((size_t)48 << 30)) CHK(ws_get(ctx, WS_BATCH, (size_t)n_res * S, &w));
+    else CHK(ws_get(ctx, WS_BATCH, (size_t)nz * S, &w));
     uint8_t *a0 = (uint8_t *)w;
     // the content-addressing tables (generation-tagged slots): cleared when the workspace or the layout is new, or the
     // generations run out -- all nz of them with one strided fill
     // (generations of their own -- batch_gen --: the single jobs' table in WS_CONS starts its count over whenever IT is new)
     if (G.n && (w != w_before || ctx->batch_tab_S != S || ctx->batch_tab_nz < nz || ctx->batch_tab_off != o_keys ||
                 ctx->batch_gen == 0 || ctx->batch_gen + RUN_MAX_LEVELS + 1 >= 4096)) {
-        HIPCHK(ctx, hipMemset2DAsync(a0 + o_keys, S, 0, key_bytes, nz, ctx->stream));
+        const size_t n_tabs = ctx->ws_bytes[WS_BATCH] / S;  // (every arena the workspace has room for: a later, larger batch finds them clear)
+        HIPCHK(ctx, hipMemset2DAsync(a0 + o_keys, S, 0, key_bytes, n_tabs, ctx->stream));
         ctx->batch_tab_S = S;
-        ctx->batch_tab_nz = nz;
+        ctx->batch_tab_nz = (unsigned)n_tabs;
         ctx->batch_tab_off = o_keys;
         ctx->batch_gen = 1;
     }
@@ -2164,7 +2170,7 @@ extern "C" zigz_status zigz_commit_begin_batch(zigz_ctx *ctx, const uint32_t *co
         // flat: one table of nz * ncols columns, built densely (no hints: they are per 64 columns of ONE proof)
         const size_t dstride = N < 4 ? 4 : N;
         void *d;
-        CHK(ws_get(ctx, WS_COLS, job->ncols * dstride * 4, &d));
+        CHK(ws_get(ctx, WS_COLS, (job->nz > ctx->batch_reserve ? job->nz : ctx->batch_reserve) * ncols * dstride * 4, &d));
         ColSrcs cs{};
         for (size_t z = 0; z < nproofs; z++) cs.p[z] = d_cols[z];
         launch_gather_cols(cs, job->nz, ncols, N, col_stride, (uint32_t *)d, dstride, ncols * dstride * 4, ctx->stream);

@@ -361,6 +361,7 @@ void GpuBatcher::build(const std::shared_ptr<Group> &g) {
         check(c, zigz_ctx_set_option(c, "small_domain_mask", (int64_t)g->m_small));
         check(c, zigz_ctx_set_option(c, "run_aware_mask", (int64_t)g->m_run));
         check(c, zigz_ctx_set_option(c, "cons_group_mask", (int64_t)g->m_cons));
+        (void)zigz_ctx_set_option(c, "batch_reserve", (int64_t)max_batch_);  // (workspaces for a full group from the start)
         const size_t k = g->cols.size();
         g->roots.resize(k * ZIGZ_NUM_COLUMNS * 32);
         check(c, zigz_commit_begin_batch(c, g->cols.data(), k, ZIGZ_NUM_COLUMNS, g->stride, g->nv, &g->job));
