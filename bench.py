@@ -489,6 +489,10 @@ def main():
     def slot_bytes(nv_l, worst=True):  # what a GPU slot's workspaces grow to: lists + digests in list order (0.45 GiB at 2^20 on the
         # bench trace, measured), slabs for a dropped group and longer lists on a trace that never loops (2.2 GiB)
         return int((2.4 if worst else 0.47) * (1 << 30) * (1 << max(nv_l - 20, 0)))
+    if use_slots_ and args.batch <= 0 and args.nv <= 17:
+        # small traces: a proof spends more of its cycle in its (shared) GPU phases than in its 2.4 ms sponge: three lanes for two
+        # sponge slots (2^16, 16 proofs per job: 93 lanes 1.10 G, 128 lanes 1.26 G steps/s at 15.6 of 16 CPUs busy)
+        B = B * 11 // 8
     hbm_free = None
     if not shard and args.batch <= 0:
         probe = zigz_amd.Context(local_rank)
@@ -536,6 +540,8 @@ def main():
             return args.slots
         # (A/B at 2^20, 93 lanes: 8 slots 1.94 G, 12 1.96 G, 16 1.89-1.99 G, 24 1.81 G, 32 1.75 G -- more builds in flight get in
         # each other's way; the lanes of one sponge server leave their transcripts together, so fewer than 8 makes them queue)
+        if nv_l <= 17:  # small traces share commit jobs, 16 proofs each (make_slots): 8 slots carry 128 proofs at once
+            return 8
         return max(4, min(12, nl // 8 + 1)) if nv_l < 22 else 8
 
     class Lane:  # one trace + its resident witness; proves through the shared GPU slots (or, --slots 0 / --mode shard, a context of its own)
@@ -666,7 +672,7 @@ def main():
         slots = make_slots(slot_count(B, nv), nv)
     lanes = [Lane(k) for k in range(B)]
     setup_ctx.release_workspaces()
-    pool = ThreadPoolExecutor(max_workers=B)
+    pool = ThreadPoolExecutor(max_workers=B * 11 // 8 + 8)  # (the small-trace leg runs more lanes than the main region)
 
     def all_contexts():
         if use_slots:
@@ -1104,14 +1110,15 @@ def main():
             slots = None
         setup_ctx.release_workspaces()
         free_now = setup_ctx.mem_info()[0] // gpu_share
-        for nv_s, steps_s in ((16, 10), (22, 5), (24, 4)):
+        for nv_s, steps_s in ((16, 40), (22, 5), (24, 4)):
             if nv_s == nv:
                 continue
             if use_slots:
                 k_s = slot_count(B, nv_s)
                 while k_s > 4 and k_s * slot_bytes(nv_s, worst=False) > 0.35 * free_now:
                     k_s -= 1
-                nl = max(1, min(B, (int(free_now * 0.92) - k_s * slot_bytes(nv_s, worst=False)) // lane_bytes(nv_s)))
+                b_s = B * 11 // 8 if nv_s <= 17 and nv > 17 else B  # (small traces: more lanes than sponge slots, see above)
+                nl = max(1, min(b_s, (int(free_now * 0.92) - k_s * slot_bytes(nv_s, worst=False)) // lane_bytes(nv_s)))
             else:
                 # (a context per lane: the bench trace holds 0.66 / 2.5 / 9.9 GiB per proof in flight at 2^20 / 2^22 / 2^24 --
                 # resident columns, lists and digests after the first build's learning -- measured; below 2^20 the fixed
@@ -1127,8 +1134,8 @@ def main():
                     slots = make_slots(k_s, nv_s)
                 ls.extend(Lane(k, nv_s, pin=False) for k in range(nl))
                 setup_ctx.release_workspaces()
-                run_step(which=ls)
-                run_step(which=ls)
+                for _ in range(2 if nv_s > 17 else 6):  # (small traces: until every slot has met a full batch and sized its workspaces)
+                    run_step(which=ls)
                 dts_, _, _ = timed(steps_s, which=ls)
                 return {"dt": dts_, "steps": steps_s, "lanes": nl, "slots": k_s, "trace_steps": float(sum(l.trace.num_steps for l in ls))}
             legs["nv%d" % nv_s] = guard("value_nv%d" % nv_s, leg_size)
