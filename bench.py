@@ -375,7 +375,7 @@ def main():
     placement = importlib.util.module_from_spec(_ps)
     _ps.loader.exec_module(placement)
     pin = {"pinned": 0, "numa_node": -1, "why": "ZIGZ_BENCH_NO_PIN"} if os.environ.get("ZIGZ_BENCH_NO_PIN") else \
-        placement.pin_rank(local_rank)
+        placement.pin_rank(local_rank, local_world=int(os.environ.get("LOCAL_WORLD_SIZE", str(world))))
 
     if args.dry_run:
         tok = 1.0

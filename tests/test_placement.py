@@ -84,3 +84,22 @@ def test_pin_rank_applies_the_mask(tmp_path):
         assert called == [want] and rec["pinned"] == len(want) and rec["numa_node"] == 1
     else:  # this container's own mask has no core on the fake socket 1
         assert rec["pinned"] == 0 and not called
+
+
+def test_more_ranks_than_devices_split_a_devices_cores(tmp_path):
+    """A rehearsal of 8 ranks on a box with ONE GPU (VERDICT r3 #3b): rank r uses device r % 1 and the eight ranks split that
+    device's NUMA-local cores -- disjoint slices that cover them; with two devices, ranks 0, 2, 4, 6 split device 0's."""
+    root = _fake_node(tmp_path, gpus_per_socket=1)  # two GPUs, one per socket
+    allowed = set(range(64))
+    env1 = {"HIP_VISIBLE_DEVICES": "0"}
+    got = [placement.cpus_for_rank(r, root, env1, allowed, local_world=8) for r in range(8)]
+    assert all(g for g in got) and all(len(g) == 4 for g in got)
+    assert set().union(*got) == set(range(16)) | set(range(32, 48))
+    assert sum(len(g) for g in got) == 32  # disjoint
+    got2 = [placement.cpus_for_rank(r, root, {}, allowed, local_world=8) for r in range(8)]
+    assert set().union(*[got2[r] for r in (0, 2, 4, 6)]) == set(range(16)) | set(range(32, 48))
+    assert set().union(*[got2[r] for r in (1, 3, 5, 7)]) == set(range(16, 32)) | set(range(48, 64))
+    applied = []
+    rec = placement.pin_rank(4, root, {}, apply=applied.append, local_world=8)  # (this process's own affinity mask applies here)
+    if rec["pinned"]:
+        assert rec["numa_node"] == 0 and applied and applied[0] <= set(range(16)) | set(range(32, 48))

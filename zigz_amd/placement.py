@@ -86,10 +86,18 @@ def gpu_nodes(sysfs_root="/sys", env=None):
     return [gpus[i] for i in vis]
 
 
-def cpus_for_rank(local_rank, sysfs_root="/sys", env=None, allowed=None):
+def cpus_for_rank(local_rank, sysfs_root="/sys", env=None, allowed=None, local_world=None):
     """The cores rank `local_rank` (= HIP device index) should run on: its GPU's NUMA-local cores that this process may
-    use, split among the GPUs of the same NUMA node.  None when the topology says nothing useful."""
+    use, split among the GPUs of the same NUMA node.  None when the topology says nothing useful.
+    local_world: ranks of this node when there are MORE of them than GPUs (a rehearsal of N ranks on fewer devices): rank r
+    then uses device r % n_gpus and the ranks of one device split that device's share of the cores."""
     gpus = gpu_nodes(sysfs_root, env)
+    sub = (0, 1)
+    if local_world and gpus and local_world > len(gpus) and 0 <= local_rank < local_world:
+        ng = len(gpus)
+        on_dev = [r for r in range(local_world) if r % ng == local_rank % ng]
+        sub = (on_dev.index(local_rank), len(on_dev))
+        local_rank = local_rank % ng
     if local_rank < 0 or local_rank >= len(gpus):
         return None
     me = gpus[local_rank]
@@ -106,17 +114,22 @@ def cpus_for_rank(local_rank, sysfs_root="/sys", env=None, allowed=None):
         return set(local)
     lo = pos * per
     hi = len(local) if pos == k - 1 else lo + per
-    return set(local[lo:hi])
+    mine = local[lo:hi]
+    if sub[1] > 1:  # several ranks on this device: its cores once more
+        per2 = len(mine) // sub[1]
+        if per2 > 0:
+            mine = mine[sub[0] * per2:(len(mine) if sub[0] == sub[1] - 1 else (sub[0] + 1) * per2)]
+    return set(mine)
 
 
-def pin_rank(local_rank, sysfs_root="/sys", env=None, apply=None):
+def pin_rank(local_rank, sysfs_root="/sys", env=None, apply=None, local_world=None):
     """Pin the calling process (threads started later inherit it).  Returns a small record for the bench line."""
     try:
-        cpus = cpus_for_rank(local_rank, sysfs_root, env)
+        cpus = cpus_for_rank(local_rank, sysfs_root, env, local_world=local_world)
     except Exception as e:  # placement is an optimisation: never fail a run over it
         return {"pinned": 0, "numa_node": -1, "why": repr(e)[:80]}
     if not cpus:
         return {"pinned": 0, "numa_node": -1, "why": "no NUMA information for this GPU"}
     gpus = gpu_nodes(sysfs_root, env)
     (apply or (lambda c: os.sched_setaffinity(0, c)))(cpus)
-    return {"pinned": len(cpus), "numa_node": gpus[local_rank]["numa_node"], "first_cpu": min(cpus), "last_cpu": max(cpus)}
+    return {"pinned": len(cpus), "numa_node": gpus[local_rank % len(gpus)]["numa_node"], "first_cpu": min(cpus), "last_cpu": max(cpus)}
