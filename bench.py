@@ -722,6 +722,10 @@ def main():
                 l.proof, st, tm = l.trace.prove_slots_repeat(slots, steps, l.d_cols, l.N)
                 st["_timed"] = 0
                 return [(st, tm)]
+            if use_slots and fn is Lane.upload_and_prove:  # (the same lane loop, every proof uploading its trace inside its slot)
+                l.proof, st, tm = l.trace.prove_slots_repeat(slots, steps, None, 0)
+                st["_timed"] = 0
+                return [(st, tm)]
             out = []
             for _ in range(steps):
                 out.append(fn(l))

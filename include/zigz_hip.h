@@ -249,6 +249,34 @@ zigz_status zigz_dev_witness_from_steps_async(zigz_ctx *ctx, const zigz_trace_st
  * zigz_ctx_release_workspaces on the context -- in particular through a commit job begun on them. */
 zigz_status zigz_dev_witness_from_steps_ws(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
                                            const uint64_t *initial_regs, const uint32_t **d_cols, size_t *col_stride);
+/* The 32-BYTE record (what crosses PCIe per step decides the rate of a service whose traces arrive from the host: 48 B per step
+ * are 50 MB per 2^20 proof).  Two observations about src/vm/trace.zig:73-97: instruction.imm is a sign-extended field of at
+ * most 32 bits in every RV64IM format (src/isa/rv64i.zig:156-233), and memory_access is null on every step that is not a
+ * LOAD / STORE.  So: imm as i32, and the memory triple in a SIDE LIST of zigz_mem_access (16 B per access) that a step refers
+ * to by index -- ZIGZ_NO_MEM_ACCESS on the steps without one (an index >= num_mem reads as "none" as well).  mem_is_read
+ * stays in the record.  A kernel widens the records on the device (zigz_trace_step, above) and the same expansion follows:
+ * identical columns (tests/test_gpu_parity.py: both records against the numpy restatement and the oracle). */
+typedef struct zigz_trace_step32 {
+    uint64_t pc;        /* step.pc */
+    uint64_t rd_value;  /* regs_after[wr_reg]; ignored when wr_reg == 0 */
+    int32_t imm;        /* instruction.imm (sign-extended to i64 on the device) */
+    uint32_t mem_index; /* index of this step's access in the side list, or ZIGZ_NO_MEM_ACCESS */
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7;
+    uint8_t wr_reg;      /* 1..31: the register this step wrote; 0 (or any value >= 32): none */
+    uint8_t mem_is_read; /* 1 = load, 0 = store or no access */
+} zigz_trace_step32;
+typedef struct zigz_mem_access {
+    uint64_t addr, value; /* memory_access.address / .value */
+} zigz_mem_access;
+#define ZIGZ_NO_MEM_ACCESS 4294967295
+/* as zigz_dev_witness_from_steps (waits for the copies) */
+zigz_status zigz_dev_witness_from_steps32(zigz_ctx *ctx, const zigz_trace_step32 *h_steps, size_t num_steps,
+                                          const zigz_mem_access *h_mem, size_t num_mem, size_t nv, const uint64_t *initial_regs,
+                                          uint32_t *d_cols, size_t col_stride);
+/* as zigz_dev_witness_from_steps_ws (asynchronous, into the context's own column buffer; page-locked records) */
+zigz_status zigz_dev_witness_from_steps32_ws(zigz_ctx *ctx, const zigz_trace_step32 *h_steps, size_t num_steps,
+                                             const zigz_mem_access *h_mem, size_t num_mem, size_t nv, const uint64_t *initial_regs,
+                                             const uint32_t **d_cols, size_t *col_stride);
 /* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
  * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer; page-locking belongs
  * to the process, so unregister accepts ctx == NULL (the registering context may already be destroyed). */

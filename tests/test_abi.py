@@ -126,10 +126,10 @@ def test_zig_binding_is_in_step_with_the_header():
             continue
         assert ('pub extern "c" fn %s(' % n) in committed, n
     for t in ("Ctx", "Merkle", "CommitJob", "Transcript", "ShmComm", "TraceStep", "RadixOps", "KernelStats", "BenchResult",
-              "AllgatherFn", "LaunchRec"):
+              "AllgatherFn", "LaunchRec", "TraceStep32", "MemAccess"):
         assert ("pub const %s = " % t) in committed, t
     # the value structs have the C layout sizes the header's consumers rely on
-    assert committed.count("extern struct") == 5
+    assert committed.count("extern struct") == 7
     # ... and the layout the ZIG side gives them is the C compiler's (VERDICT r3 #8a: what can be checked without a Zig compiler):
     # offsetof / sizeof _Static_asserts generated from the Zig field lists, compiled against the header
     layout = os.path.join(ROOT, "bindings", "zig", "zigz_hip_layout_check.c")

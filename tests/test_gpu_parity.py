@@ -1397,3 +1397,92 @@ def test_commit_batch_equals_single_jobs(ctx, nv):
             ctx.set_option(k, v)
         for d, _ in bufs:
             ctx.dev_free(d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ns", [1, 63, 64, 65, 4096, 4097, 70000])
+def test_witness_from_32_byte_records_synthetic(ctx, ns):
+    """the 32-byte step record (imm as i32, the memory triple in a side list a step refers to by index --
+    zigz_trace_step32 / zigz_mem_access) must expand to the same 43 columns as the 48-byte record of the same steps and as
+    the numpy restatement of witness.zig: full-range i32 immediates (min, max, -1), full-range 64-bit values, steps with and
+    without a memory access in every mix (none at all, every step, the first / last step only), an index past the list
+    (reads as "no access"), accesses whose address and value are 0."""
+    import zigz_amd
+    from zigz_amd.hip import TRACE_STEP_DTYPE, compact_steps32, NO_MEM_ACCESS
+    rng = np.random.default_rng(3200 + ns)
+    nv = 0 if ns == 1 else int(ns - 1).bit_length()
+    N = 1 << nv
+    stride = max(N, 4)
+    init = rng.integers(0, 2**64, size=32, dtype=np.uint64)
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        for mix in ("some", "none", "all", "ends"):
+            st = np.zeros(ns, dtype=TRACE_STEP_DTYPE)
+            for f in ("pc", "rd_value"):
+                st[f] = rng.integers(0, 2**64, size=ns, dtype=np.uint64)
+            st["imm"] = rng.integers(-2**31, 2**31, size=ns, dtype=np.int64)
+            st["imm"][0] = -2**31
+            st["imm"][ns // 2] = 2**31 - 1
+            st["imm"][ns - 1] = -1
+            for f, hi in (("opcode", 128), ("rd", 32), ("rs1", 32), ("rs2", 32), ("funct3", 8), ("funct7", 128), ("mem_is_read", 2)):
+                st[f] = rng.integers(0, hi, size=ns)
+            st["wr_reg"] = rng.integers(0, 32, size=ns)
+            has = {"some": rng.random(ns) < 0.3, "none": np.zeros(ns, dtype=bool), "all": np.ones(ns, dtype=bool),
+                   "ends": np.isin(np.arange(ns), (0, ns - 1))}[mix]
+            st["mem_addr"] = np.where(has, rng.integers(0, 2**64, size=ns, dtype=np.uint64), 0)
+            st["mem_value"] = np.where(has, rng.integers(0, 2**64, size=ns, dtype=np.uint64), 0)
+            if has.any():  # an access at address 0 with value 0 is still an access
+                k = int(np.flatnonzero(has)[0])
+                st["mem_addr"][k] = 0
+                st["mem_value"][k] = 0
+            s32, mem = compact_steps32(st, has)
+            assert s32.nbytes == 32 * ns and mem.nbytes == 16 * int(has.sum())
+            if mix == "some" and ns > 2 and not has[1]:
+                s32["mem_index"][1] = len(mem) + 5  # past the list: no access, like NO_MEM_ACCESS
+            ctx.witness_from_steps32(s32, mem, nv, d, stride, init)
+            got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+            i0 = init.copy()
+            i0[0] = 0
+            exp = _expand_reference(st, ns, N, i0)
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (mix, bad[:5])
+            ctx.witness_from_steps(st, nv, d, stride, init)  # ... and the 48-byte record of the same steps
+            assert np.array_equal(ctx.download(d, 43 * stride).reshape(43, stride)[:, :N], exp), mix
+    finally:
+        ctx.dev_free(d)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maker,arg", [("mixed_loop", 700), ("fibonacci", 60), ("add_xor_loop", 2000)])
+def test_witness_from_32_byte_records_vs_oracle(ctx, maker, arg):
+    """Real traces through the 32-byte record: the host VM's steps, compacted (a side-list entry for every LOAD / STORE step),
+    expanded on the device == the oracle's VM + WitnessGenerator; and a proof whose witness is built from them inside its GPU
+    slot (the service's upload path) is byte-identical to the oracle's."""
+    import hashlib
+    import programs
+    from zigz_amd import host
+    from zigz_amd.hip import compact_steps32
+    made = getattr(programs, maker)(arg)
+    prog, inp = made if isinstance(made, tuple) else (made, None)
+    tr = host.Trace(prog, 0x1000, None, 1 << 20, inp)
+    cols, nv, ns = O.witness_from_program(P, prog, 0x1000, None, 1 << 20, inp)
+    st, init = tr.steps()
+    has = np.isin(st["opcode"], (0x03, 0x23))
+    if maker == "mixed_loop":
+        assert has.any() and (st["mem_addr"][~has] == 0).all()
+    s32, mem = compact_steps32(st, has)
+    N = 1 << nv
+    d = ctx.dev_alloc(43 * max(N, 4) * 4)
+    try:
+        ctx.witness_from_steps32(s32, mem, nv, d, max(N, 4), init)
+        assert np.array_equal(ctx.download(d, 43 * max(N, 4)).reshape(43, max(N, 4))[:, :N], cols)
+    finally:
+        ctx.dev_free(d)
+    tr.pin(ctx)  # builds + page-locks the 32-byte form inside the host mirror
+    slots = host.Slots(0, 1)
+    try:
+        proof, _, _ = tr.prove_slots(slots, None, 0)
+        assert hashlib.sha3_256(proof.tobytes()).hexdigest() == hashlib.sha3_256(O.prove(P, prog, 0x1000, None, 1 << 20, inp)[0]).hexdigest()
+    finally:
+        slots.close()
+        del tr

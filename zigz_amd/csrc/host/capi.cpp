@@ -50,6 +50,34 @@ struct zigzh_trace {
     std::optional<std::vector<uint64_t>> initial_regs;
     mutable std::vector<uint64_t> rows_cache;  // expandRows(), built on first use by zigzh_trace_rows
     zigz_ctx *registered = nullptr;            // context that page-locked trace.steps (zigzh_trace_pin)
+    // the 32-byte form of the records + the side list of memory accesses (zigz_hip.h: zigz_trace_step32): what a service
+    // uploads; built (and page-locked) by zigzh_trace_pin
+    std::vector<zigz_trace_step32> steps32;
+    std::vector<zigz_mem_access> mem;
+    bool registered32 = false, registered_mem = false;
+    void compact32() {
+        if (!steps32.empty() || trace.stepCount() == 0) return;
+        const size_t n = trace.stepCount();
+        steps32.resize(n);
+        for (size_t i = 0; i < n; i++) {
+            const zigz_trace_step &a = trace.steps[i];
+            zigz_trace_step32 &b = steps32[i];
+            if (a.imm != (int64_t)(int32_t)a.imm) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "an immediate does not fit 32 bits");
+            b.pc = a.pc;
+            b.rd_value = a.rd_value;
+            b.imm = (int32_t)a.imm;
+            b.opcode = a.opcode; b.rd = a.rd; b.rs1 = a.rs1; b.rs2 = a.rs2; b.funct3 = a.funct3; b.funct7 = a.funct7;
+            b.wr_reg = a.wr_reg;
+            b.mem_is_read = a.mem_is_read;
+            // (a step has a memory access iff it is a LOAD (opcode 3) or a STORE (35): src/vm/state.zig:467-504)
+            if (a.opcode == 0x03 || a.opcode == 0x23) {
+                b.mem_index = (uint32_t)mem.size();
+                mem.push_back(zigz_mem_access{a.mem_addr, a.mem_value});
+            } else {
+                b.mem_index = (uint32_t)ZIGZ_NO_MEM_ACCESS;
+            }
+        }
+    }
 };
 
 extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_t entry_pc, const uint64_t *initial_regs,
@@ -90,6 +118,8 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
 extern "C" void zigzh_trace_free(zigzh_trace *t) {
     if (!t) return;
     // (the context that registered the buffer may be gone by now: page-locking is process-wide, so no context is named)
+    if (t->registered32) (void)zigz_host_unregister(nullptr, t->steps32.data());
+    if (t->registered_mem) (void)zigz_host_unregister(nullptr, t->mem.data());
     if (t->registered) (void)zigz_host_unregister(nullptr, t->trace.steps.data());
     else if (t->trace.steps.capacity() > g_step_pool.capacity()) g_step_pool.swap(t->trace.steps);
     delete t;
@@ -99,6 +129,13 @@ extern "C" int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx) {
         if (t->registered || t->trace.stepCount() == 0) return;
         check(ctx, zigz_host_register(ctx, t->trace.steps.data(), t->trace.stepCount() * sizeof(zigz_trace_step)));
         t->registered = ctx;
+        t->compact32();  // the 32-byte form a service uploads (zigzh_prove_trace_slots without resident columns)
+        check(ctx, zigz_host_register(ctx, t->steps32.data(), t->steps32.size() * sizeof(zigz_trace_step32)));
+        t->registered32 = true;
+        if (!t->mem.empty()) {
+            check(ctx, zigz_host_register(ctx, t->mem.data(), t->mem.size() * sizeof(zigz_mem_access)));
+            t->registered_mem = true;
+        }
     });
 }
 extern "C" const void *zigzh_trace_steps(const zigzh_trace *t) { return t->trace.steps.data(); }
@@ -195,6 +232,22 @@ extern "C" void zigzh_slots_release(zigzh_slots *s, zigz_ctx *ctx) {
     if (s && ctx) s->slots.release(ctx);
 }
 
+// the records a proof uploads inside its slot: the 32-byte form when the trace has it (pinned traces), else the 48-byte one
+// (ZIGZ_TRACE48=1 forces the 48-byte form: A/B)
+static TraceRecords records_of(const zigzh_trace *t) {
+    TraceRecords r;
+    r.regs_before = t->trace.initial_regs;
+    static const bool force48 = getenv("ZIGZ_TRACE48") && getenv("ZIGZ_TRACE48")[0] == '1';
+    if (!t->steps32.empty() && !force48) {
+        r.s32 = t->steps32.data();
+        r.mem = t->mem.data();
+        r.nmem = t->mem.size();
+    } else {
+        r.s48 = t->trace.steps.data();
+    }
+    return r;
+}
+
 extern "C" int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, const uint32_t *d_cols, size_t stride,
                                        uint8_t **proof_out, size_t *proof_len, zigz_kernel_stats *stats_out,
                                        zigz_launch_rec *log_out, size_t log_cap, size_t *log_n) {
@@ -204,7 +257,7 @@ extern "C" int zigzh_prove_trace_slots(const zigzh_trace *t, zigzh_slots *s, con
         Prover prover(&s->slots, 0, s->batcher.get());
         const std::vector<uint64_t> *ir = t->initial_regs ? &*t->initial_regs : nullptr;
         if (d_cols) prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
-        else prover.proveStepsToBytes(t->io, t->num_lookups, t->trace.steps.data(), t->trace.initial_regs, t->num_vars, ir, g_proof);
+        else prover.proveStepsToBytes(t->io, t->num_lookups, records_of(t), t->num_vars, ir, g_proof);
         memcpy(g_timings, prover.timings, sizeof(g_timings));
         *proof_out = g_proof.data();
         *proof_len = g_proof.size();
@@ -272,7 +325,7 @@ extern "C" int zigzh_prove_trace_slots_repeat(const zigzh_trace *t, zigzh_slots 
         for (size_t r = 0; r < reps; r++) {
             Prover prover(&s->slots, 0, s->batcher.get());
             if (d_cols) prover.proveWitnessToBytes(t->io, t->num_lookups, nullptr, d_cols, stride, t->num_vars, ir, g_proof);
-            else prover.proveStepsToBytes(t->io, t->num_lookups, t->trace.steps.data(), t->trace.initial_regs, t->num_vars, ir, g_proof);
+            else prover.proveStepsToBytes(t->io, t->num_lookups, records_of(t), t->num_vars, ir, g_proof);
             stats_add(sum, prover.last_stats);
             for (int i = 0; i < 10; i++) tsum[i] += prover.timings[i];
             memcpy(g_timings, prover.timings, sizeof(g_timings));

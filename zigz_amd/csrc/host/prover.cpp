@@ -287,11 +287,11 @@ void Prover::proveWitnessToBytes(const PublicIO &io, size_t num_lookups, const W
     (void)proveWitnessImpl(io, num_lookups, witness, d_cols, d_col_stride, num_vars, initial_regs, &out);
 }
 
-void Prover::proveStepsToBytes(const PublicIO &io, size_t num_lookups, const zigz_trace_step *steps, const uint64_t *regs_before,
-                               size_t num_vars, const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out) {
+void Prover::proveStepsToBytes(const PublicIO &io, size_t num_lookups, const TraceRecords &records, size_t num_vars,
+                               const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out) {
     if (!slots_) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "proveStepsToBytes: needs a prover of a service (GpuSlots)");
-    if (!steps) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "proveStepsToBytes: no trace records");
-    (void)proveWitnessImpl(io, num_lookups, nullptr, nullptr, 0, num_vars, initial_regs, &out, steps, regs_before);
+    if (!records) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "proveStepsToBytes: no trace records");
+    (void)proveWitnessImpl(io, num_lookups, nullptr, nullptr, 0, num_vars, initial_regs, &out, records);
 }
 
 // ---------------------------------------------------------------- GpuSlots
@@ -516,7 +516,8 @@ void GpuBatcher::abandon(const std::shared_ptr<Group> &g, unsigned idx) {
 
 Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                                size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
-                               std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps, const uint64_t *regs_before) {
+                               std::vector<uint8_t> *bytes_out, const TraceRecords &records) {
+    const bool steps = (bool)records;
     // transcript binding of the public inputs (prover.zig:91-110)
     bindPublicInputs(io.program_hash, io.initial_pc, initial_regs);
     const size_t num_steps = io.num_steps;
@@ -597,7 +598,11 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         if (steps) {  // the witness from the compact trace, inside the slot: upload + expansion + builds on one stream
             const uint32_t *wc = nullptr;
             size_t ws = 0;
-            check(ctx_, zigz_dev_witness_from_steps_ws(ctx_, steps, num_steps, num_vars, regs_before, &wc, &ws));
+            if (records.s32)
+                check(ctx_, zigz_dev_witness_from_steps32_ws(ctx_, records.s32, num_steps, records.mem, records.nmem, num_vars,
+                                                             records.regs_before, &wc, &ws));
+            else
+                check(ctx_, zigz_dev_witness_from_steps_ws(ctx_, records.s48, num_steps, num_vars, records.regs_before, &wc, &ws));
             check(ctx_, zigz_commit_begin_dev(ctx_, wc + c0 * ws, c1 - c0, ws, num_vars, &guard.job));
         } else if (witness) {
             check(ctx_, zigz_commit_begin(ctx_, witness->columns.data() + c0 * ((size_t)1 << num_vars), c1 - c0,
@@ -748,7 +753,12 @@ Proof Prover::prove(const std::vector<uint8_t> &program, uint64_t entry_pc, cons
     io.final_regs = fr;
     io.num_steps = num_steps;
     if (!vm->output_tape.empty()) io.outputs = vm->output_tape;
-    if (slots_) return proveWitnessImpl(io, L, nullptr, nullptr, 0, nv, initial_regs, serialized, vm->trace.steps.data(), vm->trace.initial_regs);
+    if (slots_) {
+        TraceRecords rec;
+        rec.s48 = vm->trace.steps.data();
+        rec.regs_before = vm->trace.initial_regs;
+        return proveWitnessImpl(io, L, nullptr, nullptr, 0, nv, initial_regs, serialized, rec);
+    }
     return proveWitnessImpl(io, L, nullptr, (const uint32_t *)dcols.p, stride, nv, initial_regs, serialized);
 }
 

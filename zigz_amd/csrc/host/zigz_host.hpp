@@ -353,6 +353,17 @@ class GpuBatcher {
     std::map<std::array<uint64_t, 5>, std::shared_ptr<Group>> open_;
 };
 
+// the compact trace records of a proof whose witness is built inside its GPU slot: the 48-byte form, or the 32-byte form +
+// the side list of memory accesses (zigz_hip.h)
+struct TraceRecords {
+    const zigz_trace_step *s48 = nullptr;
+    const zigz_trace_step32 *s32 = nullptr;
+    const zigz_mem_access *mem = nullptr;
+    size_t nmem = 0;
+    const uint64_t *regs_before = nullptr;
+    explicit operator bool() const { return s48 || s32; }
+};
+
 class Prover {  // src/prover/prover.zig
   public:
     Prover(zigz_ctx *ctx, uint64_t seed) : ctx_(ctx), seed_(seed) {}
@@ -376,8 +387,8 @@ class Prover {  // src/prover/prover.zig
     // The same from the compact trace records (zigz_trace_step, page-locked): the witness is built inside the proof's GPU
     // slot, in a column buffer the slot's context owns (upload + expansion kernels + commit job on one stream) -- a proof in
     // flight then holds nothing in HBM outside its slot.  Needs a prover of a service (GpuSlots).
-    void proveStepsToBytes(const PublicIO &io_template, size_t num_lookups, const zigz_trace_step *steps, const uint64_t *regs_before,
-                           size_t num_vars, const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out);
+    void proveStepsToBytes(const PublicIO &io_template, size_t num_lookups, const TraceRecords &records, size_t num_vars,
+                           const std::vector<uint64_t> *initial_regs, std::vector<uint8_t> &out);
     // wall-clock seconds of the phases of the last proveWitness: 0 commit_begin, 1 sumcheck transcript,
     // 2 lasso transcript, 3 wait for roots, 4 absorb roots + challenges, 5 open_all, 6 packaging, 7 serialisation tail,
     // 8 wait for a GPU slot, 9 the whole time in the slot
@@ -412,7 +423,7 @@ class Prover {  // src/prover/prover.zig
     void generateCommitments(Proof &proof, const CommitSteps &gpu, size_t num_vars);                                 // :366-467
     Proof proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Witness *witness, const uint32_t *d_cols,
                            size_t d_col_stride, size_t num_vars, const std::vector<uint64_t> *initial_regs,
-                           std::vector<uint8_t> *bytes_out, const zigz_trace_step *steps = nullptr, const uint64_t *regs_before = nullptr);
+                           std::vector<uint8_t> *bytes_out, const TraceRecords &records = TraceRecords());
     zigz_ctx *ctx_;
     uint64_t seed_;
     GpuSlots *slots_ = nullptr;

@@ -676,6 +676,32 @@ __global__ __launch_bounds__(TPB) void k_steps_expand(const TraceStep *__restric
     }
 }
 
+// 32-byte records + the side list of memory accesses -> the 48-byte records the expansion reads (80 B of HBM traffic per step:
+// noise next to the 32 B per step that crossed PCIe to get here)
+__global__ __launch_bounds__(TPB) void k_steps_widen(const TraceStep32 *__restrict__ in, size_t n, const MemAccess *__restrict__ mem,
+                                                     size_t num_mem, TraceStep *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const uint4 a = reinterpret_cast<const uint4 *>(in)[2 * i], b = reinterpret_cast<const uint4 *>(in)[2 * i + 1];
+    uint64_t addr = 0, value = 0;
+    if (b.y < num_mem) {  // (ZIGZ_NO_MEM_ACCESS and any other index past the list: no access)
+        const ulonglong2 m = reinterpret_cast<const ulonglong2 *>(mem)[b.y];
+        addr = m.x;
+        value = m.y;
+    }
+    const long long imm = (long long)(int)b.x;
+    uint4 *o = reinterpret_cast<uint4 *>(out) + 3 * i;
+    o[0] = a;                                                                       // pc, rd_value
+    o[1] = make_uint4((uint32_t)addr, (uint32_t)(addr >> 32), (uint32_t)value, (uint32_t)(value >> 32));
+    o[2] = make_uint4((uint32_t)imm, (uint32_t)((unsigned long long)imm >> 32), b.z, b.w);  // imm, the eight field bytes
+}
+void launch_steps_widen(const TraceStep32 *d_in, size_t num_steps, const MemAccess *d_mem, size_t num_mem, TraceStep *d_out,
+                        hipStream_t s) {
+    if (num_steps == 0) return;
+    hipLaunchKernelGGL(k_steps_widen, dim3((unsigned)((num_steps + TPB - 1) / TPB)), dim3(TPB), 0, s, d_in, num_steps, d_mem, num_mem,
+                       d_out);
+}
+
 void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
                           uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand) {
     if (num_steps == 0) return;

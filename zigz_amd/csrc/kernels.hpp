@@ -38,6 +38,19 @@ struct TraceStep {
     uint8_t opcode, rd, rs1, rs2, funct3, funct7, wr_reg, mem_is_read;
 };
 static_assert(sizeof(TraceStep) == 48, "TraceStep must mirror zigz_trace_step (48 bytes)");
+// the 32-byte record and its side list (zigz_hip.h: zigz_trace_step32 / zigz_mem_access), widened on the device
+struct TraceStep32 {
+    uint64_t pc, rd_value;
+    int32_t imm;
+    uint32_t mem_index;
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7, wr_reg, mem_is_read;
+};
+static_assert(sizeof(TraceStep32) == 32, "TraceStep32 must mirror zigz_trace_step32 (32 bytes)");
+struct MemAccess {
+    uint64_t addr, value;
+};
+void launch_steps_widen(const TraceStep32 *d_in, size_t num_steps, const MemAccess *d_mem, size_t num_mem, TraceStep *d_out,
+                        hipStream_t s);
 struct Regs32 {
     uint32_t v[32];  // initial register values mod p (x0 = 0)
 };

@@ -18,6 +18,30 @@ TRACE_STEP_DTYPE = np.dtype([("pc", "<u8"), ("rd_value", "<u8"), ("mem_addr", "<
                              ("opcode", "u1"), ("rd", "u1"), ("rs1", "u1"), ("rs2", "u1"), ("funct3", "u1"), ("funct7", "u1"),
                              ("wr_reg", "u1"), ("mem_is_read", "u1")])
 assert TRACE_STEP_DTYPE.itemsize == 48
+# the 32-byte record and its side list (include/zigz_hip.h: zigz_trace_step32 / zigz_mem_access)
+TRACE_STEP32_DTYPE = np.dtype([("pc", "<u8"), ("rd_value", "<u8"), ("imm", "<i4"), ("mem_index", "<u4"), ("opcode", "u1"), ("rd", "u1"),
+                               ("rs1", "u1"), ("rs2", "u1"), ("funct3", "u1"), ("funct7", "u1"), ("wr_reg", "u1"), ("mem_is_read", "u1")])
+MEM_ACCESS_DTYPE = np.dtype([("addr", "<u8"), ("value", "<u8")])
+assert TRACE_STEP32_DTYPE.itemsize == 32 and MEM_ACCESS_DTYPE.itemsize == 16
+NO_MEM_ACCESS = 0xFFFFFFFF
+
+
+def compact_steps32(steps, has_access):
+    """48-byte records -> (32-byte records, side list): has_access[i] says whether step i has a memory access at all (a LOAD /
+    STORE; its address and value may well be 0).  imm must fit 32 bits (it does in every RV64IM format)."""
+    steps = np.ascontiguousarray(steps, dtype=TRACE_STEP_DTYPE)
+    has_access = np.asarray(has_access, dtype=bool)
+    out = np.zeros(len(steps), dtype=TRACE_STEP32_DTYPE)
+    for f in ("pc", "rd_value", "opcode", "rd", "rs1", "rs2", "funct3", "funct7", "wr_reg", "mem_is_read"):
+        out[f] = steps[f]
+    assert np.all(steps["imm"] == steps["imm"].astype(np.int32)), "an immediate does not fit 32 bits"
+    out["imm"] = steps["imm"].astype(np.int32)
+    idx = np.flatnonzero(has_access)
+    out["mem_index"] = NO_MEM_ACCESS
+    out["mem_index"][idx] = np.arange(len(idx), dtype=np.uint32)
+    mem = np.zeros(len(idx), dtype=MEM_ACCESS_DTYPE)
+    mem["addr"], mem["value"] = steps["mem_addr"][idx], steps["mem_value"][idx]
+    return out, mem
 
 
 def _name(code):
@@ -117,6 +141,18 @@ class Context:
             assert ira.size == 32
             ir = ira.ctypes.data_as(u64p)
         self.check(lib.zigz_dev_witness_from_steps(self.h, vp(steps.ctypes.data), steps.shape[0], nv, ir, vp(d_cols), stride))
+
+    def witness_from_steps32(self, steps32, mem, nv, d_cols, stride, initial_regs=None):
+        """the same from the 32-byte records + side list of memory accesses (zigz_dev_witness_from_steps32)"""
+        steps32 = np.ascontiguousarray(steps32, dtype=TRACE_STEP32_DTYPE)
+        mem = np.ascontiguousarray(mem, dtype=MEM_ACCESS_DTYPE)
+        ir = None
+        if initial_regs is not None:
+            ira = np.ascontiguousarray(initial_regs, dtype=np.uint64)
+            assert ira.size == 32
+            ir = ira.ctypes.data_as(u64p)
+        self.check(lib.zigz_dev_witness_from_steps32(self.h, vp(steps32.ctypes.data), steps32.shape[0], vp(mem.ctypes.data) if len(mem) else None,
+                                                     len(mem), nv, ir, vp(d_cols), stride))
 
     def download(self, d_ptr, n):
         o, op = _out_u64(n)
