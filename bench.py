@@ -327,6 +327,11 @@ def main():
                     "lane (round 3's form: the build overlaps the proof's own transcript, and every proof in flight holds its "
                     "workspaces throughout)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
+    ap.add_argument("--trace", choices=["bench", "mixed", "worst", "straight"], default="bench",
+                    help="the program whose traces the lanes prove: bench (default, BASELINE config 3: the RV64I ADD/XOR loop); mixed "
+                    "(config 4's RV64IM mix); worst (31 registers written in turn); straight (a program that never loops).  The "
+                    "default run measures the other three in legs of their own; this switch makes one of them THE workload "
+                    "(profiling, A/B)")
     ap.add_argument("--merkle", choices=["cons", "struct", "regs", "all", "tables", "dense"], default="cons",
                     help="Merkle build of the 43 columns (identical trees and proofs in every mode).  cons (the product's default): "
                     "struct + the ten instruction-determined columns as a content-addressed group (repeat wherever the program "
@@ -544,6 +549,19 @@ def main():
             return 8
         return max(4, min(12, nl // 8 + 1)) if nv_l < 22 else 8
 
+    _straight = {}
+
+    def main_program(n_rows, i):
+        if args.trace == "mixed":
+            return programs.mixed_loop((n_rows - 8) // 12 - i)
+        if args.trace == "worst":
+            return programs.register_round_robin((n_rows - 2) // 31 - i)
+        if args.trace == "straight":
+            if n_rows not in _straight:
+                _straight[n_rows] = programs.straight_line_program(1000 + rank, int(0.95 * n_rows))
+            return _straight[n_rows][:4 * (int(0.95 * n_rows) - i % 1000)]
+        return programs.add_xor_loop((n_rows - 3) // 4 - i)
+
     class Lane:  # one trace + its resident witness; proves through the shared GPU slots (or, --slots 0 / --mode shard, a context of its own)
         def __init__(self, k, nv_l=None, prog=None, pin=True):
             self.nv = nv if nv_l is None else nv_l
@@ -551,8 +569,7 @@ def main():
             self.ctx = None if use_slots else zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
             c = setup_ctx if use_slots else self.ctx
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
-            self.prog = prog if prog is not None else \
-                programs.add_xor_loop((self.N - 3) // 4 - (0 if shard else rank * B + k))  # shard: the same trace everywhere
+            self.prog = prog if prog is not None else main_program(self.N, 0 if shard else rank * B + k)  # shard: the same trace everywhere
             self.trace = host.Trace(self.prog, 0x1000, None, 2 * self.N)  # [1/6] VM execution: outside the timed region
             assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
             self.d_cols = c.dev_alloc(43 * self.N * 4)

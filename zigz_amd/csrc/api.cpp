@@ -2302,7 +2302,9 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
             if (dropped) c.g_slabs = true;  // this context's traces do not repeat: give the group's columns slabs from now on
             if (job->cons_hinted) {
                 c.g_drops = dropped ? c.g_drops + 1 : 0;
-                if (c.g_drops >= 2) c.g_skip = 15;  // ... and after the second drop in a row, skip the attempt for 15 jobs
+                // ... and after the second drop in a row, skip the attempt for 15 jobs -- twice as many after every further attempt
+                // that is dropped again (a context shared by a service's lanes sees hundreds of jobs of one kind of trace)
+                if (c.g_drops >= 2) c.g_skip = 15u << (c.g_drops - 2 < 6 ? c.g_drops - 2 : 6);
             }
             again = r_over || (g_over && !dropped) || g_noslab;
         }

@@ -431,11 +431,20 @@ __device__ __forceinline__ void cons_insert_level(const MerkleBuild &b, unsigned
     }
 }
 
-__global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b) {
+// sample != 0: the PROBE -- only every CONS_SAMPLE-th chunk of 64 leaves takes part (spread over the whole trace: a loop of P
+// steps shows all its P tuples in any such sample, a program that never repeats shows nothing but distinct ones), so that a
+// group that does not repeat is found out and dropped (k_cons_decide) for a sixteenth of the price of inserting every leaf --
+// 12 ms for 2^20 all-distinct leaves, whose waves go through the election loop 64 times -- and the full pass (sample == 0)
+// returns at once when the probe has dropped the group.  Keys the probe inserted are found again by the full pass: they keep
+// the list slots they took.
+constexpr unsigned CONS_SAMPLE = 16;
+__global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b, int sample) {
     __shared__ unsigned long long s_set[CONS_SET];
+    if (!sample && b.g_ctr[8]) return;  // dropped by the probe
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
     __syncthreads();
     const size_t k = (size_t)blockIdx.x * CONS_TPB + threadIdx.x;
+    if (sample && ((k / 64) % CONS_SAMPLE) != 0) return;  // (wave-uniform; no barrier below)
     const unsigned lane = threadIdx.x & 63;
     const bool valid = k < b.npad;
     const unsigned long long key = ((unsigned long long)b.g_gen << CONS_GEN_SHIFT) | (valid ? cons_leaf_payload(b, k) : 0);
@@ -503,16 +512,22 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
     }
 }
 
-// keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing
-__global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b) {
+// keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing.  After the
+// probe (sample != 0) the count is of the sampled leaves; after the full pass of all.
+__global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b, int sample) {
     unsigned long long c = threadIdx.x < RUN_SUBS ? b.g_ctr[run_ctr_index(0, threadIdx.x)] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
     if (threadIdx.x == 0) {
-        const bool drop = c > b.npad / 4;
-        b.g_ctr[9] = c;
-        b.g_ctr[8] = drop ? 1 : 0;
-        if (drop && !b.g_has_slabs) atomicOr(&b.g_ctr[10], 2ull);  // nowhere to build the columns densely: the build is repeated
+        if (sample) {  // the probe: a sixteenth of the leaves
+            const bool drop = c > b.npad / CONS_SAMPLE / 4;
+            b.g_ctr[8] = drop ? 1 : 0;
+            b.g_ctr[9] = drop ? c * CONS_SAMPLE : 0;  // (distinct leaves: an estimate when the probe drops the group)
+        } else if (!b.g_ctr[8]) {  // (a group the probe dropped stays dropped: the full pass did not run)
+            b.g_ctr[9] = c;
+            b.g_ctr[8] = c > b.npad / 4 ? 1 : 0;
+        }
+        if (!sample && b.g_ctr[8] && !b.g_has_slabs) atomicOr(&b.g_ctr[10], 2ull);  // nowhere to build the columns densely: repeated
     }
 }
 
@@ -521,10 +536,17 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
     const unsigned top = b.t.g_lists.top;
     const unsigned nz = b.t.nz ? b.t.nz : 1;
     const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB), 1, nz);
-    if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b);
-    else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b);
+    // the probe first (trees of >= 2^16 leaves: below that the whole insert costs less than a launch), then the full pass
+    const bool probe = b.npad >= ((size_t)1 << 16);
+    if (probe) {
+        if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b, 1);
+        else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b, 1);
+        hipLaunchKernelGGL(k_cons_decide, dim3(1, 1, nz), dim3(64), 0, s, b, 1);
+    }
+    if (kt && !probe) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b, 0);
+    else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b, 0);
     hipLaunchKernelGGL(k_cons_pass<true>, g0, dim3(CONS_TPB), 0, s, b, 0u, top >= 1 ? 1 : 0);
-    hipLaunchKernelGGL(k_cons_decide, dim3(1, 1, nz), dim3(64), 0, s, b);
+    hipLaunchKernelGGL(k_cons_decide, dim3(1, 1, nz), dim3(64), 0, s, b, 0);
     for (unsigned lr = 1; lr <= top; lr++) {
         const dim3 g((unsigned)(((b.npad >> lr) + CONS_TPB - 1) / CONS_TPB), 1, nz);
         const int ins = lr < top ? 1 : 0;
