@@ -155,13 +155,35 @@ void launch_bind(const uint32_t *d_in, size_t in_stride, uint32_t *d_out, size_t
 
 // ------------------------------------------------------------------ K2/K3: block sums (half sums = 2 blocks)
 // sums[c][b] += sum of in[c][b*m .. (b+1)*m), b < n/m, m = 2^log2_m >= 256.  The unit of work is the WAVE: each wave
-// streams W = 256*iters CONTIGUOUS elements that lie inside one block (W <= m), 8 x 16-byte loads per lane in flight,
+// streams W = 256*iters CONTIGUOUS elements that lie inside one block (W <= m), 4 x 16-byte non-temporal loads per lane in flight,
 // accumulates exactly in u64, reduces with shuffles and issues ONE atomic.  (The previous form -- one 16 KiB tile per
 // workgroup, then shuffle -> LDS -> barrier -> atomic -- spent most of a workgroup's life in that tail with no loads in
 // flight: 3.4 TB/s for 43 x 2^20 and, with every workgroup adding to the same two words, 1.2 TB/s for one 2^24 table;
 // same-address atomics serialise at ~15 ns each.)  nslots > 1 spreads the adds of one (c, b) over nslots copies of the
 // sums array, slot_stride words apart; the consumer adds the copies.
-constexpr int BS_INFLIGHT = 8;
+#ifndef ZK_BS_INFLIGHT
+#define ZK_BS_INFLIGHT 4  // (16 loses a quarter on the 13 us launches of one 2^24 table; 4 and 8 tie on 43 x 2^20, 4 wins there)
+#endif
+constexpr int BS_INFLIGHT = ZK_BS_INFLIGHT;
+// A table that is read ONCE by a pass says so: non-temporal loads (global_load_dwordx4 ... nt) do not displace what the caches
+// hold for somebody else and stream faster on this part -- cold 43 x 2^20 launches, A/B on one box (profiles/r04_ab_notes.txt):
+// k_block_sums 35.3 -> 31.4 us (0.64 -> 0.72 of 8 TB/s), k_radix_fold 34.4 -> 30.5 us (0.68 -> 0.76), one 2^24 table 14.4 ->
+// 13.3 us.  (-DZK_STREAM_PLAIN: the plain loads of rounds 1-3, for A/B.)
+#ifndef ZK_STREAM_PLAIN
+__device__ __forceinline__ uint4 zk_stream_load(const uint4 *q) {
+    const zk_v4u v = __builtin_nontemporal_load(reinterpret_cast<const zk_v4u *>(q));
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+#define ZK_STREAM_LOAD(q) zk_stream_load(q)
+#else
+#define ZK_STREAM_LOAD(q) (*(q))
+#endif
+#ifndef ZK_BS_ITERS_SHIFT
+#define ZK_BS_ITERS_SHIFT 0
+#endif
+#ifndef ZK_FOLD_RLOOPS
+#define ZK_FOLD_RLOOPS 4
+#endif
 __global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__ in, size_t in_stride, size_t n, unsigned log2_m,
                                                     unsigned iters, unsigned long long *__restrict__ sums, SumsLayout lay) {
     const size_t col = blockIdx.y;
@@ -175,7 +197,7 @@ __global__ __launch_bounds__(TPB) void k_block_sums(const uint32_t *__restrict__
     for (unsigned it = 0; it < iters; it += BS_INFLIGHT) {
         uint4 a[BS_INFLIGHT];
 #pragma unroll
-        for (int j = 0; j < BS_INFLIGHT; j++) a[j] = p[(size_t)(it + j < iters ? it + j : iters - 1) * 64];  // clamped, not branched
+        for (int j = 0; j < BS_INFLIGHT; j++) a[j] = ZK_STREAM_LOAD(p + (size_t)(it + j < iters ? it + j : iters - 1) * 64);  // clamped, not branched
 #pragma unroll
         for (int j = 0; j < BS_INFLIGHT; j++)
             acc += it + j < iters ? (unsigned long long)a[j].x + a[j].y + a[j].z + a[j].w : 0ull;
@@ -205,6 +227,7 @@ static size_t block_sums_iters(size_t n, unsigned log2_m, size_t ncols) {
     const size_t m = (size_t)1 << log2_m;
     size_t iters = (ncols * n / 256) / 8192;
     iters = iters < 1 ? 1 : (size_t)1 << floor_log2(iters);
+    iters <<= ZK_BS_ITERS_SHIFT;
     if (iters > m / 256) iters = m / 256;
     if (iters > 64) iters = 64;
     return iters;
@@ -263,7 +286,7 @@ void launch_half_sums(const uint32_t *d_in, size_t in_stride, size_t n, size_t n
 // ceiling at v = 20).  The 64-bit products W[b]*T[..] are accumulated as two exact u64 sums of their 32-bit halves
 // (64 terms: each < 2^38); one reduction per output then gives  hi + lo * 2^-32  ==  sum_b w_b * T[b*m+i]  (mod p).
 constexpr int RB = 16;     // independent 16-byte loads in flight per lane
-constexpr int RLOOPS = 4;  // RB-chunks per thread: accumulators stay in registers
+constexpr int RLOOPS = ZK_FOLD_RLOOPS;  // RB-chunks per thread: accumulators stay in registers
 // FULL: nb is a multiple of RB*RLOOPS (every launch but the late, small sumcheck stages): no row needs a bounds test
 // and the RB loads of a chunk are issued back to back.  Otherwise rows past nb are clamped to a valid row and given
 // weight 0 (per-row branches would make the compiler serialise the loads behind s_waitcnt vmcnt(0)).
@@ -303,7 +326,7 @@ __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__
         if (!FULL && b0 >= nb) break;
         uint4 v[RB];
 #pragma unroll
-        for (int j = 0; j < RB; j++) v[j] = p[(FULL || b0 + j < nb ? b0 + j : nb - 1) * mq];
+        for (int j = 0; j < RB; j++) v[j] = ZK_STREAM_LOAD(p + (FULL || b0 + j < nb ? b0 + j : nb - 1) * mq);
 #pragma unroll
         for (int j = 0; j < RB; j++) {
             // wave-uniform, Montgomery form, < p
