@@ -889,7 +889,10 @@ static zigz_status dev_eval_folds(zigz_ctx *ctx, const uint32_t *d_cols, size_t 
     CHK(ws_get(ctx, WS_MISC, nv * ncols * 4 + 64, &d_rt));
     HIPCHK(ctx, hipMemcpyAsync(d_rt, rt, nv * ncols * 4, hipMemcpyHostToDevice, ctx->stream));
     void *fold;
-    const size_t a_elems = ncols * (N / 2), b_elems = ncols * (N / 4 ? N / 4 : 1);
+    // (a column of fewer than 4 elements still takes 4 -- dst_stride below -- so that every column stays 16-byte aligned: the two
+    // buffers are sized with that stride.  Sized by the element counts alone, N = 4 let round 1 write its results over the
+    // columns round 1 was still reading whenever ncols * 2 was a multiple of 4: a batched job of 16 x 43 columns found it)
+    const size_t a_elems = ncols * (N / 2 < 4 ? 4 : N / 2), b_elems = ncols * (N / 4 < 4 ? 4 : N / 4);
     CHK(ws_get(ctx, WS_FOLD, (a_elems + b_elems) * 4, &fold));
     uint32_t *bufA = (uint32_t *)fold, *bufB = bufA + a_elems;
     bind_pool_reset(ctx);
