@@ -327,6 +327,9 @@ def main():
                     "lane (round 3's form: the build overlaps the proof's own transcript, and every proof in flight holds its "
                     "workspaces throughout)")
     ap.add_argument("--nv", type=int, default=20, help="log2 of the padded trace length (BASELINE config 3: 20)")
+    ap.add_argument("--upload", action="store_true", help="A/B only (never the headline: the metric's inputs are resident): the timed "
+                    "region uploads every proof's compact trace and builds its witness inside the proof's GPU slot, as the "
+                    "PCIe-inclusive leg of the default run does")
     ap.add_argument("--trace", choices=["bench", "mixed", "worst", "straight"], default="bench",
                     help="the program whose traces the lanes prove: bench (default, BASELINE config 3: the RV64I ADD/XOR loop); mixed "
                     "(config 4's RV64IM mix); worst (31 registers written in turn); straight (a program that never loops).  The "
@@ -483,10 +486,11 @@ def main():
     # its GPU phases (roots, challenges, openings: 2-4 of its 40-odd ms): 10 x 8 slots, 88 lanes -- 2.00-2.03 G steps/s against
     # 1.95-1.98 G with 80 on one box, 14.0 of 16 CPUs busy (96 / 104 lanes: 2.02 / 2.05 G at 15.0 / 15.7 CPUs)
     use_slots_ = not shard and args.slots != 0
-    # lanes: with slots a lane's GPU phases are no longer underneath its own transcript, so a sixth more proofs than sponge slots
-    # keeps the slots full (a tenth with a context per lane)
+    # lanes: with slots a lane's GPU phases are no longer underneath its own transcript, so three proofs for ten sponge slots on
+    # top keep the slots full (104 lanes on 80 slots; 93: -1 % resident, -12 % with the trace uploads inside the slots; a tenth
+    # more than slots with a context per lane)
     B = 1 if shard else (args.batch if args.batch > 0 else
-                         (8 * servers + max(1, 8 * servers // (6 if use_slots_ else 10)) if servers else default_batch(ncpu)))
+                         (8 * servers + max(1, 8 * servers * (3 if use_slots_ else 1) // 10) if servers else default_batch(ncpu)))
 
     def lane_bytes(nv_l):   # what a lane holds between its proofs: the 43 resident columns
         return 43 * 4 * (1 << nv_l) + (32 << 20)
@@ -765,9 +769,10 @@ def main():
         acc["process_cpu_s"] = time.process_time() - c0  # all threads of this process (lanes, sponge servers, helpers)
         return time.perf_counter() - t0, acc, phases
 
-    run_step()  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
+    main_fn = Lane.upload_and_prove if (args.upload and use_slots) else Lane.prove
+    run_step(main_fn)  # set-up, not a step: first-use allocation of every lane's workspaces (2.7 GiB of tree each), thread start-up
     for _ in range(args.warmup):
-        run_step()
+        run_step(main_fn)
     # Per-launch kernel timestamps (HIP events on every launch's own stream) cost host CPU -- two events per launch, collected
     # per proof, and their completion handlers on the runtime's event thread: ~0.5 ms of the ~8 ms of CPU per proof on a
     # host-bound box.  THE timed region therefore carries none (VERDICT r3 #3d); `roofline` comes from a short leg right after it
@@ -784,7 +789,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import thread_cpu
         snap0 = thread_cpu.snapshot()
-    dt, acc, phases = timed(args.steps)          # ---- THE timed region
+    dt, acc, phases = timed(args.steps, main_fn)  # ---- THE timed region
     if os.environ.get("ZIGZ_BENCH_THREAD_CPU"):
         rows, by = thread_cpu.diff(snap0, thread_cpu.snapshot())
         sys.stderr.write("thread CPU over the timed region (%.2f s wall):\n" % dt)
@@ -979,8 +984,18 @@ def main():
         # (after the legs above: this one gives every lane a second context and stream for its uploads -- dropped again right
         # after it: a process with twice the streams runs everything a few percent slower)
         def leg_pcie():
-            run_step(Lane.upload_and_prove)
-            dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
+            nonlocal slots
+            if use_slots:  # a slot is held ~2 ms longer per proof (the 33 MB upload + the witness kernels): a few more of them
+                slots.close()
+                slots = make_slots(min(16, slot_count(B, nv) + 4), nv)
+            try:
+                run_step(Lane.upload_and_prove)
+                run_step(Lane.upload_and_prove)
+                dtp, _, _ = timed(args.steps, Lane.upload_and_prove)   # batch B again, trace upload + witness kernels inside
+            finally:
+                if use_slots:
+                    slots.close()
+                    slots = make_slots(slot_count(B, nv), nv)
             return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
         legs["pcie"] = guard("pcie_inclusive", leg_pcie)
         guard("drop_upload_contexts", lambda: [l.drop_upload_context() for l in lanes])

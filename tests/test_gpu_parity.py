@@ -1486,3 +1486,24 @@ def test_witness_from_32_byte_records_vs_oracle(ctx, maker, arg):
     finally:
         slots.close()
         del tr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("nv,ncols", [(1, 86), (2, 86), (2, 688), (3, 344), (2, 43), (3, 1000)])
+def test_commit_job_many_tiny_columns(ctx, nv, ncols):
+    """The eval of a commit job over MANY columns of 2, 4 or 8 rows (what a batched job of small traces is): values against the
+    oracle's eval, five times over (the fold buffers were once sized without the 4-element column stride, and N = 4 let a
+    launch overwrite inputs other workgroups were still reading whenever ncols * 2 was a multiple of 4)."""
+    import zigz_amd
+    N = 1 << nv
+    cols = rnd(0x71A7 + 31 * nv + ncols, ncols * N).reshape(ncols, N)
+    pts = rnd(0x71A8 + nv + ncols, ncols * nv).reshape(ncols, nv)
+    want = [O.mle_eval(P, cols[c], pts[c]) for c in range(ncols)]
+    for _ in range(5):
+        job = zigz_amd.CommitJob(ctx, cols=cols)
+        job.roots()
+        got = job.open_all(pts)
+        job.end()
+        assert [int(v) for v in got["values"]] == want
+        assert np.array_equal(got["indices"], pts[:, 0] % np.uint64(N))
+        assert np.array_equal(got["leaves"], cols[np.arange(ncols), (pts[:, 0] % np.uint64(N)).astype(np.int64)])
