@@ -207,7 +207,7 @@ def test_sharded_sumcheck_fails_on_all_ranks_together():
 
 
 class _ReducedOps:
-    """Stand-in passes with the semantics of the RCCL passes of zigz_dev_sumcheck_prove_rccl (csrc/api.cpp: sums_out): a
+    """Stand-in passes with the semantics of the RCCL passes of zigz_dev_sumcheck_prove_rccl (csrc/api_mle.cpp: sums_out): a
     pass returns the sums over ALL ranks -- reduced inside the pass by a collective of its own, which carries one more word,
     the number of ranks whose local pass failed, and which EVERY rank takes part in whatever happened locally."""
 
@@ -278,7 +278,7 @@ def test_radix_run_with_reduced_sums_stays_in_step(fail_in):
     a rank whose pass fails must still take part in that pass's collective, and its peers must learn of the failure THERE:
     otherwise the failing rank goes straight to the tail exchange while the others enqueue the next stage's all-reduce, and
     RCCL -- which has no timeout -- never returns.  zigz_sumcheck_radix_run_reduced over stand-in passes with exactly the
-    protocol of csrc/api.cpp:sums_out, 2^15 rows over 4 ranks (two stages): without a failure the proof is the unsharded
+    protocol of csrc/api_mle.cpp: sums_out, 2^15 rows over 4 ranks (two stages): without a failure the proof is the unsharded
     oracle's; with one, every rank returns at once -- rank 1 with its own error, the others with what the collective told them."""
     world, nv = 4, 15
     ctx = mp.get_context("spawn")

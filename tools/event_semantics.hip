@@ -15,6 +15,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <algorithm>
 #include <vector>
 
 #define CK(x)                                                                                   \
@@ -33,6 +34,17 @@ __global__ void k_spin(unsigned long long *slot, unsigned long long ticks) {
     if (threadIdx.x == 0) atomicMin(&slot[0], t0);
     while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
     if (threadIdx.x == 0) atomicMax(&slot[1], wall_clock64());
+}
+
+// (e) the bench's shape: many streams, chains of dependent launches that oversubscribe the chip.  Every workgroup stores its own
+// begin / end (no atomics: 1024 same-address atomics at the end of a 25 us kernel are 12 us of kernel, case d).
+__global__ void k_spin_log(unsigned long long *log, unsigned long long ticks) {
+    const unsigned long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+    if (threadIdx.x == 0) {
+        log[2 * blockIdx.x] = t0;
+        log[2 * blockIdx.x + 1] = wall_clock64();
+    }
 }
 
 struct Launch {
@@ -94,6 +106,54 @@ int main() {
     sync();
     for (int k = 0; k < 3; k++) launch(st, slots, "d: one of three streams at once, 1024 wgs x 25 us", 1 + k, 4, 1024, 2500);
     sync();
+    {   // (e) 12 streams x 20 dependent launches of 1024 workgroups x 40 us: ~6 launches' worth of workgroups resident at a time
+        const int S = 12, L = 20, WG = 1024;
+        hipStream_t ss[S];
+        for (auto &x : ss) CK(hipStreamCreateWithFlags(&x, hipStreamNonBlocking));
+        unsigned long long *log;
+        CK(hipMalloc((void **)&log, (size_t)S * L * WG * 16));
+        std::vector<hipEvent_t> es(S * L), ee(S * L);
+        for (auto &x : es) CK(hipEventCreate(&x));
+        for (auto &x : ee) CK(hipEventCreate(&x));
+        for (int l = 0; l < L; l++)
+            for (int k = 0; k < S; k++)
+                hipExtLaunchKernelGGL(k_spin_log, dim3(WG), dim3(256), 0, ss[k], es[k * L + l], ee[k * L + l], 0, log + (size_t)(k * L + l) * WG * 2,
+                                      4000ull);
+        for (auto &x : ss) CK(hipStreamSynchronize(x));
+        std::vector<unsigned long long> h((size_t)S * L * WG * 2);
+        CK(hipMemcpy(h.data(), log, h.size() * 8, hipMemcpyDeviceToHost));
+        double sum_true = 0, sum_d = 0, max_ratio = 0;
+        std::vector<std::pair<double, double>> iv_true, iv_ev;
+        for (int i = 0; i < S * L; i++) {
+            unsigned long long a = ~0ull, b = 0;
+            for (int w = 0; w < WG; w++) {
+                a = h[((size_t)i * WG + w) * 2] < a ? h[((size_t)i * WG + w) * 2] : a;
+                b = h[((size_t)i * WG + w) * 2 + 1] > b ? h[((size_t)i * WG + w) * 2 + 1] : b;
+            }
+            float d = 0, e0 = 0, e1 = 0;
+            CK(hipEventElapsedTime(&d, es[i], ee[i]));
+            CK(hipEventElapsedTime(&e0, epoch, es[i]));
+            CK(hipEventElapsedTime(&e1, epoch, ee[i]));
+            const double t = (double)(b - a) * 0.01;
+            sum_true += t;
+            sum_d += d * 1e3;
+            if (d * 1e3 / t > max_ratio) max_ratio = d * 1e3 / t;
+            iv_true.push_back({(double)a * 0.01, (double)b * 0.01});
+            iv_ev.push_back({e0 * 1e3, e1 * 1e3});
+        }
+        auto uni = [](std::vector<std::pair<double, double>> v) {
+            std::sort(v.begin(), v.end());
+            double tot = 0, cs = v[0].first, ce = v[0].second;
+            for (auto &x : v) {
+                if (x.first > ce) { tot += ce - cs; cs = x.first; ce = x.second; }
+                else if (x.second > ce) ce = x.second;
+            }
+            return tot + ce - cs;
+        };
+        printf("e: %d streams x %d dependent launches (1024 wgs x 40 us): per launch first-wave-start..last-wave-end %.1f us, event pair %.1f us "
+               "(x%.2f, worst x%.2f); union of the intervals: in-kernel clock %.0f us, events %.0f us\n",
+               S, L, sum_true / (S * L), sum_d / (S * L), sum_d / sum_true, max_ratio, uni(iv_true), uni(iv_ev));
+    }
     CK(hipMemcpy(h_slots, slots, sizeof(h_slots), hipMemcpyDeviceToHost));
     const double tick_us = 0.01;
     const unsigned long long t_epoch = h_slots[126];

@@ -31,7 +31,9 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p4_b1 -- pyth
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p4_bdef -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline --no-extras > gpurun_out/p4_bdef.json 2> gpurun_out/p4_bdef.err
 T=$(ls gpurun_out/p4_bdef/*/*kernel_trace.csv | head -1)
 PPP=$(python3 -c "import json; d=json.load(open('gpurun_out/p4_bdef.json')); print(d['config']['keccak_permutations_per_proof'] - 255*43)")
-python3 tools/trace_union.py $T --perms-per-proof $PPP --json gpurun_out/p4_bdef_union.json --intervals gpurun_out/p4_bdef_intervals.csv.gz > /dev/null
+LAST=$(python3 -c "import json; print(json.load(open('gpurun_out/p4_bdef.json'))['roofline']['launches'])")
+python3 tools/trace_union.py $T --perms-per-proof $PPP --json gpurun_out/p4_bdef_union_whole_run.json --intervals gpurun_out/p4_bdef_intervals.csv.gz > /dev/null
+python3 tools/trace_union.py gpurun_out/p4_bdef_intervals.csv.gz --perms-per-proof $PPP --last $LAST --json gpurun_out/p4_bdef_union.json > /dev/null
 rm -f $T gpurun_out/p4_b1/*/*kernel_trace.csv gpurun_out/p4_kernels/*/*kernel_trace.csv
 echo "[3/4] profiled bench runs done"
 # (4) Lasso and the real sumcheck

@@ -41,17 +41,35 @@ def main():
     ap.add_argument("--instr", type=float, default=4428.0)
     ap.add_argument("--json")
     ap.add_argument("--intervals", help="write (class, start_ns, end_ns) of every classified launch, gzip CSV")
+    ap.add_argument("--last", type=int, default=0, help="only the last N launches of every class -- with N = roofline.launches of the "
+                    "bench line of the same --no-extras run: the launches of its roofline leg, the last thing such a run does")
     a = ap.parse_args()
     per = collections.defaultdict(list)
-    for r in csv.DictReader(open(a.csv)):
-        name = r["Kernel_Name"]
-        for key, cls in CLASSES:
-            if key in name:
-                per[cls].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
-                break
+    if a.csv.endswith(".gz"):  # an intervals file written by an earlier run of this tool (the full trace is not kept: ~10 MB)
+        for r in csv.DictReader(gzip.open(a.csv, "rt")):
+            per[r["class"]].append((int(r["start_ns"]), int(r["end_ns"])))
+    else:
+        for r in csv.DictReader(open(a.csv)):
+            name = r["Kernel_Name"]
+            for key, cls in CLASSES:
+                if key in name:
+                    per[cls].append((int(r["Start_Timestamp"]), int(r["End_Timestamp"])))
+                    break
+    if a.intervals:  # (all of them, before --last)
+        t00 = min(s for v in per.values() for s, _ in v)
+        with gzip.open(a.intervals, "wt") as f:
+            f.write("class,start_ns,end_ns\n")
+            for cls, iv in per.items():
+                for s, e in sorted(iv):
+                    f.write("%s,%d,%d\n" % (cls, s - t00, e - t00))
+    if a.last:
+        n_lh = len(per.get("level_hash", []))
+        for cls in list(per):
+            k = max(1, round(a.last * len(per[cls]) / max(n_lh, 1)))  # the same share of every class's launches
+            per[cls] = sorted(per[cls])[-k:]
     allv = [x for v in per.values() for x in v]
     t0, t1 = min(s for s, _ in allv), max(e for _, e in allv)
-    out = {"source": a.csv.split("/")[-1], "wall_us_first_to_last_launch": (t1 - t0) / 1e3, "classes": {}}
+    out = {"source": a.csv.split("/")[-1], "last": a.last or None, "wall_us_first_to_last_launch": (t1 - t0) / 1e3, "classes": {}}
     for cls, iv in per.items():
         u = union(iv)
         out["classes"][cls] = {"launches": len(iv), "sum_of_durations_us": sum(e - s for s, e in iv) / 1e3, "union_us": u / 1e3,
@@ -66,12 +84,6 @@ def main():
     print(json.dumps(out, indent=1))
     if a.json:
         json.dump(out, open(a.json, "w"), indent=1)
-    if a.intervals:
-        with gzip.open(a.intervals, "wt") as f:
-            f.write("class,start_ns,end_ns\n")
-            for cls, iv in per.items():
-                for s, e in sorted(iv):
-                    f.write("%s,%d,%d\n" % (cls, s - t0, e - t0))
 
 
 if __name__ == "__main__":

@@ -61,6 +61,9 @@ def build_hip(force=False):
         ("kernels.hip", [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"] + extra),
         ("merkle_levels.hip", [hipcc, f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"] + extra),
         ("api.cpp", [hipcc, "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
+        ("api_mle.cpp", [hipcc, "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
+        ("api_commit.cpp", [hipcc, "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
+        ("api_misc.cpp", [hipcc, "-O3", "-std=c++17", "-fPIC", f"-I{INC}", f"-I{CSRC}"]),
         # the host sponge is the sequential critical path of a proof: ROCm's clang schedules the scalar / BMI2 Keccak-f
         # 7 % faster than g++ on the EPYC 9575F of the GPU box (tools/host_keccak_rate.cpp: 0.178 vs 0.192 us)
         ("host_hash.cpp", [_host_cxx(), "-O3", "-std=c++17", "-fPIC", f"-I{CSRC}"]),
