@@ -508,7 +508,7 @@ def main():
         hbm_free = probe.mem_info()[0] // gpu_share
         probe.close()
         if use_slots_:
-            k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 22 else 8)
+            k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 24 else 8)
             # (the legs on traces that do not loop run at 2^20 and below; above, the budget is the bench trace's)
             B = max(1, min(B, (int(hbm_free * 0.92) - k_guess * slot_bytes(args.nv, worst=args.nv < 22)) // lane_bytes(args.nv)))
         else:
@@ -551,7 +551,7 @@ def main():
         # each other's way; the lanes of one sponge server leave their transcripts together, so fewer than 8 makes them queue)
         if nv_l <= 17:  # small traces share commit jobs, 16 proofs each (make_slots): 8 slots carry 128 proofs at once
             return 8
-        return max(4, min(12, nl // 8 + 1)) if nv_l < 22 else 8
+        return max(4, min(12, nl // 8 + 1)) if nv_l < 24 else 8
 
     _straight = {}
 
@@ -567,14 +567,15 @@ def main():
         return programs.add_xor_loop((n_rows - 3) // 4 - i)
 
     class Lane:  # one trace + its resident witness; proves through the shared GPU slots (or, --slots 0 / --mode shard, a context of its own)
-        def __init__(self, k, nv_l=None, prog=None, pin=True):
+        def __init__(self, k, nv_l=None, prog=None, pin=True, trace=None):
             self.nv = nv if nv_l is None else nv_l
             self.N = 1 << self.nv
             self.ctx = None if use_slots else zigz_amd.Context(local_rank)  # raises NoDevice: the product has no CPU path
             c = setup_ctx if use_slots else self.ctx
             # synthetic RV64I ADD/XOR loop; every lane / rank proves a different trace
             self.prog = prog if prog is not None else main_program(self.N, 0 if shard else rank * B + k)  # shard: the same trace everywhere
-            self.trace = host.Trace(self.prog, 0x1000, None, 2 * self.N)  # [1/6] VM execution: outside the timed region
+            # [1/6] VM execution: outside the timed region (`trace`: executed beforehand, by several threads for the large sizes)
+            self.trace = trace if trace is not None else host.Trace(self.prog, 0x1000, None, 2 * self.N)
             assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
             self.d_cols = c.dev_alloc(43 * self.N * 4)
             if pin:
@@ -1146,7 +1147,7 @@ def main():
             slots = None
         setup_ctx.release_workspaces()
         free_now = setup_ctx.mem_info()[0] // gpu_share
-        for nv_s, steps_s in ((16, 40), (22, 5), (24, 4)):
+        for nv_s, steps_s in ((16, 40), (22, 6), (24, 6)):
             if nv_s == nv:
                 continue
             if use_slots:
@@ -1168,7 +1169,12 @@ def main():
                 nonlocal slots
                 if use_slots:
                     slots = make_slots(k_s, nv_s)
-                ls.extend(Lane(k, nv_s, pin=False) for k in range(nl))
+                # (the VM runs of the lanes' traces -- 0.3 s each at 2^24 -- on a few threads; the device part one lane after the other)
+                progs_s = [main_program(1 << nv_s, rank * B + k) for k in range(nl)]
+                with ThreadPoolExecutor(max_workers=min(8, max(1, ncpu // 2))) as tp:
+                    traces_s = list(tp.map(lambda pr: host.Trace(pr, 0x1000, None, 2 << nv_s), progs_s))
+                ls.extend(Lane(k, nv_s, prog=progs_s[k], pin=False, trace=traces_s[k]) for k in range(nl))
+                del traces_s
                 setup_ctx.release_workspaces()
                 for _ in range(2 if nv_s > 17 else 6):  # (small traces: until every slot has met a full batch and sized its workspaces)
                     run_step(which=ls)
