@@ -1147,7 +1147,7 @@ def main():
             slots = None
         setup_ctx.release_workspaces()
         free_now = setup_ctx.mem_info()[0] // gpu_share
-        for nv_s, steps_s in ((16, 40), (22, 6), (24, 6)):
+        for nv_s, steps_s in ((16, 40), (22, 6), (24, 8)):
             if nv_s == nv:
                 continue
             if use_slots:
