@@ -508,7 +508,7 @@ def main():
         hbm_free = probe.mem_info()[0] // gpu_share
         probe.close()
         if use_slots_:
-            k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 24 else 8)
+            k_guess = args.slots if args.slots > 0 else (max(4, min(12, B // 8 + 1)) if args.nv < 24 else 6)
             # (the legs on traces that do not loop run at 2^20 and below; above, the budget is the bench trace's)
             B = max(1, min(B, (int(hbm_free * 0.92) - k_guess * slot_bytes(args.nv, worst=args.nv < 22)) // lane_bytes(args.nv)))
         else:
@@ -551,7 +551,8 @@ def main():
         # each other's way; the lanes of one sponge server leave their transcripts together, so fewer than 8 makes them queue)
         if nv_l <= 17:  # small traces share commit jobs, 16 proofs each (make_slots): 8 slots carry 128 proofs at once
             return 8
-        return max(4, min(12, nl // 8 + 1)) if nv_l < 24 else 8
+        # (2^24, 8 steps: 8 slots / 75 lanes 1.75 G, 7 / 77 1.80 G, 6 / 80 1.83 G -- a slot's 7 GiB of trees and lists are worth 2.5 lanes)
+        return max(4, min(12, nl // 8 + 1)) if nv_l < 24 else 6
 
     _straight = {}
 
