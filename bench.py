@@ -476,9 +476,10 @@ def main():
     servers = args.sponge_servers
     if servers < 0:
         # a server is one busy core per 8 proofs in flight; the lanes' own threads, the serialiser helpers and the runtime's
-        # event thread need ~2.6 ms of CPU per proof on top: 10 servers on a 16-CPU share leave them 6 cores (11 servers use
-        # 15.9 of the 16 and are 7 % faster when nothing else runs; 12 are over the quota and 15 % slower)
-        servers = 0 if shard or not has_avx512f() else max(1, min(12, ncpu * 5 // 8))
+        # event thread need ~2.2 ms of CPU per proof on top.  On a 16-CPU share (round 4, lanes on shared GPU slots, one box,
+        # three interleaved runs each): 10 servers 2.03-2.06 G steps/s at 13.1 CPUs busy, the GPU slots mostly free (host-bound);
+        # 11: 2.06-2.11 G at 14.4, proofs queue for the GPU (GPU-bound); 12: 2.07-2.11 G at 15.0-15.6; 13: 1.98-2.10 G, over the quota
+        servers = 0 if shard or not has_avx512f() else max(1, min(12, ncpu * 11 // 16))
     if servers > 0:
         zigz_amd._ffi.lib.zigz_host_sponge_servers(servers)
         servers = servers if zigz_amd._ffi.lib.zigz_host_sponge_batching() else 0
@@ -535,10 +536,11 @@ def main():
 
     def make_slots(k, nv_l):
         sl = host.Slots(local_rank, k)
-        if nv_l <= 17 and os.environ.get("ZIGZ_BENCH_NO_BATCHING") != "1":
+        if nv_l <= int(os.environ.get("ZIGZ_BENCH_BATCH_NV", "17")) and os.environ.get("ZIGZ_BENCH_NO_BATCHING") != "1":
             # small traces: proofs that reach their GPU phase together share one commit job (GpuBatcher): at 2^16 a proof's ~35
             # launches are 13 us of work each; the lanes of a sponge server leave their transcripts together anyway
-            sl.set_batching(int(os.environ.get("ZIGZ_BENCH_BATCH_MAX", "16")), float(os.environ.get("ZIGZ_BENCH_BATCH_LINGER_US", "200")), 17)
+            sl.set_batching(int(os.environ.get("ZIGZ_BENCH_BATCH_MAX", "16")), float(os.environ.get("ZIGZ_BENCH_BATCH_LINGER_US", "200")),
+                            int(os.environ.get("ZIGZ_BENCH_BATCH_NV", "17")))
         return sl
 
     def slot_count(nl, nv_l):
@@ -842,7 +844,16 @@ def main():
             steps_r = max(2, min(args.steps, 4))
             dt_r, acc_r, _ = timed(steps_r)
             recs = [r for l in lanes for lg in l.logs for r in lg]
-            roof_leg = {"dt": dt_r, "steps": steps_r, "acc": acc_r, "recs": recs}
+            # per level of k_level_hash: a proof's class-5 launches are its levels 0, 1, .. in order
+            by_level = {}
+            for l in lanes:
+                for lg in l.logs:
+                    lv = 0
+                    for c_, _p, a, b in lg:
+                        if c_ == 5:
+                            by_level.setdefault(lv, []).append((a, b))
+                            lv += 1
+            roof_leg = {"dt": dt_r, "steps": steps_r, "acc": acc_r, "recs": recs, "by_level": by_level}
         except Exception as e:  # noqa: BLE001
             sys.stderr.write("bench.py: roofline leg failed: %r\n" % (e,))
         finally:
@@ -1363,6 +1374,20 @@ def main():
                   "class_busy_share_of_wall_roofline_leg": detail_busy,
                   "roofline_leg": {"steps": roof_leg["steps"], "proofs": roof_leg["steps"] * B, "wall_us": wall_us,
                                    "launches_logged": len(roof_leg["recs"])} if roof_leg else None}
+        if roof_leg and roof_leg.get("by_level"):
+            # the big levels (0-4 hold 97 % of a proof's hashes and fill the chip alone) against the wall clock of the leg: how much
+            # of the time is at least one of them running, how many at once, and how long a launch of each level takes in company
+            bl = roof_leg["by_level"]
+            big = [iv for lv, v in bl.items() if lv <= 4 for iv in v]
+            ev = sorted([(a, 1) for a, _ in big] + [(b, -1) for _, b in big])
+            hist, cnt, last = {}, 0, ev[0][0] if ev else 0.0
+            for t_, d_ in ev:
+                hist[cnt] = hist.get(cnt, 0.0) + (t_ - last)
+                last, cnt = t_, cnt + d_
+            detail["level_hash_levels_roofline_leg"] = {
+                "avg_us_by_level": [round(sum(b - a for a, b in bl[lv]) / len(bl[lv]), 1) for lv in sorted(bl)],
+                "big_levels_0_4_union_share_of_wall": union_us(big) / wall_us if big else None,
+                "big_levels_at_once_share_of_wall": {str(k_): round(v_ / wall_us, 4) for k_, v_ in sorted(hist.items()) if k_ > 0}}
         for k_ in ("leg_wall_us", "sum_of_durations_us", "valu_instr_per_hash", "eval_hbm_frac"):
             detail["roofline_" + k_] = roof.pop(k_, None)
         if solo:

@@ -1336,7 +1336,7 @@ def _trace_cols(ctx, prog, nv):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("nv", [0, 3, 5, 10, 13, 14, 15, 16])
+@pytest.mark.parametrize("nv", [0, 3, 5, 10, 13, 14, 15, 16, 18, 20])
 def test_commit_batch_equals_single_jobs(ctx, nv):
     """zigz_commit_begin_batch: several proofs' 43 witness columns in ONE commit job -- one structure pass, one
     k_level_hash per level, one top launch, one eval, one path launch for all of them -- must give every proof exactly the

@@ -30,6 +30,7 @@ ap.add_argument("--debug-skip", type=int, default=0, help="measurement only (wro
                 "2 = no structure passes (the hash launches then find the previous job's lists)")
 ap.add_argument("--phases", action="store_true", help="also print the host wall time of each call of the commit job")
 ap.add_argument("--blocking-sync", action="store_true", help="waiting host threads sleep instead of spinning")
+ap.add_argument("--batch", type=int, default=1, help="proofs per commit job (zigz_commit_begin_batch: the arena form at 2^20)")
 args = ap.parse_args()
 if args.blocking_sync:
     zigz_amd._ffi.lib.zigz_device_set_blocking_sync(0, 1)
@@ -55,7 +56,12 @@ class Lane:
         self.tr = host.Trace(prog, 0x1000, None, 2 * N)
         self.d = self.ctx.dev_alloc(43 * N * 4)
         self.tr.witness_to_device(self.ctx, self.d, N)
-        self.points = rng.integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
+        self.ds = [self.d]
+        for j in range(1, args.batch):  # (the same witness again: what a job costs does not depend on whose columns they are)
+            d2 = self.ctx.dev_alloc(43 * N * 4)
+            self.tr.witness_to_device(self.ctx, d2, N)
+            self.ds.append(d2)
+        self.points = rng.integers(0, 2013265921, size=(43 * args.batch, nv), dtype=np.uint64)
         self.ctx.set_option("small_domain_mask", SMALL)
         self.ctx.set_option("run_aware_mask", {"regs": REGS, "regs+mem": REGS | (3 << 40), "all": ((1 << 43) - 1) & ~SMALL,
                                                "cons": REGS | (3 << 40)}[args.hint])
@@ -65,7 +71,10 @@ class Lane:
 
     def once(self):
         t0 = time.perf_counter()
-        job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)
+        if args.batch > 1:
+            job = zigz_amd.CommitJob(self.ctx, d_cols_list=self.ds, ncols=43, nv=nv, col_stride=N)
+        else:
+            job = zigz_amd.CommitJob(self.ctx, d_cols=self.d, ncols=43, nv=nv, col_stride=N)
         t1 = time.perf_counter()
         job.roots()
         t2 = time.perf_counter()
@@ -94,9 +103,9 @@ th = [threading.Thread(target=loop, args=(l,)) for l in lanes]
 [t.start() for t in th]
 [t.join() for t in th]
 dt = time.perf_counter() - t0
-n = args.lanes * args.iters
+n = args.lanes * args.iters * args.batch
 if args.phases:
     tot = [sum(l.t[i] for l in lanes) / (args.lanes * (args.iters + 1)) * 1e3 for i in range(4)]
     print("host wall per proof and lane: begin %.3f  roots %.3f  open_all %.3f  end %.3f ms" % tuple(tot))
-print("%s (hint %s): %d lanes: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
-      (args.trace, args.hint, args.lanes, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))
+print("%s (hint %s): %d lanes x %d proofs per job: %.3f ms per proof's GPU work = %.1f M steps/s if nothing else bounded it" %
+      (args.trace, args.hint, args.lanes, args.batch, dt / n * 1e3, n * lanes[0].tr.num_steps / dt / 1e6))

@@ -740,7 +740,7 @@ extern "C" zigz_status zigz_commit_begin_batch(zigz_ctx *ctx, const uint32_t *co
         return ZIGZ_ERR_BAD_STATE;
     }
     const size_t N = (size_t)1 << nv;
-    const bool arena = N >= RUN_MIN_LEAVES && N <= ((size_t)1 << 18) && ncols <= 64 && (ctx->run_aware_mask || ctx->cons_group_mask);
+    const bool arena = N >= RUN_MIN_LEAVES && N <= ((size_t)1 << BATCH_ARENA_MAX_NV) && ncols <= 64 && (ctx->run_aware_mask || ctx->cons_group_mask);
     if (N >= RUN_MIN_LEAVES && !arena) return ZIGZ_ERR_INVALID_ARGUMENT;  // (large tables: one job per proof)
     zigz_commit_job *job = new (std::nothrow) zigz_commit_job();
     if (!job) return ZIGZ_ERR_OUT_OF_MEMORY;

@@ -104,6 +104,7 @@ constexpr size_t HOST_TAIL_MAX = 1024;
 static const size_t PIN_WORDS = 1 << 19;  // 4 MiB: the openings of a batched job (32 proofs x 43 x (24 + 33 v) bytes) fit the zero-copy path
 static const size_t ROOTS_MAX_COLS = 4096;
 constexpr unsigned BATCH_MAX = 32;  // proofs per batched commit job (kernels.hpp: ColSrcs)
+constexpr unsigned BATCH_ARENA_MAX_NV = 20;  // largest table of the arena form (worst-case lists: 3.8 GiB per proof of 43 columns at 2^20)
 
 
 #define HIPCHK(ctx, call)                                                                        \

@@ -218,7 +218,7 @@ extern "C" int zigzh_slots_set_batching(zigzh_slots *s, unsigned max_batch, doub
     return guard([&] {
         if (!s || max_batch > 32) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "zigzh_slots_set_batching: bad argument");
         if (max_batch <= 1) s->batcher.reset();
-        else s->batcher.reset(new GpuBatcher(&s->slots, max_batch, linger_us * 1e-6, max_nv < 18 ? max_nv : 18));
+        else s->batcher.reset(new GpuBatcher(&s->slots, max_batch, linger_us * 1e-6, max_nv < 20 ? max_nv : 20));
     });
 }
 extern "C" int zigzh_slots_create(int device, size_t k, zigzh_slots **out) {

@@ -336,6 +336,8 @@ struct GpuBatcher::Group {
     std::vector<const uint32_t *> cols;
     int phase = 0;  // 0 collecting, 1 building, 2 roots there, 3 opening, 4 done, -1 failed
     double deadline = 0;
+    bool full = false;  // max_batch members: the driver need not linger
+    std::array<uint64_t, 5> key{};
     std::condition_variable cv;
     zigz_ctx *ctx = nullptr;
     zigz_commit_job *job = nullptr;
@@ -349,11 +351,19 @@ struct GpuBatcher::Group {
     zigz_kernel_stats stats{};
 };
 
-// begin + roots for a closed group (any member's thread; the lock is NOT held)
+// begin + roots for a group (its driver's thread; the lock is NOT held).  The group stays open while the driver waits for a GPU
+// slot: with a backlog in front of the GPU -- the only time sharing launches matters -- proofs that arrive meanwhile join, and
+// the group is as large as the backlog allows without anybody having waited for it; it closes when the slot is there.
 void GpuBatcher::build(const std::shared_ptr<Group> &g) {
     try {
         g->lease.slots = slots_;
         g->lease.ctx = g->ctx = slots_->acquire();
+        {
+            std::lock_guard<std::mutex> lk(m_);
+            auto it = open_.find(g->key);
+            if (it != open_.end() && it->second == g) open_.erase(it);
+            g->phase = 1;
+        }
         zigz_ctx *c = g->ctx;
         (void)zigz_ctx_get_option(c, "small_domain_mask", &g->sd0);
         (void)zigz_ctx_get_option(c, "run_aware_mask", &g->ra0);
@@ -372,6 +382,8 @@ void GpuBatcher::build(const std::shared_ptr<Group> &g) {
     }
     {
         std::lock_guard<std::mutex> lk(m_);
+        auto it = open_.find(g->key);  // (no slot: the group never closed)
+        if (it != open_.end() && it->second == g) open_.erase(it);
         g->phase = g->err ? -1 : 2;
         if (g->err) finish(g);
     }
@@ -417,7 +429,7 @@ std::shared_ptr<GpuBatcher::Group> GpuBatcher::join(const uint32_t *d_cols, size
                                                      uint64_t m_cons, unsigned *idx, uint8_t *roots43) {
     const std::array<uint64_t, 5> key{(uint64_t)nv, (uint64_t)stride, m_small, m_run, m_cons};
     std::shared_ptr<Group> g;
-    bool run_build = false;
+    bool run_build = false;  // the member that opened the group drives it: lingers, takes the slot, builds
     {
         std::unique_lock<std::mutex> lk(m_);
         auto it = open_.find(key);
@@ -428,28 +440,26 @@ std::shared_ptr<GpuBatcher::Group> GpuBatcher::join(const uint32_t *d_cols, size
             g->m_small = m_small;
             g->m_run = m_run;
             g->m_cons = m_cons;
+            g->key = key;
             g->deadline = now_s() + linger_s_;
             open_[key] = g;
+            run_build = true;
         } else {
             g = it->second;
         }
         *idx = (unsigned)g->cols.size();
         g->cols.push_back(d_cols);
         g->present.push_back(1);
-        if (g->cols.size() >= max_batch_) {  // full: this member closes it
-            open_.erase(key);
-            g->phase = 1;
-            run_build = true;
-        } else {
-            while (g->phase == 0) {
+        if (g->cols.size() >= max_batch_) {  // full: the next arrival opens a new group
+            auto it2 = open_.find(key);
+            if (it2 != open_.end() && it2->second == g) open_.erase(it2);
+            g->full = true;
+            g->cv.notify_all();
+        }
+        if (run_build) {
+            while (!g->full) {
                 const double left = g->deadline - now_s();
-                if (left <= 0) {  // nobody else came in time: whoever notices first closes it
-                    auto it2 = open_.find(key);
-                    if (it2 != open_.end() && it2->second == g) open_.erase(it2);
-                    g->phase = 1;
-                    run_build = true;
-                    break;
-                }
+                if (left <= 0) break;  // nobody else came in time
                 g->cv.wait_for(lk, std::chrono::duration<double>(left));
             }
         }

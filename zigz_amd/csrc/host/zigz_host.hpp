@@ -321,8 +321,9 @@ class GpuSlots {
 // Small traces: proofs that arrive at their GPU phase within a short while of each other share ONE commit job
 // (zigz_commit_begin_batch: one structure pass, one hash launch per level, one eval, one path launch for all of them) --
 // at 2^16 and below a proof's ~35 launches are mostly latency, and a service's small proofs arrive in bursts anyway (the
-// lanes of one sponge server leave their transcripts together).  A group forms per (size, hints); it closes when it is full
-// or `linger` after its first member arrived; whoever closes it takes a GPU slot and runs begin + roots for all; each
+// lanes of one sponge server leave their transcripts together).  A group forms per (size, hints); the member that opened it
+// waits until it is full or `linger` has passed, then for a GPU slot -- the group stays open meanwhile, so with a backlog in
+// front of the GPU it grows to what is waiting -- closes it and runs begin + roots for all; each
 // member then absorbs ITS roots and draws ITS challenges on its own thread (the transcripts stay per proof: the bytes of a
 // proof do not depend on whom it shared a launch with), and the last member to hand in its points runs open_all + end for
 // all.  Results are per proof exactly what a job of its own gives (tests/test_gpu_parity.py: batch == single jobs).

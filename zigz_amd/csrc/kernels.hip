@@ -312,6 +312,7 @@ __global__ __launch_bounds__(TPB) void k_radix_fold(const uint32_t *__restrict__
                                                     const uint32_t *__restrict__ w_m, size_t w_stride,
                                                     unsigned long long *__restrict__ part, size_t part_col_stride, EvalSkip skip,
                                                     int rloops) {
+    ZK_PRIO_SMALL();
     const size_t q = (size_t)blockIdx.x * TPB + threadIdx.x;  // uint4 index of the outputs
     if (q * 4 >= m) return;
     const size_t col = blockIdx.z;
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long
                                                         size_t groups, uint32_t *__restrict__ out, size_t out_stride,
                                                         size_t m, unsigned log2_m2, unsigned long long *__restrict__ sums,
                                                         EvalSkip skip) {
+    ZK_PRIO_SMALL();
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     const size_t col = blockIdx.z;
     if (eval_skips(skip, col)) return;  // (its partial sums were never written)
@@ -400,6 +402,7 @@ void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_str
 // eq weights by doubling in LDS, one workgroup per column (all values Montgomery form: mont_mul keeps the form)
 __global__ __launch_bounds__(TPB) void k_eq_weights(const uint32_t *__restrict__ r_m, size_t r_stride, unsigned k,
                                                     uint32_t *__restrict__ w_m, size_t w_stride) {
+    ZK_PRIO_SMALL();
     extern __shared__ uint32_t eqw[];
     const size_t col = blockIdx.x;
     if (threadIdx.x == 0) eqw[0] = R_MOD_P;
@@ -429,6 +432,7 @@ __global__ __launch_bounds__(TPB) void k_eq_weights(const uint32_t *__restrict__
 __global__ __launch_bounds__(TPB) void k_eq_weights2(const uint32_t *__restrict__ r_m, size_t r_stride, unsigned kA,
                                                      uint32_t *__restrict__ wA, size_t strideA, unsigned kB,
                                                      uint32_t *__restrict__ wB, size_t strideB) {
+    ZK_PRIO_SMALL();
     extern __shared__ uint32_t eqw[];
     const size_t col = blockIdx.x;
     const bool second = blockIdx.y != 0;
@@ -473,6 +477,7 @@ __global__ __launch_bounds__(TPB) void k_weighted_dot(const uint32_t *__restrict
                                                       const uint32_t *__restrict__ w_m, size_t w_stride, size_t n,
                                                       uint32_t *__restrict__ out, EvalSkip skip, const uint32_t *__restrict__ cols,
                                                       size_t col_stride) {
+    ZK_PRIO_SMALL();
     __shared__ unsigned long long red[TPB / 64];
     const size_t col = blockIdx.x;
     if (cols && eval_skips(skip, col)) {  // (workgroup-uniform) the extension of a constant column is the constant
@@ -995,6 +1000,7 @@ __device__ __forceinline__ void signal_done(const DoneFlag &done, unsigned n_gro
 __global__ __launch_bounds__(64) void k_paths(TreeRef t, size_t n_values, unsigned height, const uint32_t *__restrict__ vals,
                                               size_t val_stride, const uint64_t *__restrict__ idx, uint8_t *__restrict__ sib,
                                               uint8_t *__restrict__ dirs, uint32_t *__restrict__ leaf, DoneFlag done) {
+    ZK_PRIO_SMALL();
     const size_t col = blockIdx.x;
     const size_t fc = (size_t)blockIdx.z * gridDim.x + col;  // a batched job: proof blockIdx.z; results are numbered proof by proof
     if (t.zstride) vals += (size_t)blockIdx.z * (t.zstride / 4);
@@ -1049,6 +1055,7 @@ __global__ void k_gather_nodes(const uint8_t *__restrict__ tree, size_t tree_str
 // buffer, one copy
 __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ out, size_t ncols, const unsigned long long *r_ctr,
                               const unsigned long long *sd_ctr, const unsigned long long *g_ctr, DoneFlag done) {
+    ZK_PRIO_SMALL();
     const size_t c = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     // a batched job (proof blockIdx.y of gridDim.y): the roots of all proofs one after the other, then every proof's counters
     const unsigned z = blockIdx.z, nz = gridDim.z;
@@ -1092,6 +1099,7 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
     signal_done(done, gridDim.x * gridDim.z);
 }
 __global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g, size_t zstride) {
+    ZK_PRIO_SMALL();
     const unsigned i = blockIdx.x * TPB + threadIdx.x;
     if (zstride && blockIdx.y) {
         const size_t o = (size_t)blockIdx.y * zstride / 8;

@@ -16,7 +16,10 @@
 
 namespace zk {
 
-constexpr int CONS_TPB = 1024;  // threads per workgroup of the table passes (16 waves share one LDS key set)
+#ifndef ZK_CONS_TPB
+#define ZK_CONS_TPB 256
+#endif
+constexpr int CONS_TPB = ZK_CONS_TPB;  // threads per workgroup of the table passes (its waves share one LDS key set)
 
 // ------------------------------------------------------------------ layout helpers (host)
 static unsigned log2u(size_t n) { unsigned l = 0; while (((size_t)1 << l) < n) l++; return l; }
@@ -142,6 +145,7 @@ constexpr int RUNS_WAVES = TPB / 64;
 template <bool STAGE0>
 __global__ __launch_bounds__(TPB) void k_runs_stage(MerkleBuild b, unsigned stage, unsigned seg_log2, unsigned rmax, unsigned nseg,
                                                     size_t in_off /*bytes, stage >= 1*/, size_t out_off /*bytes, next stage or ~0*/) {
+    ZK_PRIO_SMALL();
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const unsigned y = blockIdx.y, segi = blockIdx.x * RUNS_WAVES + wave;
     if (segi >= nseg) return;  // (wave-uniform; the waves of a workgroup never meet)
@@ -406,7 +410,7 @@ __device__ __forceinline__ uint32_t cons_lookup(const unsigned long long *keys, 
 // Second filter, per workgroup: of the wave leaders that hold the same key only the first to put it into the workgroup's key
 // set (LDS) goes to the table in memory.  A loop-dominated level then costs a handful of table accesses per 1024 nodes; without
 // it every wave of the level queues at the same few words (same-address atomics serialise at ~15 ns: 85 us for level 1).
-constexpr unsigned CONS_SET = 2048;  // slots: at most 1024 keys arrive
+constexpr unsigned CONS_SET = 2 * CONS_TPB;  // slots: at most CONS_TPB keys arrive
 __device__ __forceinline__ bool wg_first(unsigned long long *set, unsigned long long key) {
     unsigned slot = (unsigned)(cons_mix(key) >> 40) & (CONS_SET - 1);
     for (;;) {
@@ -439,6 +443,7 @@ __device__ __forceinline__ void cons_insert_level(const MerkleBuild &b, unsigned
 // the list slots they took.
 constexpr unsigned CONS_SAMPLE = 16;
 __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b, int sample) {
+    ZK_PRIO_SMALL();
     __shared__ unsigned long long s_set[CONS_SET];
     if (!sample && b.g_ctr[8]) return;  // dropped by the probe
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
@@ -456,6 +461,7 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_leaf_insert(MerkleBuild b, in
 // lr + 1: node c / 2's key is the pair of the slots of c and c + 1, which sit in neighbouring lanes.
 template <bool LEAF>
 __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned lr, int do_insert) {
+    ZK_PRIO_SMALL();
     __shared__ unsigned long long s_set[CONS_SET];
     if (b.g_ctr[8]) return;  // the group was dropped (k_cons_decide)
     for (unsigned i = threadIdx.x; i < CONS_SET; i += CONS_TPB) s_set[i] = 0;
@@ -515,6 +521,7 @@ __global__ __launch_bounds__(CONS_TPB) void k_cons_pass(MerkleBuild b, unsigned 
 // keep or drop: a group whose leaves are mostly distinct does not repeat, and its table passes would find nothing.  After the
 // probe (sample != 0) the count is of the sampled leaves; after the full pass of all.
 __global__ __launch_bounds__(64) void k_cons_decide(MerkleBuild b, int sample) {
+    ZK_PRIO_SMALL();
     unsigned long long c = threadIdx.x < RUN_SUBS ? b.g_ctr[run_ctr_index(0, threadIdx.x)] : 0;
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) c += __shfl_down(c, off);
@@ -571,6 +578,7 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
     __shared__ unsigned s_pad[ZK_LEVEL_HASH_LDS_PAD / 4];
     if (b.npad == 3) s_pad[threadIdx.x] = L;  // (never true: keeps the array)
 #endif
+    if (!PAUSE) ZK_PRIO_SMALL();  // (the small levels: links of a dependent chain)
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
     if (wave < 2) {
@@ -615,6 +623,15 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
         size_t col, k;
         uint8_t *out;
         const uint8_t *in0 = nullptr, *in1 = nullptr;
+#ifdef ZK_LH_FAKE  // measurement only (wrong trees): no list, no leader search, no gathers -- what the loop costs without them
+        if (ZK_LH_FAKE) {
+            col = 0;
+            k = e;
+            out = b.t.upper + (e & 4095) * 32;
+            in0 = b.t.upper + ((2 * e) & 4095) * 32;
+            in1 = in0 + 32;
+        } else
+#endif
         if (e < cR) {
             unsigned sub = 0;  // the sub-list that holds entry e: the last one that starts at or before it
 #pragma unroll
@@ -684,6 +701,18 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
     const size_t n_L = b.npad >> L;
     size_t wgs = ((size_t)(b.rcols.n + b.gcols.n) * n_L + TPB - 1) / TPB;  // an upper bound of the work; the lists say how much
     if (wgs > 2048) wgs = 2048;                                            // there is (8 workgroups per CU stride over it)
+#ifndef ZK_LH_GRID_BY_NODES
+    {   // ... and the room the lists have (what the context's earlier builds needed + 25 %) says it better: a small level of a
+        // looping trace holds a few thousand entries, not (columns x nodes) -- and every workgroup of a launch has to find a
+        // free place on a chip full of other proofs' hash waves before it can even see that it has nothing to do.  (The loop
+        // strides over whatever there is: a group dropped on the device, whose columns are hashed densely here, takes more
+        // steps per thread, not more threads.)
+        size_t room = (b.rcols.n ? (size_t)RUN_SUBS * b.t.r_lists.cap[L] : 0) + (b.gcols.n ? (size_t)RUN_SUBS * b.t.g_lists.cap[L] * b.gcols.n : 0);
+        size_t w2 = (room + TPB - 1) / TPB;
+        if (w2 < 8) w2 = 8;
+        if (w2 < wgs) wgs = w2;
+    }
+#endif
     // fewer than two waves per SIMD even if every node were hashed: the re-arm pauses would only add latency
     const bool small = (size_t)(b.rcols.n + b.gcols.n) * n_L <= (size_t)256 * 4 * 2 * 64;
     // a batched job: the proofs share the launch (gridDim.z), and with them the chip -- the grid is per proof
@@ -700,6 +729,7 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
 // LDS.  Every hash here is a link in a dependent chain run by a few lone waves, so the permutation is the variant without
 // re-arm pauses.  The levels it computes go to TreeRef::upper (a build with lists) or into the slabs.
 __global__ __launch_bounds__(TPB) void k_merkle_top(TreeRef t, unsigned first_level, unsigned height) {
+    ZK_PRIO_SMALL();
     __shared__ Digest s_d[TPB];  // the level just computed: the next one reads its children here, not from global memory
     const size_t col = blockIdx.y;
     for (unsigned l = first_level; l < height; l++) {

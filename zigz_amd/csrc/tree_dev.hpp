@@ -12,6 +12,14 @@ namespace zk {
 
 constexpr int TPB = 256;      // 4 waves per workgroup
 
+// Issue priority of the short dependent launches (structure passes, small levels, tops, evaluations, paths): their waves share
+// SIMDs with the big hash levels of other proofs, whose waves always have a VALU instruction ready; the chip runs at most four
+// launches at a time (tools/stream_concurrency.hip), so a short launch that crawls holds a quarter of the launch slots.
+#ifndef ZK_SMALL_PRIO
+#define ZK_SMALL_PRIO 3
+#endif
+#define ZK_PRIO_SMALL() __builtin_amdgcn_s_setprio(ZK_SMALL_PRIO)
+
 // launch with (kt != nullptr) or without kernel-exact timestamps
 #define ZK_LAUNCH(kt, kern, grid, block, lds, s, ...)                                                             \
     do {                                                                                                          \
