@@ -582,7 +582,7 @@ def main():
             assert self.trace.num_vars == self.nv, (self.trace.num_vars, self.nv)
             self.d_cols = c.dev_alloc(43 * self.N * 4)
             if pin:
-                self.trace.pin(c)  # page-locked trace records (48 B per step): uploads run at PCIe rate
+                self.trace.pin(c)  # page-locked trace records (48 B per step, and the 32 / 16 B forms a service uploads): PCIe rate
             self.trace.witness_to_device(c, self.d_cols, self.N)   # [2/6] witness resident in HBM before timing
             c.synchronize()
             if not use_slots:
@@ -649,7 +649,7 @@ def main():
             self.digest = hashlib.sha256(self.proof.tobytes()).hexdigest()
             return r
 
-        def upload_and_prove(self):  # PCIe-inclusive: one upload of the compact trace (48 B per step) + one run of the witness
+        def upload_and_prove(self):  # PCIe-inclusive: one upload of the compact trace (16 B per step + code table) + one run of the witness
             # kernels per proof, inside the loop.  With slots: inside the proof's GPU slot, into a column buffer the slot owns
             # (upload, expansion and builds on the slot's stream; the other slots' kernels run underneath the copy) -- a lane
             # then needs no resident witness at all.  --slots 0: pipelined as round 3 did -- while this proof runs, the NEXT
@@ -1275,6 +1275,12 @@ def main():
 
         def valu_frac(perms, instr, us):
             return perms * instr / (us / 1e6) / 1e12 / VALU_PEAK_TOPS if us else None
+        # ALGORITHMIC instructions per permutation: what the cheapest kernel here that performs one executes for it
+        # (k_keccak_leaves, 3 976 VALU instructions: Keccak-f[1600] in the bit-interleaved 32-bit form + digest conversion).  The list
+        # kernel's own code is longer (4 428 static, all three of its branches; 4 202 executed per hash by SQ_INSTS_VALU,
+        # profiles/r04_one_proof_kernels.json): list entry, leader search and gathers are overhead, not work, so they do not
+        # count as achieved (round 3 and the first half of round 4 multiplied by the kernel's static count: x1.114)
+        IC_ALG = min(ic["leaves"], ic["level"])
         lh_perms = acc_l.get("list_hash_perms", 0)
         lh_launches = len(cls_iv.get("level_hash", [])) or (nv - 7) * nproofs_l  # one k_level_hash launch per level 0 .. v - 8
         dense_perms = acc_l.get("keccak_leaves_perms", 0) + acc_l.get("keccak_level_wide_perms", 0) + acc_l.get("keccak_level_small_perms", 0)
@@ -1292,26 +1298,29 @@ def main():
         if share["level_hash"] >= share["dense"]:
             busy = unions.get("level_hash") or classes["level_hash"]   # (no intervals: the sum of durations, as round 3)
             roof = {"kernel": "k_level_hash", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
-                    "achieved": lh_perms * ic["level_hash"] / (busy / 1e6) / 1e12 if busy else 0.0,
+                    "achieved": lh_perms * IC_ALG / (busy / 1e6) / 1e12 if busy else 0.0,
                     "traffic": traffic, "traffic_algorithmic": traffic_alg,
                     "avg_launch_us": classes["level_hash"] / max(lh_launches, 1), "launches": lh_launches,
-                    "hashes_per_launch": lh_perms / max(lh_launches, 1), "valu_instr_per_hash": ic["level_hash"],
+                    "hashes_per_launch": lh_perms / max(lh_launches, 1), "valu_instr_per_hash": IC_ALG,
+                    "valu_instr_per_hash_kernel_static": ic["level_hash"],
+                    "frac_with_kernel_static_count": valu_frac(lh_perms, ic["level_hash"], busy),
                     "busy_us": busy, "sum_of_durations_us": classes["level_hash"],
-                    "frac_by_sum_of_durations": valu_frac(lh_perms, ic["level_hash"], classes["level_hash"])}
+                    "frac_by_sum_of_durations": valu_frac(lh_perms, IC_ALG, classes["level_hash"])}
         else:  # a dense build (--merkle dense / tables): the dense leaf + level kernels dominate
             busy = unions.get("dense") or classes["dense"]
             nl_d = len(cls_iv.get("dense", [])) or nproofs_l
             roof = {"kernel": "k_keccak_leaves+k_keccak_level", "bound": "valu", "unit": "T lane-instr/s", "peak": VALU_PEAK_TOPS,
-                    "achieved": dense_perms * ic["level"] / (busy / 1e6) / 1e12 if busy else 0.0,
+                    "achieved": dense_perms * IC_ALG / (busy / 1e6) / 1e12 if busy else 0.0,
                     "traffic": None, "traffic_algorithmic": None,
                     "avg_launch_us": classes["dense"] / max(nl_d, 1), "launches": nl_d,
-                    "hashes_per_launch": dense_perms / max(nl_d, 1), "valu_instr_per_hash": ic["level"],
+                    "hashes_per_launch": dense_perms / max(nl_d, 1), "valu_instr_per_hash": IC_ALG,
                     "busy_us": busy, "sum_of_durations_us": classes["dense"],
-                    "frac_by_sum_of_durations": valu_frac(dense_perms, ic["level"], classes["dense"])}
+                    "frac_by_sum_of_durations": valu_frac(dense_perms, IC_ALG, classes["dense"])}
         roof["frac"] = roof["achieved"] / VALU_PEAK_TOPS
         roof = {k: roof[k] for k in ("kernel", "bound", "unit", "peak", "achieved", "frac", "traffic", "traffic_algorithmic",
-                                     "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash", "busy_us",
-                                     "sum_of_durations_us", "frac_by_sum_of_durations")}
+                                     "avg_launch_us", "launches", "hashes_per_launch", "valu_instr_per_hash",
+                                     "valu_instr_per_hash_kernel_static", "frac_with_kernel_static_count", "busy_us",
+                                     "sum_of_durations_us", "frac_by_sum_of_durations") if k in roof}
         # what share of the leg's wall clock (first launch begin .. last launch end) had >= 1 launch of a class on the GPU
         roof["leg_wall_us"] = wall_us
         roof["busy_share_of_wall"] = roof["busy_us"] / wall_us if unions else None
@@ -1327,14 +1336,14 @@ def main():
         # that has dropped its clocks in between (`in_proof_frac_idle_gaps`; the driver's round-3 line: 0.25 against 0.37).
         if gpu_one and gpu_one.get("acc"):
             a = gpu_one["acc"]
-            roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
+            roof["in_proof_frac"] = valu_frac(a.get("list_hash_perms", 0), IC_ALG, a.get("list_hash_us", 0.0))
             if a.get("structure_us") and struct_bytes:
                 roof["structure_in_proof_hbm_frac"] = struct_bytes * gpu_one["steps"] / 1e9 / (a["structure_us"] / 1e6) / HBM_PEAK_GBS
         if solo and solo["acc"].get("list_hash_us"):
             a = solo["acc"]
-            roof["in_proof_frac_idle_gaps"] = valu_frac(a.get("list_hash_perms", 0), ic["level_hash"], a.get("list_hash_us", 0.0))
+            roof["in_proof_frac_idle_gaps"] = valu_frac(a.get("list_hash_perms", 0), IC_ALG, a.get("list_hash_us", 0.0))
         # all Keccak work of the TIMED REGION over its wall time: a lower bound on what the chip sustained while the bench ran
-        roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * ic["level_hash"] / dt / 1e12 / VALU_PEAK_TOPS
+        roof["timed_region_aggregate_frac"] = acc["keccak_permutations"] * IC_ALG / dt / 1e12 / VALU_PEAK_TOPS
         kl = kern.get("k_keccak_leaves[43x2^%d]" % nv) if kern else None
         if kl:  # what the permutation code reaches back to back on 43 x 2^nv leaves in this process: the ceiling of its mix
             roof["permutation_ceiling_frac"] = kl["frac"]
@@ -1388,7 +1397,7 @@ def main():
                 "avg_us_by_level": [round(sum(b - a for a, b in bl[lv]) / len(bl[lv]), 1) for lv in sorted(bl)],
                 "big_levels_0_4_union_share_of_wall": union_us(big) / wall_us if big else None,
                 "big_levels_at_once_share_of_wall": {str(k_): round(v_ / wall_us, 4) for k_, v_ in sorted(hist.items()) if k_ > 0}}
-        for k_ in ("leg_wall_us", "sum_of_durations_us", "valu_instr_per_hash", "eval_hbm_frac"):
+        for k_ in ("leg_wall_us", "sum_of_durations_us", "eval_hbm_frac"):
             detail["roofline_" + k_] = roof.pop(k_, None)
         if solo:
             cfg["single_proof_ms"] = solo["dt"] / solo["n"] * 1e3
@@ -1404,6 +1413,11 @@ def main():
                 detail["single_proof"]["vm_ms"] = solo["vm_ms"]
         if legs.get("pcie"):  # trace upload + witness kernels inside the loop
             cfg["pcie_inclusive_value"] = rate(legs["pcie"])
+            try:  # what crossed PCIe per proof in that leg: the record the host mirror chose for lane 0's trace
+                form, nbytes = lanes[0].trace.upload_form()
+                detail["pcie_upload"] = {"bytes_per_step_record": form, "bytes_per_proof": nbytes}
+            except Exception:  # noqa: BLE001
+                pass
         if legs.get("gpu_all"):  # the commit path alone: what the GPU needs per proof (ms), and the same without its hashing
             def gpu_ms(leg):
                 return leg["dt"] / (leg["steps"] * leg.get("lanes", B)) * 1e3

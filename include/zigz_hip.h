@@ -277,6 +277,38 @@ zigz_status zigz_dev_witness_from_steps32(zigz_ctx *ctx, const zigz_trace_step32
 zigz_status zigz_dev_witness_from_steps32_ws(zigz_ctx *ctx, const zigz_trace_step32 *h_steps, size_t num_steps,
                                              const zigz_mem_access *h_mem, size_t num_mem, size_t nv, const uint64_t *initial_regs,
                                              const uint32_t **d_cols, size_t *col_stride);
+/* The 16-BYTE record.  One more observation about src/vm/trace.zig:73-97: the seven instruction fields of a step (opcode, rd, rs1,
+ * rs2, funct3, funct7, imm) are the decoded instruction AT step.pc (src/vm/state.zig:128-140: fetch, decode, execute) -- a
+ * program of P instructions has P different field tuples however long it runs.  So the fields travel ONCE per instruction, in a
+ * code table indexed by (pc - code_base) / 4, and a step carries where it was, what it wrote and which access it made:
+ *   pc_word : (pc - code_base) with mem_is_read in bit 0 (pc - code_base is a multiple of 4 below 2^32: RV64IM has no 16-bit forms)
+ *   mem_wr  : bits 0-26 the index of the step's access in the side list (ZIGZ_NO_MEM_ACCESS16 = none; an index >= num_mem reads as
+ *             none as well), bits 27-31 wr_reg
+ * A caller whose trace does not fit -- a pc that is not 4-aligned or 2^32 past the base, the same pc executed with two different
+ * decodings (a program that rewrote itself), 2^27 - 1 or more accesses -- uses the 32-byte record (the host mirror does: host/capi.cpp).
+ * A step whose pc_word points past the table gets zero fields.  The kernel widens to zigz_trace_step and the same expansion
+ * follows: identical columns (tests/test_gpu_parity.py).  16.8 MB instead of 33.6 cross PCIe for a 2^20 trace of a loop. */
+typedef struct zigz_trace_step16 {
+    uint32_t pc_word;
+    uint32_t mem_wr;
+    uint64_t rd_value;  /* regs_after[wr_reg]; ignored when wr_reg == 0 */
+} zigz_trace_step16;
+typedef struct zigz_code_entry {
+    int32_t imm;        /* instruction.imm (sign-extended to i64 on the device) */
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7;
+    uint8_t reserved0, reserved1; /* 0 */
+} zigz_code_entry;
+#define ZIGZ_NO_MEM_ACCESS16 134217727
+/* as zigz_dev_witness_from_steps32 (waits for the copies) */
+zigz_status zigz_dev_witness_from_steps16(zigz_ctx *ctx, const zigz_trace_step16 *h_steps, size_t num_steps,
+                                          const zigz_mem_access *h_mem, size_t num_mem, uint64_t code_base,
+                                          const zigz_code_entry *h_code, size_t num_code, size_t nv, const uint64_t *initial_regs,
+                                          uint32_t *d_cols, size_t col_stride);
+/* as zigz_dev_witness_from_steps32_ws (asynchronous, into the context's own column buffer; page-locked records, side list and table) */
+zigz_status zigz_dev_witness_from_steps16_ws(zigz_ctx *ctx, const zigz_trace_step16 *h_steps, size_t num_steps,
+                                             const zigz_mem_access *h_mem, size_t num_mem, uint64_t code_base,
+                                             const zigz_code_entry *h_code, size_t num_code, size_t nv, const uint64_t *initial_regs,
+                                             const uint32_t **d_cols, size_t *col_stride);
 /* Page-lock a host buffer the caller reuses for uploads (trace records, witness columns): H2D copies from registered
  * memory run at PCIe rate without the staging copy.  zigz_host_unregister before freeing the buffer; page-locking belongs
  * to the process, so unregister accepts ctx == NULL (the registering context may already be destroyed). */

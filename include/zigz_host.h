@@ -47,6 +47,9 @@ const void *zigzh_trace_steps(const zigzh_trace *t);
 const uint64_t *zigzh_trace_initial_regs(const zigzh_trace *t);
 /* page-lock the records for repeated uploads (zigz_host_register); released by zigzh_trace_free */
 int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx);
+/* which record a service uploads for this trace once it is pinned -- 16 (zigz_trace_step16 + code table: the trace fits the form),
+ * 32 (zigz_trace_step32) or 48 bytes per step -- and (optional) the bytes that cross PCIe per proof: records + side list + table */
+int zigzh_trace_upload_form(const zigzh_trace *t, size_t *bytes);
 /* WitnessGenerator.generate -> 43 columns of 2^nv canonical u64, column-major   witness.zig:29-61 */
 int zigzh_trace_witness(const zigzh_trace *t, uint64_t *cols_out);
 /* builds the 43 witness columns directly in HBM (packed u32, column stride `stride` elements) */

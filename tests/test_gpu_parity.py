@@ -1489,6 +1489,155 @@ def test_witness_from_32_byte_records_vs_oracle(ctx, maker, arg):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("ns", [1, 2, 3, 64, 65, 1000, 4097, 70000])
+def test_witness_from_16_byte_records_synthetic(ctx, ns):
+    """The 16-byte step record (zigz_trace_step16: pc as an offset into a CODE TABLE that carries the seven instruction fields
+    once per pc, wr_reg and the side-list index packed into one word, mem_is_read in the pc word's bit 0) must expand to the same
+    43 columns as the 48-byte record of the same steps and as the numpy restatement of witness.zig: programs of 1, 7 and ~ns / 3
+    instructions at a 64-bit base, full-range i32 immediates, every access mix, an index past the side list and the "none" index,
+    a pc_word past the code table (zero fields), wr_reg 0 and 31."""
+    import zigz_amd
+    from zigz_amd.hip import TRACE_STEP_DTYPE, compact_steps16, NO_MEM_ACCESS16
+    rng = np.random.default_rng(1600 + ns)
+    nv = 0 if ns == 1 else int(ns - 1).bit_length()
+    N = 1 << nv
+    stride = max(N, 4)
+    init = rng.integers(0, 2**64, size=32, dtype=np.uint64)
+    d = ctx.dev_alloc(43 * stride * 4)
+    try:
+        for mix, ninst in (("some", 7), ("none", 1), ("all", max(1, ns // 3)), ("ends", 7)):
+            base = int(rng.integers(0, 2**62)) & ~3
+            # the program: ninst decoded instructions; a step executes one of them
+            code = {f: rng.integers(0, hi, size=ninst) for f, hi in (("opcode", 128), ("rd", 32), ("rs1", 32), ("rs2", 32), ("funct3", 8),
+                                                                    ("funct7", 128))}
+            code["imm"] = rng.integers(-2**31, 2**31, size=ninst, dtype=np.int64)
+            code["imm"][0] = -2**31
+            code["imm"][ninst // 2] = 2**31 - 1
+            code["imm"][ninst - 1] = -1 if ninst > 2 else code["imm"][ninst - 1]
+            at = rng.integers(0, ninst, size=ns)
+            at[0] = ninst - 1  # (the table's last entry is used)
+            st = np.zeros(ns, dtype=TRACE_STEP_DTYPE)
+            st["pc"] = np.uint64(base) + (at * 4).astype(np.uint64)
+            st["rd_value"] = rng.integers(0, 2**64, size=ns, dtype=np.uint64)
+            for f in code:
+                st[f] = code[f][at]
+            st["wr_reg"] = rng.integers(0, 32, size=ns)
+            st["wr_reg"][0] = 31
+            st["wr_reg"][ns - 1] = 0
+            st["mem_is_read"] = rng.integers(0, 2, size=ns)
+            has = {"some": rng.random(ns) < 0.3, "none": np.zeros(ns, dtype=bool), "all": np.ones(ns, dtype=bool),
+                   "ends": np.isin(np.arange(ns), (0, ns - 1))}[mix]
+            st["mem_addr"] = np.where(has, rng.integers(0, 2**64, size=ns, dtype=np.uint64), 0)
+            st["mem_value"] = np.where(has, rng.integers(0, 2**64, size=ns, dtype=np.uint64), 0)
+            if has.any():
+                k = int(np.flatnonzero(has)[0])
+                st["mem_addr"][k] = 0
+                st["mem_value"][k] = 0
+            c = compact_steps16(st, has)
+            assert c is not None
+            s16, mem, cbase, ctab = c
+            assert s16.nbytes == 16 * ns and mem.nbytes == 16 * int(has.sum()) and cbase == int(st["pc"].min())
+            if mix == "some" and ns > 2 and not has[1]:
+                s16["mem_wr"][1] = (s16["mem_wr"][1] & ~np.uint32(NO_MEM_ACCESS16)) | np.uint32(len(mem) + 5)  # past the list: none
+            ctx.witness_from_steps16(s16, mem, cbase, ctab, nv, d, stride, init)
+            got = ctx.download(d, 43 * stride).reshape(43, stride)[:, :N]
+            i0 = init.copy()
+            i0[0] = 0
+            exp = _expand_reference(st, ns, N, i0)
+            bad = np.argwhere(got != exp)
+            assert bad.size == 0, (mix, bad[:5])
+            ctx.witness_from_steps(st, nv, d, stride, init)  # ... and the 48-byte record of the same steps
+            assert np.array_equal(ctx.download(d, 43 * stride).reshape(43, stride)[:, :N], exp), mix
+            if mix == "some" and ns > 3:  # a pc past the table: that step's seven fields read as zero
+                k = ns // 2
+                s16["pc_word"][k] = np.uint32(4 * len(ctab) + 8) | (s16["pc_word"][k] & np.uint32(1))
+                st2 = st.copy()
+                st2["pc"][k] = np.uint64(cbase + 4 * len(ctab) + 8)
+                for f in code:
+                    st2[f][k] = 0
+                ctx.witness_from_steps16(s16, mem, cbase, ctab, nv, d, stride, init)
+                # (the access of step 1 was cut off above: its columns are those of a step without one)
+                if not has[1]:
+                    pass
+                exp2 = _expand_reference(st2, ns, N, i0)
+                assert np.array_equal(ctx.download(d, 43 * stride).reshape(43, stride)[:, :N], exp2)
+        # what the form refuses: a pc off the grid, one pc with two decodings
+        st = np.zeros(4, dtype=TRACE_STEP_DTYPE)
+        st["pc"] = [0x1000, 0x1004, 0x1006, 0x1008]
+        assert compact_steps16(st, np.zeros(4, dtype=bool)) is None
+        st["pc"] = [0x1000, 0x1004, 0x1000, 0x1008]
+        st["rd"] = [1, 2, 3, 4]
+        assert compact_steps16(st, np.zeros(4, dtype=bool)) is None
+    finally:
+        ctx.dev_free(d)
+
+
+def _self_modifying_program():
+    """Executes the word at 0x1010 twice: as ADDI x2,x0,1, then -- after storing another instruction over it -- as ADDI x2,x0,2."""
+    import programs as pg
+    new = pg._I(0x13, 2, 0, 0, 2)                        # ADDI x2,x0,2
+    w = pg._li(3, new)                                   # 0x1000, 0x1004: x3 = the new instruction word
+    w += [pg._U(0x37, 4, 1)]                             # 0x1008: LUI x4,1 -> x4 = 0x1000
+    w += [pg._I(0x13, 5, 0, 5, 1)]                       # 0x100c: ADDI x5,x5,1 (pass counter)
+    w += [pg._I(0x13, 2, 0, 0, 1)]                       # 0x1010: ADDI x2,x0,1  <- rewritten
+    w += [pg._S(2, 4, 3, 0x10)]                          # 0x1014: SW x3,0x10(x4)
+    w += [pg._I(0x13, 6, 0, 0, 2)]                       # 0x1018: ADDI x6,x0,2
+    w += [pg._B(1, 5, 6, -16)]                           # 0x101c: BNE x5,x6,-16 -> 0x100c (second pass)
+    w += [pg._I(0x13, 7, 0, 2, 0)]                       # 0x1020: ADDI x7,x2,0
+    return pg._pack(w)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("maker,arg", [("mixed_loop", 700), ("fibonacci", 60), ("add_xor_loop", 2000), ("random_program", 7),
+                                       ("self_modifying", 0)])
+def test_witness_from_16_byte_records_vs_oracle(ctx, maker, arg):
+    """Real traces through the 16-byte record: the host VM's steps, compacted (code table from the decoded fields of the steps
+    themselves), expanded on the device == the oracle's VM + WitnessGenerator; the host mirror picks the form for a pinned trace
+    and a proof whose witness is built from it inside its GPU slot is byte-identical to the oracle's.  A program that REWRITES an
+    instruction it executes twice does not fit the form (one pc, two decodings): the mirror falls back to the 32-byte record, the
+    proof is the oracle's all the same."""
+    import hashlib
+    import programs
+    from zigz_amd import host
+    from zigz_amd.hip import compact_steps16
+    if maker == "self_modifying":
+        made = _self_modifying_program()
+    elif maker == "random_program":
+        made = programs.random_program(np.random.default_rng(arg), n_insts=80)
+    else:
+        made = getattr(programs, maker)(arg)
+    prog, inp = made if isinstance(made, tuple) else (made, None)
+    tr = host.Trace(prog, 0x1000, None, 1 << 20, inp)
+    cols, nv, ns = O.witness_from_program(P, prog, 0x1000, None, 1 << 20, inp)
+    st, init = tr.steps()
+    has = np.isin(st["opcode"], (0x03, 0x23))
+    c = compact_steps16(st, has)
+    N = 1 << nv
+    if maker == "self_modifying":
+        assert c is None and int(cols[1 + 2].max()) == 2  # (column 1 + r is xr: x2 ended as 2 -- the rewritten instruction did run)
+    else:
+        s16, mem, cbase, ctab = c
+        d = ctx.dev_alloc(43 * max(N, 4) * 4)
+        try:
+            ctx.witness_from_steps16(s16, mem, cbase, ctab, nv, d, max(N, 4), init)
+            assert np.array_equal(ctx.download(d, 43 * max(N, 4)).reshape(43, max(N, 4))[:, :N], cols)
+        finally:
+            ctx.dev_free(d)
+    tr.pin(ctx)  # builds + page-locks the forms inside the host mirror
+    form, nbytes = tr.upload_form()
+    assert form == (32 if maker == "self_modifying" else 16), (form, nbytes)
+    if form == 16:
+        assert nbytes == 16 * ns + 16 * int(has.sum()) + 12 * len(ctab)
+    slots = host.Slots(0, 1)
+    try:
+        proof, _, _ = tr.prove_slots(slots, None, 0)
+        assert hashlib.sha3_256(proof.tobytes()).hexdigest() == hashlib.sha3_256(O.prove(P, prog, 0x1000, None, 1 << 20, inp)[0]).hexdigest()
+    finally:
+        slots.close()
+        del tr
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("nv,ncols", [(1, 86), (2, 86), (2, 688), (3, 344), (2, 43), (3, 1000)])
 def test_commit_job_many_tiny_columns(ctx, nv, ncols):
     """The eval of a commit job over MANY columns of 2, 4 or 8 rows (what a batched job of small traces is): values against the

@@ -2,12 +2,13 @@
 """Per kernel class of a rocprofv3 --kernel-trace CSV: launches, sum of durations, UNION of the launches' intervals (time with at
 least one launch of the class on the GPU), and -- for k_level_hash -- the `roofline.frac` that follows from them.
 
-    python tools/trace_union.py TRACE_kernel_trace.csv [--perms-per-proof 3735131 --instr 4428] [--json out.json] [--intervals out.csv.gz]
+    python tools/trace_union.py TRACE_kernel_trace.csv [--perms-per-proof 3735131 --instr 3976] [--json out.json] [--intervals out.csv.gz]
 
 This is the recipe profiles/README.md gives for re-deriving `roofline.frac` of a bench line from the profiler's own trace of
 the same command: a proof of the bench trace makes 13 k_level_hash launches (levels 0 .. v - 8 at v = 20) and
 hashes `--perms-per-proof` nodes with them (config.keccak_permutations_per_proof minus the 255 x 43 of k_merkle_top), so
-    permutations = launches / 13 * perms-per-proof,   achieved = permutations * instr / union,   frac = achieved / 78.64 T.
+    permutations = launches / 13 * perms-per-proof,   achieved = permutations * instr / union,   frac = achieved / 78.64 T
+(instr = 3976, the algorithmic count per permutation bench.py uses: the instructions of the cheapest kernel that performs one).
 The union cannot exceed the wall clock; the sum of durations of launches that share the chip does (round 3 divided by it).
 """
 import argparse
@@ -38,7 +39,7 @@ def main():
     ap.add_argument("csv")
     ap.add_argument("--perms-per-proof", type=float, default=0.0)
     ap.add_argument("--launches-per-proof", type=int, default=13)
-    ap.add_argument("--instr", type=float, default=4428.0)
+    ap.add_argument("--instr", type=float, default=3976.0, help="algorithmic VALU instructions per permutation (bench.py: IC_ALG)")
     ap.add_argument("--json")
     ap.add_argument("--intervals", help="write (class, start_ns, end_ns) of every classified launch, gzip CSV")
     ap.add_argument("--last", type=int, default=0, help="only the last N launches of every class -- with N = roofline.launches of the "

@@ -101,6 +101,9 @@ SIGNATURES = {
     "zigz_dev_witness_from_steps_async": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_witness_from_steps32": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
     "zigz_dev_witness_from_steps32_ws": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(vp), szp]),
+    "zigz_dev_witness_from_steps16": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, C.c_size_t, C.c_size_t, u64p, vp, C.c_size_t]),
+    "zigz_dev_witness_from_steps16_ws": (C.c_int32, [vp, vp, C.c_size_t, vp, C.c_size_t, C.c_uint64, vp, C.c_size_t, C.c_size_t, u64p,
+                                                     C.POINTER(vp), szp]),
     "zigz_dev_witness_from_steps_ws": (C.c_int32, [vp, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(vp), szp]),
     "zigz_dev_mem_info": (C.c_int32, [vp, szp, szp]),
     "zigz_ctx_set_epoch": (C.c_int32, [vp, vp]),

@@ -482,6 +482,59 @@ extern "C" zigz_status zigz_dev_witness_from_steps32_ws(zigz_ctx *ctx, const zig
     return ZIGZ_OK;
 }
 
+static_assert(sizeof(zigz_trace_step16) == sizeof(TraceStep16) && sizeof(zigz_code_entry) == sizeof(CodeEntry), "16-byte record mirrors differ");
+static zigz_status witness_from_steps16(zigz_ctx *ctx, const zigz_trace_step16 *h_steps, size_t num_steps, const zigz_mem_access *h_mem,
+                                        size_t num_mem, uint64_t code_base, const zigz_code_entry *h_code, size_t num_code, size_t nv,
+                                        const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride, bool wait) {
+    if (!ctx || !h_steps || !d_cols || nv > 40 || (num_mem && !h_mem) || num_mem >= ZIGZ_NO_MEM_ACCESS16 || (num_code && !h_code) ||
+        num_code > ((size_t)1 << 30))
+        return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (num_steps == 0) return ZIGZ_ERR_EMPTY_TRACE;
+    const size_t npad = (size_t)1 << nv;
+    if (num_steps > npad || (nv > 0 && num_steps <= npad / 2) || col_stride < npad) return ZIGZ_ERR_INVALID_ARGUMENT;
+    // staging: [48-byte records the expansion reads | the 16-byte records as uploaded | the side list | the code table]
+    auto al = [](size_t b) { return (b + 255) & ~(size_t)255; };
+    const size_t wide_b = al(num_steps * sizeof(zigz_trace_step)), raw_b = al(num_steps * 16), mem_b = al(num_mem * 16);
+    void *d_st, *d_ws;
+    CHK(ws_get(ctx, WS_IN64, wide_b + raw_b + mem_b + num_code * sizeof(zigz_code_entry) + 256, &d_st));
+    CHK(ws_get(ctx, WS_WITNESS, witness_steps_ws_words(npad) * 4, &d_ws));
+    uint8_t *q = (uint8_t *)d_st;
+    HIPCHK(ctx, hipMemcpyAsync(q + wide_b, h_steps, num_steps * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (num_mem) HIPCHK(ctx, hipMemcpyAsync(q + wide_b + raw_b, h_mem, num_mem * 16, hipMemcpyHostToDevice, ctx->stream));
+    if (num_code)
+        HIPCHK(ctx, hipMemcpyAsync(q + wide_b + raw_b + mem_b, h_code, num_code * sizeof(zigz_code_entry), hipMemcpyHostToDevice, ctx->stream));
+    launch_steps_widen16((const TraceStep16 *)(q + wide_b), num_steps, (const MemAccess *)(q + wide_b + raw_b), num_mem, code_base,
+                         (const CodeEntry *)(q + wide_b + raw_b + mem_b), num_code, (TraceStep *)q, ctx->stream);
+    Regs32 init;
+    for (int r = 0; r < 32; r++) init.v[r] = (r && initial_regs) ? (uint32_t)(initial_regs[r] % (uint64_t)P) : 0u;
+    launch_witness_steps((const TraceStep *)q, num_steps, npad, init, (uint32_t *)d_ws, d_cols, col_stride, ctx->stream);
+    HIPCHK(ctx, hipGetLastError());
+    if (wait) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    return ZIGZ_OK;
+}
+extern "C" zigz_status zigz_dev_witness_from_steps16(zigz_ctx *ctx, const zigz_trace_step16 *h_steps, size_t num_steps,
+                                                     const zigz_mem_access *h_mem, size_t num_mem, uint64_t code_base,
+                                                     const zigz_code_entry *h_code, size_t num_code, size_t nv,
+                                                     const uint64_t *initial_regs, uint32_t *d_cols, size_t col_stride) {
+    ZIGZ_ENTER(ctx);
+    return witness_from_steps16(ctx, h_steps, num_steps, h_mem, num_mem, code_base, h_code, num_code, nv, initial_regs, d_cols, col_stride, true);
+}
+extern "C" zigz_status zigz_dev_witness_from_steps16_ws(zigz_ctx *ctx, const zigz_trace_step16 *h_steps, size_t num_steps,
+                                                        const zigz_mem_access *h_mem, size_t num_mem, uint64_t code_base,
+                                                        const zigz_code_entry *h_code, size_t num_code, size_t nv,
+                                                        const uint64_t *initial_regs, const uint32_t **d_cols, size_t *col_stride) {
+    ZIGZ_ENTER(ctx);
+    if (!ctx || !d_cols || !col_stride || nv > 40) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (ctx->active_job) return ZIGZ_ERR_BAD_STATE;
+    const size_t N = (size_t)1 << nv, stride = N < 4 ? 4 : N;
+    void *d;
+    CHK(ws_get(ctx, WS_COLS, ZIGZ_NUM_COLUMNS * stride * 4, &d));
+    CHK(witness_from_steps16(ctx, h_steps, num_steps, h_mem, num_mem, code_base, h_code, num_code, nv, initial_regs, (uint32_t *)d, stride, false));
+    *d_cols = (const uint32_t *)d;
+    *col_stride = stride;
+    return ZIGZ_OK;
+}
+
 extern "C" zigz_status zigz_dev_witness_from_steps_ws(zigz_ctx *ctx, const zigz_trace_step *h_steps, size_t num_steps, size_t nv,
                                                       const uint64_t *initial_regs, const uint32_t **d_cols, size_t *col_stride) {
     ZIGZ_ENTER(ctx);

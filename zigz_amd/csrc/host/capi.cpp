@@ -55,6 +55,55 @@ struct zigzh_trace {
     std::vector<zigz_trace_step32> steps32;
     std::vector<zigz_mem_access> mem;
     bool registered32 = false, registered_mem = false;
+    // the 16-byte form (zigz_trace_step16 + the code table: the instruction fields once per pc) -- what a service uploads when
+    // the trace allows it; shares the side list `mem` with the 32-byte form
+    std::vector<zigz_trace_step16> steps16;
+    std::vector<zigz_code_entry> code;
+    uint64_t code_base = 0;
+    bool registered16 = false, registered_code = false, tried16 = false;
+    // false (and nothing kept) when the trace does not fit the form: a pc off the 4-byte grid or 2^32 past the lowest one, a code
+    // span out of proportion to the trace, a pc executed with two different decodings, too many accesses
+    bool compact16() {
+        if (tried16) return !steps16.empty();
+        tried16 = true;
+        compact32();
+        const size_t n = trace.stepCount();
+        if (n == 0 || mem.size() >= ZIGZ_NO_MEM_ACCESS16) return false;
+        uint64_t lo = ~0ull, hi = 0;
+        for (size_t i = 0; i < n; i++) {
+            const uint64_t pc = trace.steps[i].pc;
+            lo = pc < lo ? pc : lo;
+            hi = pc > hi ? pc : hi;
+        }
+        const uint64_t span = hi - lo;
+        if ((lo & 3) || span >= (1ull << 32) || span / 4 + 1 > 4 * n + 1024) return false;
+        std::vector<zigz_code_entry> tab(span / 4 + 1);
+        std::vector<uint8_t> seen(tab.size(), 0);
+        std::vector<zigz_trace_step16> out(n);
+        for (size_t i = 0; i < n; i++) {
+            const zigz_trace_step &a = trace.steps[i];
+            const uint64_t off = a.pc - lo;
+            if ((off & 3) || a.imm != (int64_t)(int32_t)a.imm || a.wr_reg >= 32 || a.mem_is_read > 1) return false;
+            zigz_code_entry e{};
+            e.imm = (int32_t)a.imm;
+            e.opcode = a.opcode; e.rd = a.rd; e.rs1 = a.rs1; e.rs2 = a.rs2; e.funct3 = a.funct3; e.funct7 = a.funct7;
+            zigz_code_entry &t = tab[off / 4];
+            if (!seen[off / 4]) {
+                t = e;
+                seen[off / 4] = 1;
+            } else if (memcmp(&t, &e, sizeof(e)) != 0) {
+                return false;  // the program rewrote this instruction
+            }
+            const uint32_t mi = steps32[i].mem_index == (uint32_t)ZIGZ_NO_MEM_ACCESS ? (uint32_t)ZIGZ_NO_MEM_ACCESS16 : steps32[i].mem_index;
+            out[i].pc_word = (uint32_t)off | (a.mem_is_read & 1u);
+            out[i].mem_wr = mi | ((uint32_t)a.wr_reg << 27);
+            out[i].rd_value = a.rd_value;
+        }
+        steps16.swap(out);
+        code.swap(tab);
+        code_base = lo;
+        return true;
+    }
     void compact32() {
         if (!steps32.empty() || trace.stepCount() == 0) return;
         const size_t n = trace.stepCount();
@@ -118,11 +167,30 @@ extern "C" int zigzh_execute(const uint8_t *program, size_t program_len, uint64_
 extern "C" void zigzh_trace_free(zigzh_trace *t) {
     if (!t) return;
     // (the context that registered the buffer may be gone by now: page-locking is process-wide, so no context is named)
+    if (t->registered16) (void)zigz_host_unregister(nullptr, t->steps16.data());
+    if (t->registered_code) (void)zigz_host_unregister(nullptr, t->code.data());
     if (t->registered32) (void)zigz_host_unregister(nullptr, t->steps32.data());
     if (t->registered_mem) (void)zigz_host_unregister(nullptr, t->mem.data());
     if (t->registered) (void)zigz_host_unregister(nullptr, t->trace.steps.data());
     else if (t->trace.steps.capacity() > g_step_pool.capacity()) g_step_pool.swap(t->trace.steps);
     delete t;
+}
+// which record a service uploads for this trace (after zigzh_trace_pin): 16, 32 or 48 bytes per step; *bytes = what crosses
+// PCIe per proof (records + side list + code table)
+extern "C" int zigzh_trace_upload_form(const zigzh_trace *t, size_t *bytes) {
+    if (!t) return 0;
+    const size_t n = t->trace.stepCount();
+    int form = 48;
+    size_t b = n * sizeof(zigz_trace_step);
+    if (!t->steps16.empty()) {
+        form = 16;
+        b = n * 16 + t->mem.size() * 16 + t->code.size() * sizeof(zigz_code_entry);
+    } else if (!t->steps32.empty()) {
+        form = 32;
+        b = n * 32 + t->mem.size() * 16;
+    }
+    if (bytes) *bytes = b;
+    return form;
 }
 extern "C" int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx) {
     return guard([&] {
@@ -135,6 +203,12 @@ extern "C" int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx) {
         if (!t->mem.empty()) {
             check(ctx, zigz_host_register(ctx, t->mem.data(), t->mem.size() * sizeof(zigz_mem_access)));
             t->registered_mem = true;
+        }
+        if (t->compact16()) {  // the 16-byte form + code table, when the trace fits it
+            check(ctx, zigz_host_register(ctx, t->steps16.data(), t->steps16.size() * sizeof(zigz_trace_step16)));
+            t->registered16 = true;
+            check(ctx, zigz_host_register(ctx, t->code.data(), t->code.size() * sizeof(zigz_code_entry)));
+            t->registered_code = true;
         }
     });
 }
@@ -232,13 +306,21 @@ extern "C" void zigzh_slots_release(zigzh_slots *s, zigz_ctx *ctx) {
     if (s && ctx) s->slots.release(ctx);
 }
 
-// the records a proof uploads inside its slot: the 32-byte form when the trace has it (pinned traces), else the 48-byte one
-// (ZIGZ_TRACE48=1 forces the 48-byte form: A/B)
+// the records a proof uploads inside its slot: the 16-byte form when the trace has it (pinned traces that fit it), else the
+// 32-byte one, else the 48-byte one (ZIGZ_TRACE32=1 / ZIGZ_TRACE48=1 force those forms: A/B)
 static TraceRecords records_of(const zigzh_trace *t) {
     TraceRecords r;
     r.regs_before = t->trace.initial_regs;
     static const bool force48 = getenv("ZIGZ_TRACE48") && getenv("ZIGZ_TRACE48")[0] == '1';
-    if (!t->steps32.empty() && !force48) {
+    static const bool force32 = getenv("ZIGZ_TRACE32") && getenv("ZIGZ_TRACE32")[0] == '1';
+    if (!t->steps16.empty() && !force48 && !force32) {
+        r.s16 = t->steps16.data();
+        r.code = t->code.data();
+        r.ncode = t->code.size();
+        r.code_base = t->code_base;
+        r.mem = t->mem.data();
+        r.nmem = t->mem.size();
+    } else if (!t->steps32.empty() && !force48) {
         r.s32 = t->steps32.data();
         r.mem = t->mem.data();
         r.nmem = t->mem.size();

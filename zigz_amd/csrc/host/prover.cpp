@@ -608,7 +608,10 @@ Proof Prover::proveWitnessImpl(const PublicIO &io, size_t num_lookups, const Wit
         if (steps) {  // the witness from the compact trace, inside the slot: upload + expansion + builds on one stream
             const uint32_t *wc = nullptr;
             size_t ws = 0;
-            if (records.s32)
+            if (records.s16)
+                check(ctx_, zigz_dev_witness_from_steps16_ws(ctx_, records.s16, num_steps, records.mem, records.nmem, records.code_base,
+                                                             records.code, records.ncode, num_vars, records.regs_before, &wc, &ws));
+            else if (records.s32)
                 check(ctx_, zigz_dev_witness_from_steps32_ws(ctx_, records.s32, num_steps, records.mem, records.nmem, num_vars,
                                                              records.regs_before, &wc, &ws));
             else

@@ -354,15 +354,19 @@ class GpuBatcher {
     std::map<std::array<uint64_t, 5>, std::shared_ptr<Group>> open_;
 };
 
-// the compact trace records of a proof whose witness is built inside its GPU slot: the 48-byte form, or the 32-byte form +
-// the side list of memory accesses (zigz_hip.h)
+// the compact trace records of a proof whose witness is built inside its GPU slot: the 48-byte form, the 32-byte form + the
+// side list of memory accesses, or the 16-byte form + side list + code table (zigz_hip.h)
 struct TraceRecords {
     const zigz_trace_step *s48 = nullptr;
     const zigz_trace_step32 *s32 = nullptr;
+    const zigz_trace_step16 *s16 = nullptr;  // the 16-byte form + the code table (instruction fields once per pc)
+    const zigz_code_entry *code = nullptr;
+    size_t ncode = 0;
+    uint64_t code_base = 0;
     const zigz_mem_access *mem = nullptr;
     size_t nmem = 0;
     const uint64_t *regs_before = nullptr;
-    explicit operator bool() const { return s48 || s32; }
+    explicit operator bool() const { return s48 || s32 || s16; }
 };
 
 class Prover {  // src/prover/prover.zig

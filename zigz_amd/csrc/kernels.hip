@@ -730,6 +730,42 @@ void launch_steps_widen(const TraceStep32 *d_in, size_t num_steps, const MemAcce
                        d_out);
 }
 
+// 16-byte records + side list + code table -> the same 48-byte records (64 B of HBM traffic per step + the table, which a loop keeps
+// in the caches)
+__global__ __launch_bounds__(TPB) void k_steps_widen16(const TraceStep16 *__restrict__ in, size_t n, const MemAccess *__restrict__ mem,
+                                                       size_t num_mem, uint64_t code_base, const uint32_t *__restrict__ code,
+                                                       size_t num_code, TraceStep *__restrict__ out) {
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i >= n) return;
+    const uint4 a = reinterpret_cast<const uint4 *>(in)[i];  // pc_word, mem_wr, rd_value
+    const uint64_t pc = code_base + (a.x & ~3u);
+    const uint32_t mi = a.y & 0x7ffffffu, wr = a.y >> 27, is_read = a.x & 1u, ci = a.x >> 2;
+    uint64_t addr = 0, value = 0;
+    if (mi < num_mem) {  // (ZIGZ_NO_MEM_ACCESS16 and any other index past the list: no access)
+        const ulonglong2 m = reinterpret_cast<const ulonglong2 *>(mem)[mi];
+        addr = m.x;
+        value = m.y;
+    }
+    uint32_t c0 = 0, c1 = 0, c2 = 0;  // imm | opcode rd rs1 rs2 | funct3 funct7 - -
+    if (ci < num_code) {
+        c0 = code[3 * (size_t)ci];
+        c1 = code[3 * (size_t)ci + 1];
+        c2 = code[3 * (size_t)ci + 2];
+    }
+    const long long imm = (long long)(int)c0;
+    uint4 *o = reinterpret_cast<uint4 *>(out) + 3 * i;
+    o[0] = make_uint4((uint32_t)pc, (uint32_t)(pc >> 32), a.z, a.w);  // pc, rd_value
+    o[1] = make_uint4((uint32_t)addr, (uint32_t)(addr >> 32), (uint32_t)value, (uint32_t)(value >> 32));
+    // imm, then the eight field bytes: opcode rd rs1 rs2 | funct3 funct7 wr_reg mem_is_read
+    o[2] = make_uint4((uint32_t)imm, (uint32_t)((unsigned long long)imm >> 32), c1, (c2 & 0xffffu) | (wr << 16) | (is_read << 24));
+}
+void launch_steps_widen16(const TraceStep16 *d_in, size_t num_steps, const MemAccess *d_mem, size_t num_mem, uint64_t code_base,
+                          const CodeEntry *d_code, size_t num_code, TraceStep *d_out, hipStream_t s) {
+    if (num_steps == 0) return;
+    hipLaunchKernelGGL(k_steps_widen16, dim3((unsigned)((num_steps + TPB - 1) / TPB)), dim3(TPB), 0, s, d_in, num_steps, d_mem, num_mem,
+                       code_base, (const uint32_t *)d_code, num_code, d_out);
+}
+
 void launch_witness_steps(const TraceStep *d_steps, size_t num_steps, size_t npad, const Regs32 &init, uint32_t *d_ws,
                           uint32_t *d_cols, size_t stride, hipStream_t s, const KTime *kt_expand) {
     if (num_steps == 0) return;

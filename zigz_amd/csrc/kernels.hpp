@@ -51,6 +51,18 @@ struct MemAccess {
 };
 void launch_steps_widen(const TraceStep32 *d_in, size_t num_steps, const MemAccess *d_mem, size_t num_mem, TraceStep *d_out,
                         hipStream_t s);
+// the 16-byte record and the code table (zigz_hip.h: zigz_trace_step16 / zigz_code_entry), widened on the device
+struct TraceStep16 {
+    uint32_t pc_word, mem_wr;
+    uint64_t rd_value;
+};
+struct CodeEntry {
+    int32_t imm;
+    uint8_t opcode, rd, rs1, rs2, funct3, funct7, reserved[2];
+};
+static_assert(sizeof(TraceStep16) == 16 && sizeof(CodeEntry) == 12, "16-byte record / code entry mirrors");
+void launch_steps_widen16(const TraceStep16 *d_in, size_t num_steps, const MemAccess *d_mem, size_t num_mem, uint64_t code_base,
+                          const CodeEntry *d_code, size_t num_code, TraceStep *d_out, hipStream_t s);
 struct Regs32 {
     uint32_t v[32];  // initial register values mod p (x0 = 0)
 };

@@ -44,6 +44,45 @@ def compact_steps32(steps, has_access):
     return out, mem
 
 
+# the 16-byte record and the code table (include/zigz_hip.h: zigz_trace_step16 / zigz_code_entry)
+TRACE_STEP16_DTYPE = np.dtype([("pc_word", "<u4"), ("mem_wr", "<u4"), ("rd_value", "<u8")])
+CODE_ENTRY_DTYPE = np.dtype([("imm", "<i4"), ("opcode", "u1"), ("rd", "u1"), ("rs1", "u1"), ("rs2", "u1"), ("funct3", "u1"), ("funct7", "u1"),
+                             ("reserved0", "u1"), ("reserved1", "u1")])
+assert TRACE_STEP16_DTYPE.itemsize == 16 and CODE_ENTRY_DTYPE.itemsize == 12
+NO_MEM_ACCESS16 = (1 << 27) - 1
+
+
+def compact_steps16(steps, has_access):
+    """48-byte records -> (16-byte records, side list, code_base, code table), or None when the trace does not fit the form (a pc off
+    the 4-byte grid or 2^32 past the lowest one, one pc with two different decodings, 2^27 - 1 or more accesses)."""
+    steps = np.ascontiguousarray(steps, dtype=TRACE_STEP_DTYPE)
+    s32, mem = compact_steps32(steps, has_access)
+    if len(steps) == 0 or len(mem) >= NO_MEM_ACCESS16:
+        return None
+    base = int(steps["pc"].min())
+    off = steps["pc"] - np.uint64(base)
+    if base & 3 or int(off.max()) >= 1 << 32 or np.any(off & np.uint64(3)) or np.any(steps["wr_reg"] >= 32) or np.any(steps["mem_is_read"] > 1):
+        return None
+    idx = (off >> np.uint64(2)).astype(np.int64)
+    code = np.zeros(int(idx.max()) + 1, dtype=CODE_ENTRY_DTYPE)
+    fields = ("imm", "opcode", "rd", "rs1", "rs2", "funct3", "funct7")
+    first = {}
+    for i in np.unique(idx, return_index=True)[1]:
+        first[int(idx[i])] = int(i)
+    for ci, i in first.items():
+        for f in fields:
+            code[f][ci] = s32[f][i]
+    for f in fields:  # every step must agree with the entry of its pc
+        if np.any(code[f][idx] != s32[f]):
+            return None
+    out = np.zeros(len(steps), dtype=TRACE_STEP16_DTYPE)
+    out["pc_word"] = off.astype(np.uint32) | (steps["mem_is_read"].astype(np.uint32) & 1)
+    mi = np.where(s32["mem_index"] == NO_MEM_ACCESS, np.uint32(NO_MEM_ACCESS16), s32["mem_index"]).astype(np.uint32)
+    out["mem_wr"] = mi | (steps["wr_reg"].astype(np.uint32) << 27)
+    out["rd_value"] = steps["rd_value"]
+    return out, mem, base, code
+
+
 def _name(code):
     return lib.zigz_status_name(code).decode()
 
@@ -153,6 +192,20 @@ class Context:
             ir = ira.ctypes.data_as(u64p)
         self.check(lib.zigz_dev_witness_from_steps32(self.h, vp(steps32.ctypes.data), steps32.shape[0], vp(mem.ctypes.data) if len(mem) else None,
                                                      len(mem), nv, ir, vp(d_cols), stride))
+
+    def witness_from_steps16(self, steps16, mem, code_base, code, nv, d_cols, stride, initial_regs=None):
+        """the same from the 16-byte records + side list + code table (zigz_dev_witness_from_steps16)"""
+        steps16 = np.ascontiguousarray(steps16, dtype=TRACE_STEP16_DTYPE)
+        mem = np.ascontiguousarray(mem, dtype=MEM_ACCESS_DTYPE)
+        code = np.ascontiguousarray(code, dtype=CODE_ENTRY_DTYPE)
+        ir = None
+        if initial_regs is not None:
+            ira = np.ascontiguousarray(initial_regs, dtype=np.uint64)
+            assert ira.size == 32
+            ir = ira.ctypes.data_as(u64p)
+        self.check(lib.zigz_dev_witness_from_steps16(self.h, vp(steps16.ctypes.data), steps16.shape[0], vp(mem.ctypes.data) if len(mem) else None,
+                                                     len(mem), int(code_base), vp(code.ctypes.data) if len(code) else None, len(code), nv, ir,
+                                                     vp(d_cols), stride))
 
     def download(self, d_ptr, n):
         o, op = _out_u64(n)

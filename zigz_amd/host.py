@@ -35,6 +35,7 @@ SIGNATURES = {
     "zigzh_trace_steps": (vp, [vp]),
     "zigzh_trace_initial_regs": (u64p, [vp]),
     "zigzh_trace_pin": (C.c_int, [vp, vp]),
+    "zigzh_trace_upload_form": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
     "zigzh_trace_witness": (C.c_int, [vp, u64p]),
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_trace_witness_dev_async": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -161,6 +162,11 @@ class Trace:
     def pin(self, ctx):
         """Page-lock the records: repeated witness_to_device uploads then run at PCIe rate."""
         _check(lib.zigzh_trace_pin(self.h, ctx.h))
+
+    def upload_form(self):
+        """(bytes per step of the record a service uploads for this trace: 16 / 32 / 48, bytes that cross PCIe per proof)"""
+        b = C.c_size_t()
+        return int(lib.zigzh_trace_upload_form(self.h, C.byref(b))), int(b.value)
 
     def witness(self):
         """WitnessGenerator.generate: [43, 2^nv] canonical uint64 (host)."""
