@@ -229,3 +229,54 @@ def test_stats_add_covers_every_field():
     host.lib.zigzh_stats_add(C.byref(a), C.byref(b))
     for i, (f, _) in enumerate(KernelStats._fields_):
         assert getattr(a, f) == 101 + 2 * i, f
+
+
+@pytest.mark.parametrize("maker,arg", [("mixed_loop", 300), ("fibonacci", 40), ("add_xor_loop", 500), ("register_round_robin", 20)])
+def test_compact_records_widen_back_to_the_trace(maker, arg):
+    """The 32-byte and the 16-byte record (include/zigz_hip.h) are lossless restatements of the VM's 48-byte steps: compacted
+    by the numpy helpers and widened again by the rule the device kernels follow (k_steps_widen / k_steps_widen16: side list by
+    index, code table by (pc - base) / 4, wr_reg and the access index out of one word), they give every field of every step
+    back.  What the 16-byte form refuses is checked too: a pc off the 4-byte grid, one pc with two decodings."""
+    import programs
+    from zigz_amd.hip import TRACE_STEP_DTYPE, compact_steps16, compact_steps32, NO_MEM_ACCESS, NO_MEM_ACCESS16
+    made = getattr(programs, maker)(arg)
+    prog, inp = made if isinstance(made, tuple) else (made, None)
+    tr = host.Trace(prog, 0x1000, None, 1 << 20, inp)
+    st, _ = tr.steps()
+    has = np.isin(st["opcode"], (0x03, 0x23))
+    fields = ("opcode", "rd", "rs1", "rs2", "funct3", "funct7")
+    s32, mem = compact_steps32(st, has)
+    back = np.zeros(len(st), dtype=TRACE_STEP_DTYPE)
+    for f in ("pc", "rd_value", "wr_reg", "mem_is_read") + fields:
+        back[f] = s32[f]
+    back["imm"] = s32["imm"].astype(np.int64)
+    ok = s32["mem_index"] != NO_MEM_ACCESS
+    back["mem_addr"][ok] = mem["addr"][s32["mem_index"][ok]]
+    back["mem_value"][ok] = mem["value"][s32["mem_index"][ok]]
+    assert back.tobytes() == np.ascontiguousarray(st, dtype=TRACE_STEP_DTYPE).tobytes()
+    s16, mem16, base, code = compact_steps16(st, has)
+    assert s16.nbytes == 16 * len(st) and len(code) <= len(prog) // 4
+    back = np.zeros(len(st), dtype=TRACE_STEP_DTYPE)
+    ci = (s16["pc_word"] >> 2).astype(np.int64)
+    back["pc"] = np.uint64(base) + (s16["pc_word"] & ~np.uint32(3)).astype(np.uint64)
+    back["mem_is_read"] = s16["pc_word"] & 1
+    back["wr_reg"] = s16["mem_wr"] >> 27
+    back["rd_value"] = s16["rd_value"]
+    for f in fields:
+        back[f] = code[f][ci]
+    back["imm"] = code["imm"][ci].astype(np.int64)
+    mi = s16["mem_wr"] & np.uint32(NO_MEM_ACCESS16)
+    ok = mi != NO_MEM_ACCESS16
+    back["mem_addr"][ok] = mem16["addr"][mi[ok]]
+    back["mem_value"][ok] = mem16["value"][mi[ok]]
+    assert back.tobytes() == np.ascontiguousarray(st, dtype=TRACE_STEP_DTYPE).tobytes()
+    bad = st.copy()
+    bad["pc"][len(bad) // 2] += 2
+    assert compact_steps16(bad, has) is None
+    if len(st) > 8:
+        bad = st.copy()
+        k = int(np.flatnonzero(st["pc"] == st["pc"][len(st) // 2])[0])
+        bad["rd"][k] ^= 1  # (the same pc executed later with another decoding -- or this is its only execution: then pick another)
+        again = np.flatnonzero(st["pc"] == st["pc"][k])
+        if len(again) > 1:
+            assert compact_steps16(bad, has) is None

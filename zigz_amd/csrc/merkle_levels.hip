@@ -572,13 +572,16 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
 #define ZK_LEVEL_HASH_MIN_WAVES 1  // (A/B: waves per SIMD the compiler must leave room for)
 #endif
 template <bool LEAF, bool PAUSE>
-__global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense) {
+__global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(MerkleBuild b, unsigned L, ColMap gdense, int prio) {
     __shared__ unsigned long long s_r[RUN_SUBS + 1], s_g[RUN_SUBS + 1];  // exclusive prefixes of the sub-list lengths
 #ifdef ZK_LEVEL_HASH_LDS_PAD  // (A/B: unused LDS per workgroup caps the workgroups per CU)
     __shared__ unsigned s_pad[ZK_LEVEL_HASH_LDS_PAD / 4];
     if (b.npad == 3) s_pad[threadIdx.x] = L;  // (never true: keeps the array)
 #endif
-    if (!PAUSE) ZK_PRIO_SMALL();  // (the small levels: links of a dependent chain)
+    // A level that cannot fill the chip is a link in its proof's chain of dependent launches: its waves go first on the SIMDs they
+    // share with other proofs' big levels (tools/prio_probe.hip: a lone hashing wave among six others takes 80-250 us for a
+    // permutation at priority 0, 10-15 us -- what it takes alone -- at priority 3)
+    if (prio) ZK_PRIO_SMALL();
     const unsigned lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const bool dropped = b.gcols.n != 0 && b.g_ctr[8] != 0;
     if (wave < 2) {
@@ -719,9 +722,22 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
     const unsigned nz = b.t.nz ? b.t.nz : 1;
     if (nz > 1 && wgs > (2048 + nz - 1) / nz) wgs = (2048 + nz - 1) / nz;
     const bool pause = !small || (size_t)nz * (b.rcols.n + b.gcols.n) * n_L > (size_t)256 * 4 * 2 * 64;
-    if (L == 0) ZK_LAUNCH(kt, (k_level_hash<true, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
-    else if (!pause) ZK_LAUNCH(kt, (k_level_hash<false, false>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
-    else ZK_LAUNCH(kt, (k_level_hash<false, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), 0, s, b, L, gd);
+    // priority for the launches that cannot fill the chip (the room of their lists is under half of the 1536 workgroups it holds)
+#ifndef ZK_LH_PRIO_WGS
+#define ZK_LH_PRIO_WGS 768
+#endif
+    const int prio = (size_t)wgs * nz <= ZK_LH_PRIO_WGS ? 1 : 0;
+    // Unused dynamic LDS on the launches that fill the chip caps their workgroups at five per CU (160 KB / CU; six fit by
+    // registers) and leaves registers and a wave slot per SIMD for the short launches of other proofs, which otherwise wait for
+    // a workgroup of a big level to retire before they can start at all (A/B, GPU-bound ms per proof, two rounds: no cap 0.504 /
+    // 0.503, five 0.498 / 0.494, four 0.519 / 0.524; the small levels take 37-45 us in company instead of 42-56)
+#ifndef ZK_LH_BIG_LDS
+#define ZK_LH_BIG_LDS 28672
+#endif
+    const unsigned lds = prio ? 0u : (unsigned)ZK_LH_BIG_LDS;
+    if (L == 0) ZK_LAUNCH(kt, (k_level_hash<true, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), lds, s, b, L, gd, prio);
+    else if (!pause) ZK_LAUNCH(kt, (k_level_hash<false, false>), dim3((unsigned)wgs, 1, nz), dim3(TPB), lds, s, b, L, gd, prio);
+    else ZK_LAUNCH(kt, (k_level_hash<false, true>), dim3((unsigned)wgs, 1, nz), dim3(TPB), lds, s, b, L, gd, prio);
 }
 
 // ------------------------------------------------------------------ the top of the trees
