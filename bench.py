@@ -1009,7 +1009,8 @@ def main():
                 if use_slots:
                     slots.close()
                     slots = make_slots(slot_count(B, nv), nv)
-            return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps}
+            form, nbytes = lanes[0].trace.upload_form()  # the record the host mirror chose for these traces, bytes over PCIe per proof
+            return {"dt": dtp, "steps": args.steps, "trace_steps": local_steps, "upload_form": form, "upload_bytes": nbytes}
         legs["pcie"] = guard("pcie_inclusive", leg_pcie)
         guard("drop_upload_contexts", lambda: [l.drop_upload_context() for l in lanes])
         guard("release", lambda: [c.release_workspaces() for c in all_contexts()])  # (the slots' column buffers and staging)
@@ -1413,11 +1414,7 @@ def main():
                 detail["single_proof"]["vm_ms"] = solo["vm_ms"]
         if legs.get("pcie"):  # trace upload + witness kernels inside the loop
             cfg["pcie_inclusive_value"] = rate(legs["pcie"])
-            try:  # what crossed PCIe per proof in that leg: the record the host mirror chose for lane 0's trace
-                form, nbytes = lanes[0].trace.upload_form()
-                detail["pcie_upload"] = {"bytes_per_step_record": form, "bytes_per_proof": nbytes}
-            except Exception:  # noqa: BLE001
-                pass
+            detail["pcie_upload"] = {"bytes_per_step_record": legs["pcie"].get("upload_form"), "bytes_per_proof": legs["pcie"].get("upload_bytes")}
         if legs.get("gpu_all"):  # the commit path alone: what the GPU needs per proof (ms), and the same without its hashing
             def gpu_ms(leg):
                 return leg["dt"] / (leg["steps"] * leg.get("lanes", B)) * 1e3

@@ -181,7 +181,11 @@ def main():
                       ("p4_event_semantics.txt", "event_semantics.txt"), ("p4_event_semantics_profiled.txt", "event_semantics_profiled.txt"),
                       ("p4_bench_s0.json", "final_bench_own_thread_transcripts.json"), ("p4_gpu_bound.txt", "gpu_bound_rate.txt"),
                       ("p4_lasso.json", "lasso.json"), ("p4_sumcheck.json", "sumcheck.json"), ("p4_extra.json", "extra.json"),
-                      ("p4_configs.jsonl", "configs.jsonl")):
+                      ("p4_configs.jsonl", "configs.jsonl"), ("p4_bdef_concurrency.json", "bdef_concurrency.json"),
+                      ("p4_stream_concurrency.txt", "stream_concurrency.txt"), ("p4_prio_probe.txt", "prio_probe.txt"),
+                      ("p4_icache_corun.txt", "icache_corun.txt"), ("p4_bench_upload16.json", "bench_upload_16_byte_records.json"),
+                      ("p4_bench_upload32.json", "bench_upload_32_byte_records.json"),
+                      ("p4_bench_batch4.json", "bench_2p20_jobs_of_up_to_4.json")):
         if os.path.exists(os.path.join("gpurun_out", src_)):
             shutil.copy(os.path.join("gpurun_out", src_), "profiles/%s_%s" % (ROUND, dst))
     if os.path.exists("profiles/%s_bdef_union.json" % ROUND) and os.path.exists("profiles/%s_bdef_bench.json" % ROUND):

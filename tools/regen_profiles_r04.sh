@@ -33,6 +33,7 @@ T=$(ls gpurun_out/p4_bdef/*/*kernel_trace.csv | head -1)
 PPP=$(python3 -c "import json; d=json.load(open('gpurun_out/p4_bdef.json')); print(d['config']['keccak_permutations_per_proof'] - 255*43)")
 LAST=$(python3 -c "import json; print(json.load(open('gpurun_out/p4_bdef.json'))['roofline']['launches'])")
 python3 tools/trace_union.py $T --perms-per-proof $PPP --json gpurun_out/p4_bdef_union_whole_run.json --intervals gpurun_out/p4_bdef_intervals.csv.gz > /dev/null
+python3 tools/trace_concurrency.py $T --json gpurun_out/p4_bdef_concurrency.json > /dev/null  # how many launches at once, and which
 python3 tools/trace_union.py gpurun_out/p4_bdef_intervals.csv.gz --perms-per-proof $PPP --last $LAST --json gpurun_out/p4_bdef_union.json > /dev/null
 rm -f $T gpurun_out/p4_b1/*/*kernel_trace.csv gpurun_out/p4_kernels/*/*kernel_trace.csv
 echo "[3/4] profiled bench runs done"
@@ -41,6 +42,10 @@ rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p4_lasso -- p
 rocprofv3 --kernel-trace --stats --output-format csv -d gpurun_out/p4_sumcheck -- python3 tools/measure_extra.py --sumcheck-only > gpurun_out/p4_sumcheck.json 2> gpurun_out/p4_sumcheck.err
 rm -f gpurun_out/p4_lasso/*/*kernel_trace.csv gpurun_out/p4_sumcheck/*/*kernel_trace.csv
 ./tools/bin/event_semantics > gpurun_out/p4_event_semantics.txt 2>&1 || true
+# how the chip schedules launches: chains side by side (4), a hashing wave's priority on full SIMDs, co-running Keccak variants
+(timeout -k 10 120 ./tools/bin/stream_concurrency; for q in 2 8 16; do GPU_MAX_HW_QUEUES=$q timeout -k 10 120 ./tools/bin/stream_concurrency; done) > gpurun_out/p4_stream_concurrency.txt 2>&1 || true
+timeout -k 10 120 ./tools/bin/prio_probe > gpurun_out/p4_prio_probe.txt 2>&1 || true
+(timeout -k 10 120 ./tools/bin/icache_corun; timeout -k 10 120 ./tools/bin/icache_corun 4000 2) > gpurun_out/p4_icache_corun.txt 2>&1 || true
 rocprofv3 --kernel-trace --output-format csv -d gpurun_out/p4_evsem -o t -- $GRAFT_REPO_ROOT/tools/bin/event_semantics > gpurun_out/p4_event_semantics_profiled.txt 2>/dev/null || true
 echo "[4/4] lasso / sumcheck / event semantics done"
 python3 -c "import json; print(json.dumps(json.load(open('gpurun_out/p4_bdef_union.json'))['classes']['level_hash']))"
@@ -52,6 +57,12 @@ python3 bench.py --batch 1 --sponge-servers 0 --no-cpu-baseline --no-extras > gp
 python3 bench.py --sponge-servers 0 --no-cpu-baseline --no-extras > gpurun_out/p4_bench_s0.json 2>> gpurun_out/p4_bench.err
 echo "[5/7] bench lines done"
 for t in add_xor mixed round_robin straight; do python3 tools/gpu_bound_rate.py --lanes 14 --trace $t --phases; done > gpurun_out/p4_gpu_bound.txt 2>> gpurun_out/p4_bench.err
+for cfg in "8 2" "8 3" "8 4" "4 8"; do set -- $cfg; python3 tools/gpu_bound_rate.py --lanes $1 --batch $2 --iters 20; done >> gpurun_out/p4_gpu_bound.txt 2>> gpurun_out/p4_bench.err
+# the PCIe-inclusive path with the 16-byte and the 32-byte record
+python3 bench.py --upload --slots 16 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/p4_bench_upload16.json 2>> gpurun_out/p4_bench.err
+ZIGZ_TRACE32=1 python3 bench.py --upload --slots 16 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/p4_bench_upload32.json 2>> gpurun_out/p4_bench.err
+# small proofs of 2^20 traces in shared commit jobs (arena form, groups of up to 4 that form while their driver waits for a slot)
+ZIGZ_BENCH_BATCH_NV=20 ZIGZ_BENCH_BATCH_LINGER_US=0 ZIGZ_BENCH_BATCH_MAX=4 python3 bench.py --slots 8 --steps 20 --warmup 3 --no-cpu-baseline --no-extras > gpurun_out/p4_bench_batch4.json 2>> gpurun_out/p4_bench.err
 python3 tools/measure_extra.py > gpurun_out/p4_extra.json 2>> gpurun_out/p4_bench.err
 # (6) BASELINE configs 2-5 at full size on one GPU
 rm -f gpurun_out/p4_configs.jsonl
