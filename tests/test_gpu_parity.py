@@ -1489,6 +1489,59 @@ def test_witness_from_32_byte_records_vs_oracle(ctx, maker, arg):
 
 
 @pytest.mark.gpu
+def test_group_probe_left_out_after_kept_builds_then_a_trace_that_does_not_repeat(ctx):
+    """A context whose last builds all kept their content-addressed group leaves the probe pass out (two launches that find out
+    what is known).  The trace that does not repeat after all must still come out right: the full insert drops the group, the
+    build is repeated with slabs for its columns -- roots and openings equal a fresh context's (which probes), and the looping
+    traces before and after it equal theirs too."""
+    import programs
+    import zigz_amd
+    nv = 16
+    steps = 1 << nv
+    loop_a, loop_b = programs.add_xor_loop((steps - 3) // 4), programs.mixed_loop((steps - 8) // 12 - 3)
+    straight = programs.straight_line_program(11, int(0.9 * steps))
+    small = (1 << 1) | (0x3f << 33) | (1 << 42)
+    masks = {"small_domain_mask": small, "run_aware_mask": (0x7fffffff << 2) | (3 << 40),
+             "cons_group_mask": 1 | (1 << 1) | (0x7f << 33) | (1 << 42)}
+    fresh = zigz_amd.Context(0)
+    saved = {k: ctx.get_option(k) for k in masks}
+    bufs = []
+    try:
+        for c in (ctx, fresh):
+            for k, v in masks.items():
+                c.set_option(k, v)
+        pts = np.random.default_rng(5).integers(0, 2013265921, size=(43, nv), dtype=np.uint64)
+
+        def run(c, d, stride):
+            job = zigz_amd.CommitJob(c, d_cols=d, ncols=43, nv=nv, col_stride=stride)
+            r = job.roots()
+            o = job.open_all(pts)
+            job.end()
+            return r, o
+        seq = [loop_a, loop_a, loop_b, loop_a, straight, loop_a, straight, loop_b]
+        for i, prog in enumerate(seq):
+            d, stride = _trace_cols(ctx, prog, nv)
+            bufs.append(d)
+            got = run(ctx, d, stride)
+            f2 = zigz_amd.Context(0)  # no history at all: probes
+            try:
+                for k, v in masks.items():
+                    f2.set_option(k, v)
+                want = run(f2, d, stride)
+            finally:
+                f2.close()
+            assert np.array_equal(got[0], want[0]), (i, "roots")
+            for key in ("values", "indices", "leaves", "siblings", "dirs"):
+                assert np.array_equal(got[1][key], want[1][key]), (i, key)
+    finally:
+        for k, v in saved.items():
+            ctx.set_option(k, v)
+        for d in bufs:
+            ctx.dev_free(d)
+        fresh.close()
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("ns", [1, 2, 3, 64, 65, 1000, 4097, 70000])
 def test_witness_from_16_byte_records_synthetic(ctx, ns):
     """The 16-byte step record (zigz_trace_step16: pc as an offset into a CODE TABLE that carries the seven instruction fields

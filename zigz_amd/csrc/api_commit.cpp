@@ -15,7 +15,7 @@ static void caps_for(zigz_ctx *ctx, size_t npad, unsigned rn, unsigned gn) {
     c.rn = rn;
     c.gn = gn;
     c.g_slabs = false;
-    c.g_drops = c.g_skip = 0;
+    c.g_drops = c.g_skip = c.g_kept = 0;
     const LevelLists rw = runs_lists(npad, rn ? rn : 1), gw = cons_lists(npad);
     for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) {
         c.r[l] = l <= rw.top ? (rw.cap[l] / 8 > 256 ? rw.cap[l] / 8 : 256) : 0;  // an eighth of "every node hashed"
@@ -243,6 +243,8 @@ zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride
             ctx->cons_gen += top + 1;
             b.g_ctr = g_ctr;
             b.g_has_slabs = whole || ctx->caps.g_slabs;
+            static const bool always_probe = getenv("ZIGZ_CONS_PROBE_ALWAYS") != nullptr;  // (A/B)
+            b.g_no_probe = ref && ctx->caps.npad == npad && ctx->caps.g_kept >= 2 && !ctx->cons_always && !always_probe;
             t.g_ncols = G.n;
             t.g_dropped = g_ctr + 8;
             for (unsigned k = 0; k < G.n; k++) t.g_j_of_col[G.c[k]] = (signed char)k;
@@ -848,6 +850,7 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
             if (dropped) c.g_slabs = true;  // this context's traces do not repeat: give the group's columns slabs from now on
             if (job->cons_hinted) {
                 c.g_drops = dropped ? c.g_drops + 1 : 0;
+                c.g_kept = dropped ? 0 : c.g_kept + 1;
                 // ... and after the second drop in a row, skip the attempt for 15 jobs -- twice as many after every further attempt
                 // that is dropped again (a context shared by a service's lanes sees hundreds of jobs of one kind of trace)
                 if (c.g_drops >= 2) c.g_skip = 15u << (c.g_drops - 2 < 6 ? c.g_drops - 2 : 6);

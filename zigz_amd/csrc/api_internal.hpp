@@ -33,6 +33,7 @@ struct ListCaps {
     unsigned r[RUN_MAX_LEVELS], g[RUN_MAX_LEVELS];  // entries per sub-list and level
     bool g_slabs;  // this context's traces made the group be dropped: give its columns slabs up front
     unsigned g_drops, g_skip;  // consecutive builds that dropped the group; builds left that do not even try it
+    unsigned g_kept;           // consecutive builds that kept it (from the second on the probe pass is left out)
 };
 struct zigz_ctx {
     int device;

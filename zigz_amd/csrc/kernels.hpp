@@ -295,6 +295,7 @@ struct MerkleBuild {   // everything the structure-aware launches share (device 
     ColMap gcols;                 // the group, ascending
     ColMap gcols_sd;              // its small-domain members (levels 0-1 from the tables when the group is dropped)
     int g_has_slabs;              // the group's columns have slabs to be built into when the group is dropped
+    int g_no_probe;               // the context's last builds all kept the group: no probe pass before the full insert
     ZPtr<unsigned long long> g_keys;  // 2 npad slots: generation << 52 | payload
     ZPtr<uint32_t> g_idx;         // 2 npad: the list slot of the node that inserted the slot's key
     ZPtr<uint32_t> g_rep;         // 2 npad: list slot of the representative of every node of the levels 0..top

@@ -544,7 +544,10 @@ void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt)
     const unsigned nz = b.t.nz ? b.t.nz : 1;
     const dim3 g0((unsigned)((b.npad + CONS_TPB - 1) / CONS_TPB), 1, nz);
     // the probe first (trees of >= 2^16 leaves: below that the whole insert costs less than a launch), then the full pass
-    const bool probe = b.npad >= ((size_t)1 << 16);
+    // -- unless the context's recent builds all kept their group (a service's slots see one kind of trace after the other): the
+    // probe is then two launches that find out what is known; a trace that does not repeat after all is dropped by the full pass,
+    // the expensive way, once
+    const bool probe = b.npad >= ((size_t)1 << 16) && !b.g_no_probe;
     if (probe) {
         if (kt) hipExtLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, kt->start, nullptr, 0, b, 1);
         else hipLaunchKernelGGL(k_cons_leaf_insert, g0, dim3(CONS_TPB), 0, s, b, 1);
