@@ -16,6 +16,9 @@ static void caps_for(zigz_ctx *ctx, size_t npad, unsigned rn, unsigned gn) {
     c.gn = gn;
     c.g_slabs = false;
     c.g_drops = c.g_skip = c.g_kept = 0;
+    memset(c.r_last, 0, sizeof(c.r_last));
+    memset(c.g_last, 0, sizeof(c.g_last));
+    c.last_dropped = false;
     const LevelLists rw = runs_lists(npad, rn ? rn : 1), gw = cons_lists(npad);
     for (unsigned l = 0; l < RUN_MAX_LEVELS; l++) {
         c.r[l] = l <= rw.top ? (rw.cap[l] / 8 > 256 ? rw.cap[l] / 8 : 256) : 0;  // an eighth of "every node hashed"
@@ -275,7 +278,13 @@ zigz_status build_trees(zigz_ctx *ctx, const uint32_t *d_vals, size_t val_stride
     unsigned first_top = 0;  // the level the top kernel starts from
     if (lists) {
         for (unsigned l = 0; l <= top; l++) {
-            if (ctx->debug_skip != 1) launch_level_hash(b, l, ctx->stream, stamp(5, 0));
+            size_t expect = 0;  // what the last build of this shape held here, + 25 % + the sub-lists' slack (sizing only)
+            if (ref && ctx->caps.npad == npad && (ctx->caps.r_last[l] || ctx->caps.g_last[l])) {
+                auto more = [](unsigned v) { return (size_t)RUN_SUBS * (v + v / 4 + 8); };
+                expect = (R.n ? more(ctx->caps.r_last[l]) : 0) + (G.n ? more(ctx->caps.g_last[l]) * G.n : 0) +
+                         (G.n && ctx->caps.last_dropped ? (size_t)G.n * (npad >> l) : 0);
+            }
+            if (ctx->debug_skip != 1) launch_level_hash(b, l, ctx->stream, stamp(5, 0), expect);
             if (l == top) break;
             ColMap m{};  // the densely built columns that already have level l: D, and H from level 1
             for (size_t c = 0; c < ncols; c++) {
@@ -842,11 +851,14 @@ extern "C" zigz_status zigz_commit_roots(zigz_commit_job *job, uint8_t *roots) {
         } else if (job->tree.lists && c.npad == job->N) {
             for (unsigned l = 0; l <= job->tree.top; l++) {
                 const unsigned long long ru = h_cnt[8 + l], gu = h_cnt[8 + RUN_MAX_LEVELS + l];
+                c.r_last[l] = job->run_cols ? (unsigned)(ru ? ru : 1) : 0;
+                c.g_last[l] = job->cons_hinted && !dropped ? (unsigned)(gu ? gu : 1) : 0;
                 if (job->run_cols && (r_over ? ru > c.r[l] : ru * 10 > (unsigned long long)c.r[l] * 8))
                     c.r[l] = (unsigned)(ru + ru / 4 + 64);
                 if (job->cons_hinted && !dropped && (g_over ? gu > c.g[l] : gu * 10 > (unsigned long long)c.g[l] * 8))
                     c.g[l] = (unsigned)(gu + gu / 4 + 64);
             }
+            c.last_dropped = dropped;
             if (dropped) c.g_slabs = true;  // this context's traces do not repeat: give the group's columns slabs from now on
             if (job->cons_hinted) {
                 c.g_drops = dropped ? c.g_drops + 1 : 0;

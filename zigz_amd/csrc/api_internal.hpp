@@ -34,6 +34,8 @@ struct ListCaps {
     bool g_slabs;  // this context's traces made the group be dropped: give its columns slabs up front
     unsigned g_drops, g_skip;  // consecutive builds that dropped the group; builds left that do not even try it
     unsigned g_kept;           // consecutive builds that kept it (from the second on the probe pass is left out)
+    unsigned r_last[RUN_MAX_LEVELS], g_last[RUN_MAX_LEVELS];  // the longest sub-list of the LAST build per level (0: none yet): launch sizing only
+    bool last_dropped;  // ... and whether it dropped its group (whose columns are then hashed densely by the level launches)
 };
 struct zigz_ctx {
     int device;

@@ -317,7 +317,7 @@ void launch_runs_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt 
 // G: the table passes of the levels 0..top and the keep / drop decision (top + 3 launches, no hashing)
 void launch_cons_structure(const MerkleBuild &b, hipStream_t s, const KTime *kt = nullptr);
 // level L (<= top) of the R and G columns: hashes the two lists (and, when the group was dropped, its columns densely)
-void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt = nullptr);
+void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt = nullptr, size_t expect = 0);  // expect: entries the level is expected to hold (sizing only; 0: the lists' room)
 // writes the copies / non-representatives of the levels 0..top (whole-tree comparisons, single trees that outlive the call)
 void launch_fill_virtual(const MerkleBuild &b, hipStream_t s);
 // from level `first_level` (at most 512 nodes per column, found through t) to the root, one workgroup per column; the levels

@@ -694,7 +694,7 @@ __global__ __launch_bounds__(TPB, ZK_LEVEL_HASH_MIN_WAVES) void k_level_hash(Mer
     }
 }
 
-void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt) {
+void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KTime *kt, size_t expect) {
     if (b.rcols.n == 0 && b.gcols.n == 0) return;
     // when the group was dropped its columns are hashed densely here -- except the small-domain members on the levels 0 and 1,
     // which come from the tables (launch_keccak_small_l01, guarded by the same flag)
@@ -714,6 +714,9 @@ void launch_level_hash(const MerkleBuild &b, unsigned L, hipStream_t s, const KT
         // strides over whatever there is: a group dropped on the device, whose columns are hashed densely here, takes more
         // steps per thread, not more threads.)
         size_t room = (b.rcols.n ? (size_t)RUN_SUBS * b.t.r_lists.cap[L] : 0) + (b.gcols.n ? (size_t)RUN_SUBS * b.t.g_lists.cap[L] * b.gcols.n : 0);
+        // `expect`: what the context's LAST build of this shape held on this level (+ 25 %) -- the room only ever grows, and a
+        // context that has met one trace with long lists would size and schedule every later one as if it were that
+        if (expect && expect < room) room = expect;
         size_t w2 = (room + TPB - 1) / TPB;
         if (w2 < 8) w2 = 8;
         if (w2 < wgs) wgs = w2;
