@@ -197,18 +197,25 @@ extern "C" int zigzh_trace_pin(zigzh_trace *t, zigz_ctx *ctx) {
         if (t->registered || t->trace.stepCount() == 0) return;
         check(ctx, zigz_host_register(ctx, t->trace.steps.data(), t->trace.stepCount() * sizeof(zigz_trace_step)));
         t->registered = ctx;
-        t->compact32();  // the 32-byte form a service uploads (zigzh_prove_trace_slots without resident columns)
-        check(ctx, zigz_host_register(ctx, t->steps32.data(), t->steps32.size() * sizeof(zigz_trace_step32)));
-        t->registered32 = true;
-        if (!t->mem.empty()) {
-            check(ctx, zigz_host_register(ctx, t->mem.data(), t->mem.size() * sizeof(zigz_mem_access)));
-            t->registered_mem = true;
-        }
-        if (t->compact16()) {  // the 16-byte form + code table, when the trace fits it
+        // the form a service uploads (zigzh_prove_trace_slots without resident columns): 16-byte records + code table when the trace
+        // fits them -- the 32-byte records are then given back, a 2^24 trace is 0.5 GiB of them --, else the 32-byte records
+        // (ZIGZ_TRACE32=1 / ZIGZ_TRACE48=1 at this point: keep the 32-byte form for an A/B)
+        const bool keep32 = getenv("ZIGZ_TRACE32") || getenv("ZIGZ_TRACE48");
+        const bool fits16 = !keep32 && t->compact16();
+        if (fits16) {
+            std::vector<zigz_trace_step32>().swap(t->steps32);
             check(ctx, zigz_host_register(ctx, t->steps16.data(), t->steps16.size() * sizeof(zigz_trace_step16)));
             t->registered16 = true;
             check(ctx, zigz_host_register(ctx, t->code.data(), t->code.size() * sizeof(zigz_code_entry)));
             t->registered_code = true;
+        } else {
+            t->compact32();
+            check(ctx, zigz_host_register(ctx, t->steps32.data(), t->steps32.size() * sizeof(zigz_trace_step32)));
+            t->registered32 = true;
+        }
+        if (!t->mem.empty()) {
+            check(ctx, zigz_host_register(ctx, t->mem.data(), t->mem.size() * sizeof(zigz_mem_access)));
+            t->registered_mem = true;
         }
     });
 }
