@@ -100,7 +100,18 @@ bool sleep_wait(const unsigned long long *flag, unsigned long long seq) {
     }
     return false;
 }
-DoneFlag done_flag(zigz_ctx *ctx, int which) {  // which: 0 = the roots of a commit job, 1 = its openings
+// the short waits of a sumcheck's data passes (tens of microseconds): look at the word without sleeping for ~0.3 ms, then give up
+// (the caller asks the runtime)
+bool spin_wait(const unsigned long long *flag, unsigned long long seq) {
+    for (int i = 0; i < 400000; i++) {
+        if (__atomic_load_n(flag, __ATOMIC_ACQUIRE) == seq) return true;
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    return false;
+}
+DoneFlag done_flag(zigz_ctx *ctx, int which) {  // which: 0 = the roots of a commit job, 1 = its openings, 2 = a sumcheck's pass
     DoneFlag d;
     d.count = ctx->d_flag + 4;
     d.flag = (unsigned long long *)(ctx->h_roots + ROOTS_MAX_COLS * 32 + JOB_SUMMARY_WORDS * 8) + which;

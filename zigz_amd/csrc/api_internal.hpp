@@ -152,6 +152,7 @@ inline size_t ceil_pow2(size_t n) { size_t v = 1; while (v < n) v <<= 1; return 
 void set_err(zigz_ctx *ctx, const char *fmt, ...);
 zigz_status ws_get(zigz_ctx *ctx, int slot, size_t bytes, void **out);
 bool sleep_wait(const unsigned long long *flag, unsigned long long seq);
+bool spin_wait(const unsigned long long *flag, unsigned long long seq);
 DoneFlag done_flag(zigz_ctx *ctx, int which);
 zigz_status log_launch(zigz_ctx *ctx, int cls, uint64_t perms, hipEvent_t start, hipEvent_t stop, hipEvent_t first, double *dur_us);
 zigz_status upload_u64(zigz_ctx *ctx, const uint64_t *h_in, size_t n, uint32_t *d_out, bool reduce);

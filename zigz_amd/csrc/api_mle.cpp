@@ -518,6 +518,8 @@ struct GpuRadix {
     void *wbuf;
     unsigned stage;
     zigz_rccl_comm *rccl;  // != nullptr: block sums are all-reduced over the ranks in HBM, on the context's stream
+    bool tail_pending = false;  // the last fold's finalize publishes the remaining table itself: read_tail only waits for it
+    DoneFlag tail_done{};
 };
 // The sums a data pass has just produced in d_sums[0, n) -> `out`.  Sharded over RCCL they are first all-reduced in place, on
 // the context's stream -- together with word n, the number of ranks whose local pass failed (st != OK: this rank adds 1) -- so
@@ -525,11 +527,36 @@ struct GpuRadix {
 // the failing rank returns its own error, the others ZIGZ_ERR_COMM, and radix_run then skips the remaining passes on all of
 // them alike (their collectives stay matched).  The wait behind the collective has the communicator's deadline: a peer that
 // never enters it costs an abort and ZIGZ_ERR_COMM here, not a hang (RCCL has no timeout of its own).
+// n words at d_src (u64, or u32 widened) -> out through pinned memory, written there by a kernel the host polls for: a copy
+// command and a stream wait cost 15-25 us a time, a sumcheck of 2^24 entries is 30 us of data passes and three such hand-overs.
+// rezero: the words are left zero (the sums of a later pass accumulate into them).  Many waiting threads (blocking sync): the
+// sleeping wait, as in the commit path.
+static zigz_status published(zigz_ctx *ctx, const DoneFlag &done, size_t n, bool u32, uint64_t *out);
+static zigz_status publish_out(zigz_ctx *ctx, void *d_src, size_t n, bool u32, bool rezero, uint64_t *out) {
+    if (n > PIN_WORDS / 4) return ZIGZ_ERR_INVALID_ARGUMENT;
+    const DoneFlag done = done_flag(ctx, 2);
+    if (u32) launch_publish_u32((const uint32_t *)d_src, n, (uint32_t *)ctx->h_pin, ctx->stream, done);
+    else launch_publish_u64((unsigned long long *)d_src, n, (unsigned long long *)ctx->h_pin, rezero, ctx->stream, done);
+    HIPCHK(ctx, hipGetLastError());
+    return published(ctx, done, n, u32, out);
+}
+// waits for what a kernel has been asked to publish into ctx->h_pin under `done`, and hands it out
+static zigz_status published(zigz_ctx *ctx, const DoneFlag &done, size_t n, bool u32, uint64_t *out) {
+    const bool seen = !ctx->timing && (g_sleep_wait.load() ? sleep_wait(done.flag, done.seq) : spin_wait(done.flag, done.seq));
+    if (!seen) HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
+    if (u32) {
+        const uint32_t *h = (const uint32_t *)ctx->h_pin;
+        for (size_t i = 0; i < n; i++) out[i] = h[i];
+    } else {
+        memcpy(out, ctx->h_pin, n * 8);
+    }
+    return ZIGZ_OK;
+}
 zigz_status sums_out(GpuRadix *g, unsigned long long *d_sums, size_t n, zigz_status st, uint64_t *out) {
     zigz_ctx *ctx = g->ctx;
     if (!g->rccl) {
         CHK(st);
-        return read_u64(ctx, d_sums, n, out);
+        return publish_out(ctx, d_sums, n, false, true, out);
     }
     if (st != ZIGZ_OK) (void)hipMemsetAsync(d_sums + n, 1, 1, ctx->stream);  // (the word was zeroed with the sums: now 1)
     const int rc = zigz_rccl_allreduce_u64_dev(g->rccl, (uint64_t *)d_sums, n + 1, ctx->stream);
@@ -558,7 +585,9 @@ zigz_status gpu_block_sums(void *user, unsigned k, uint64_t *sums) {
     zigz_ctx *ctx = g->ctx;
     const size_t nb = (size_t)1 << k;
     auto local = [&]() -> zigz_status {
-        HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, (nb + 1) * 8, ctx->stream));
+        // (alone, both regions of d_sums were zeroed once when the sumcheck began and every read-back leaves what it read zero;
+        // over RCCL the sums and the failure word behind them are filled before every pass, as the all-reduce wants them)
+        if (g->rccl) HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, (nb + 1) * 8, ctx->stream));
         launch_block_sums(g->cur, g->len, g->len, log2_floor(g->len >> k), 1, ctx->d_sums, SumsLayout{0, 1, 0, 1}, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
         return ZIGZ_OK;
@@ -573,6 +602,8 @@ zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k
     // the next stage's block sums alternate between two regions of d_sums ((1 << RADIX_MAX_K) + 1 words each: sums + the
     // failure word of sums_out), so a stage's memset never touches words a read-back of the stage before may still copy
     unsigned long long *d_B2 = ctx->d_sums + ((g->stage + 1) & 1 ? 2048 : 0);
+    DoneFlag fin_done{};
+    bool fin_published = false;
     auto local = [&]() -> zigz_status {
         uint32_t *wst = (uint32_t *)(ctx->h_pin + PIN_WORDS / 2);
         for (size_t b = 0; b < nb; b++) wst[b] = host_to_mont(weights[b]);
@@ -580,18 +611,37 @@ zigz_status gpu_fold(void *user, unsigned k, const uint64_t *weights, unsigned k
         const size_t groups = radix_fold_groups(nb);
         launch_radix_fold(g->cur, 0, m, nb, (const uint32_t *)g->wbuf, 0, g->d_part, 0, 1, ctx->stream);
         HIPCHK(ctx, hipGetLastError());
-        if (k_next) {
-            HIPCHK(ctx, hipMemsetAsync(d_B2, 0, (((size_t)1 << k_next) + 1) * 8, ctx->stream));
-            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream);
-        } else {
-            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream);
+        // alone, the finalize kernel's last workgroup hands the result to the host itself (the next stage's sums, or -- last
+        // fold -- the remaining table): no read-back launch behind it
+        FinalizePublish pub;
+        if (!g->rccl && m <= PIN_WORDS / 4) {
+            fin_done = done_flag(ctx, 2);
+            pub.kind = k_next ? 1 : 2;
+            pub.n = (unsigned)(k_next ? (size_t)1 << k_next : m);
+            pub.h_dst = ctx->h_pin;
+            pub.count = fin_done.count;
+            pub.flag = fin_done.flag;
+            pub.seq = fin_done.seq;
         }
+        if (k_next) {
+            if (g->rccl) HIPCHK(ctx, hipMemsetAsync(d_B2, 0, (((size_t)1 << k_next) + 1) * 8, ctx->stream));
+            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, log2_floor(m) - k_next, d_B2, 1, ctx->stream, nullptr, &pub);
+        } else {
+            launch_radix_finalize(g->d_part, 0, groups, d_out, 0, m, 0, nullptr, 1, ctx->stream, nullptr, &pub);
+        }
+        fin_published = pub.kind != 0;
         HIPCHK(ctx, hipGetLastError());
         return ZIGZ_OK;
     };
     const zigz_status st = local();
-    if (k_next) CHK(sums_out(g, d_B2, (size_t)1 << k_next, st, next_sums));
-    else CHK(st);
+    if (k_next) {
+        if (fin_published && st == ZIGZ_OK) CHK(published(ctx, fin_done, (size_t)1 << k_next, false, next_sums));
+        else CHK(sums_out(g, d_B2, (size_t)1 << k_next, st, next_sums));
+    } else {
+        CHK(st);
+        g->tail_pending = fin_published;
+        g->tail_done = fin_done;
+    }
     g->cur = d_out;
     g->len = m;
     g->stage++;
@@ -601,6 +651,11 @@ zigz_status gpu_read_tail(void *user, size_t m, uint64_t *out) {
     GpuRadix *g = (GpuRadix *)user;
     zigz_ctx *ctx = g->ctx;
     if (m > PIN_WORDS) return ZIGZ_ERR_INVALID_ARGUMENT;
+    if (g->tail_pending) {  // (the last fold's finalize kernel is publishing exactly these m words)
+        g->tail_pending = false;
+        return published(ctx, g->tail_done, m, true, out);
+    }
+    if (!g->rccl) return publish_out(ctx, (void *)g->cur, m, true, false, out);
     uint32_t *h32 = (uint32_t *)ctx->h_pin;
     HIPCHK(ctx, hipMemcpyAsync(h32, g->cur, m * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(ctx, hipStreamSynchronize(ctx->stream));
@@ -624,6 +679,8 @@ static zigz_status sumcheck_radix_sharded(zigz_ctx *ctx, const uint32_t *d_in, s
         g.d_outs = (uint32_t *)(g.d_part + g0 * g.m0);
         CHK(ws_get(ctx, WS_MISC, ((size_t)1 << RADIX_MAX_K) * 4 + 64, &g.wbuf));
     }
+    // both regions of the stage sums zero before the first pass (one fill per sumcheck; every read-back re-zeroes what it read)
+    if (!rccl && n > HOST_TAIL_MAX) HIPCHK(ctx, hipMemsetAsync(ctx->d_sums, 0, (2048 + ((size_t)1 << RADIX_MAX_K) + 1) * 8, ctx->stream));
     const RadixOps ops{&g, gpu_block_sums, gpu_fold, gpu_read_tail};
     return radix_run(ctx, ops, n, comm, fixed, rounds, point, final_eval);
 }

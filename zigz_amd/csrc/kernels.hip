@@ -372,8 +372,9 @@ void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t 
 __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long *__restrict__ part, size_t part_col_stride,
                                                         size_t groups, uint32_t *__restrict__ out, size_t out_stride,
                                                         size_t m, unsigned log2_m2, unsigned long long *__restrict__ sums,
-                                                        EvalSkip skip) {
+                                                        EvalSkip skip, FinalizePublish pub) {
     ZK_PRIO_SMALL();
+    __shared__ int s_last;
     const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
     const size_t col = blockIdx.z;
     if (eval_skips(skip, col)) return;  // (its partial sums were never written)
@@ -389,14 +390,37 @@ __global__ __launch_bounds__(TPB) void k_radix_finalize(const unsigned long long
         unsigned long long t = wave_sum((unsigned long long)v);
         if ((threadIdx.x & 63) == 0 && i < m && t) atomicAdd(&sums[i >> log2_m2], t);
     }
+    if (pub.kind) {  // the last workgroup to get here publishes (a sumcheck's read-back without a launch of its own)
+        __threadfence();
+        __syncthreads();
+        if (threadIdx.x == 0) s_last = atomicAdd(pub.count, 1u) == gridDim.x - 1;
+        __syncthreads();
+        if (s_last) {
+            __threadfence();
+            if (pub.kind == 1) {
+                for (unsigned j = threadIdx.x; j < pub.n; j += TPB) {
+                    reinterpret_cast<unsigned long long *>(pub.h_dst)[j] = __hip_atomic_load(&sums[j], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    sums[j] = 0;
+                }
+            } else {
+                for (unsigned j = threadIdx.x; j < pub.n; j += TPB) reinterpret_cast<uint32_t *>(pub.h_dst)[j] = out[j];
+            }
+            __threadfence_system();
+            __syncthreads();
+            if (threadIdx.x == 0) {
+                *pub.count = 0;
+                __hip_atomic_store(pub.flag, pub.seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
+        }
+    }
 }
 
 void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
                            size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
-                           hipStream_t s, const EvalSkip *skip) {
+                           hipStream_t s, const EvalSkip *skip, const FinalizePublish *pub) {
     dim3 grid((unsigned)((m + TPB - 1) / TPB), 1, (unsigned)ncols);
     hipLaunchKernelGGL(k_radix_finalize, grid, dim3(TPB), 0, s, d_part, part_col_stride, groups, d_out, out_stride, m, log2_m2,
-                       d_sums, skip ? *skip : EvalSkip());
+                       d_sums, skip ? *skip : EvalSkip(), pub && ncols == 1 ? *pub : FinalizePublish());
 }
 
 // eq weights by doubling in LDS, one workgroup per column (all values Montgomery form: mont_mul keeps the form)
@@ -1134,6 +1158,33 @@ __global__ void k_job_summary(TreeRef t, unsigned height, uint8_t *__restrict__ 
     }
     signal_done(done, gridDim.x * gridDim.z);
 }
+// n words of device memory -> pinned host memory, by the device (no copy command, no stream wait: the host polls `done`);
+// rezero: the words are zero again afterwards -- the sums of the next pass accumulate into them without a fill command.
+// W = 8: u64 words; W = 4: u32 words (widened by the host)
+template <int W>
+__global__ __launch_bounds__(TPB) void k_publish(void *d_src, size_t n, void *h_dst, int rezero, DoneFlag done) {
+    ZK_PRIO_SMALL();
+    const size_t i = (size_t)blockIdx.x * TPB + threadIdx.x;
+    if (i < n) {
+        if (W == 8) {
+            unsigned long long *s = reinterpret_cast<unsigned long long *>(d_src);
+            reinterpret_cast<unsigned long long *>(h_dst)[i] = s[i];
+            if (rezero) s[i] = 0;
+        } else {
+            uint32_t *s = reinterpret_cast<uint32_t *>(d_src);
+            reinterpret_cast<uint32_t *>(h_dst)[i] = s[i];
+            if (rezero) s[i] = 0;
+        }
+    }
+    signal_done(done, gridDim.x);
+}
+void launch_publish_u64(unsigned long long *d_src, size_t n, unsigned long long *h_dst, bool rezero, hipStream_t s, DoneFlag done) {
+    hipLaunchKernelGGL(k_publish<8>, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, (void *)d_src, n, (void *)h_dst, rezero ? 1 : 0, done);
+}
+void launch_publish_u32(const uint32_t *d_src, size_t n, uint32_t *h_dst, hipStream_t s, DoneFlag done) {
+    hipLaunchKernelGGL(k_publish<4>, dim3((unsigned)((n + TPB - 1) / TPB)), dim3(TPB), 0, s, (void *)d_src, n, (void *)h_dst, 0, done);
+}
+
 __global__ __launch_bounds__(TPB) void k_zero_counters(unsigned long long *sd, unsigned long long *r, unsigned long long *g, size_t zstride) {
     ZK_PRIO_SMALL();
     const unsigned i = blockIdx.x * TPB + threadIdx.x;

@@ -128,9 +128,20 @@ void launch_radix_fold(const uint32_t *d_in, size_t in_stride, size_t m, size_t 
                        hipEvent_t t_start = nullptr, hipEvent_t t_stop = nullptr, const EvalSkip *skip = nullptr, int rloops = 0);
 //  (3) out[c][i] = (sum_g part[c][g][i]) mod p; if d_sums (ncols == 1): sums[i >> log2_m2] += out[i]  (block sums of
 //      the next stage, m2 >= 256; must be zeroed by the caller)
+//      publish (single-column use): the LAST workgroup to finish hands the result to the host itself -- kind 1: the n next-stage
+//      sums (u64; left zero afterwards), kind 2: the first n outputs (u32) -- into pinned memory and signals `done` there
+struct DoneFlag;
+struct FinalizePublish {
+    int kind = 0;
+    unsigned n = 0;
+    void *h_dst = nullptr;
+    unsigned *count = nullptr;           // (DoneFlag's three words: the struct is declared further down)
+    unsigned long long *flag = nullptr;
+    unsigned long long seq = 0;
+};
 void launch_radix_finalize(const unsigned long long *d_part, size_t part_col_stride, size_t groups, uint32_t *d_out,
                            size_t out_stride, size_t m, unsigned log2_m2, unsigned long long *d_sums, size_t ncols,
-                           hipStream_t s, const EvalSkip *skip = nullptr);
+                           hipStream_t s, const EvalSkip *skip = nullptr, const FinalizePublish *pub = nullptr);
 // eq weights of k variables, Montgomery form: W[c][b] = prod_j (bit_j(b) ? r_cj : 1 - r_cj) with bit 0 of the
 // loop being the MOST significant bit of b; d_r_m[c*r_stride + j] = r_cj in Montgomery form.  k <= 14.
 void launch_eq_weights(const uint32_t *d_r_m, size_t r_stride, unsigned k, uint32_t *d_w_m, size_t w_stride, size_t ncols,
@@ -358,6 +369,10 @@ struct DoneFlag {
     unsigned long long *flag = nullptr;
     unsigned long long seq = 0;
 };
+// n words of device memory into pinned host memory by a kernel that then signals `done` (the host polls it: no copy command, no
+// stream wait); rezero: leaves the source zero for the sums of the next pass
+void launch_publish_u64(unsigned long long *d_src, size_t n, unsigned long long *h_dst, bool rezero, hipStream_t s, DoneFlag done);
+void launch_publish_u32(const uint32_t *d_src, size_t n, uint32_t *h_dst, hipStream_t s, DoneFlag done);
 void launch_paths(const TreeRef &t, size_t n_values, unsigned height, const uint32_t *d_vals, size_t val_stride,
                   const uint64_t *d_idx, uint8_t *d_sib, uint8_t *d_dirs, uint32_t *d_leaf, size_t ncols, hipStream_t s,
                   DoneFlag done = DoneFlag());
