@@ -951,6 +951,10 @@ def main():
                         return once_on(c, l)
                 return once_on(l.ctx, l)
 
+            def loop_in_library(l):  # (no interpreter in the loop: ~70 us per job per worker behind one lock would be in the figure)
+                slots.commit_path_repeat(l.d_cols, N, nv, pts, (want["small_domain_mask"], want["run_aware_mask"], want["cons_group_mask"]), iters)
+                return []
+
             def once_on(c, l):
                 job = zigz_amd.CommitJob(c, d_cols=l.d_cols, ncols=43, nv=nv, col_stride=N)
                 job.roots()
@@ -974,7 +978,7 @@ def main():
                 gather([pool.submit(once, l) for l in gl])
                 sync_all()
                 t0 = time.perf_counter()
-                res = gather([pool.submit(loop, l) for l in gl])
+                res = gather([pool.submit(loop_in_library if (use_slots and not timing) else loop, l) for l in gl])
                 dtg = time.perf_counter() - t0
                 for r in res:
                     for st in r:

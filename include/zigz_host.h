@@ -77,6 +77,10 @@ int zigzh_prove_trace(const zigzh_trace *t, zigz_ctx *ctx, const uint32_t *d_col
  * _release: a slot for work of the caller's own (uploads, allocations). */
 typedef struct zigzh_slots zigzh_slots;
 int zigzh_slots_create(int device, size_t k, zigzh_slots **out);
+/* measurement: the commit path alone -- slot, begin on 43 resident columns, roots, open_all at `points` (43 x nv), end -- `reps`
+ * times back to back inside the library; masks = {small_domain_mask, run_aware_mask, cons_group_mask} for the jobs */
+int zigzh_commit_path_repeat(zigzh_slots *s, const uint32_t *d_cols, size_t stride, size_t nv, const uint64_t *points,
+                             const int64_t masks[3], size_t reps);
 /* small traces (2^nv rows, nv <= max_nv <= 18): proofs that reach their GPU phase within linger_us of each other share ONE
  * commit job of up to max_batch (<= 32) proofs (zigz_commit_begin_batch; zigz_host.hpp: GpuBatcher) -- each proof keeps its
  * own transcript and gets exactly the roots and openings a job of its own would give.  max_batch <= 1: off (the default).

@@ -426,6 +426,38 @@ extern "C" int zigzh_prove_trace_slots_repeat(const zigzh_trace *t, zigzh_slots 
     });
 }
 
+// The commit path alone, `reps` times back to back inside the library (measurement: what the GPU needs per proof when no host
+// transcript stands in front of it -- bench.py's gpu_bound legs; a worker in the interpreter would add its own ~70 us per job and
+// serialise with the other workers behind the interpreter lock): take a slot, begin on the 43 resident columns, roots, open_all
+// at `points` (43 x nv canonical), end, give the slot back.  masks: small_domain / run_aware / cons_group options for the jobs.
+extern "C" int zigzh_commit_path_repeat(zigzh_slots *s, const uint32_t *d_cols, size_t stride, size_t nv, const uint64_t *points,
+                                        const int64_t masks[3], size_t reps) {
+    return guard([&] {
+        if (!s || !d_cols || !points || !masks || reps == 0) throw Error(ZIGZ_ERR_INVALID_ARGUMENT, "null argument");
+        const size_t nc = ZIGZ_NUM_COLUMNS;
+        std::vector<uint8_t> roots(nc * 32), sib(nc * nv * 32 + 1), dirs(nc * nv + 1);
+        std::vector<uint64_t> values(nc), indices(nc), leaves(nc);
+        static const char *const names[3] = {"small_domain_mask", "run_aware_mask", "cons_group_mask"};
+        for (size_t r = 0; r < reps; r++) {
+            GpuSlots::Lease lease;
+            lease.slots = &s->slots;
+            zigz_ctx *c = lease.ctx = s->slots.acquire();
+            int64_t saved[3];
+            for (int i = 0; i < 3; i++) {
+                (void)zigz_ctx_get_option(c, names[i], &saved[i]);
+                check(c, zigz_ctx_set_option(c, names[i], masks[i]));
+            }
+            zigz_commit_job *job = nullptr;
+            zigz_status st = zigz_commit_begin_dev(c, d_cols, nc, stride, nv, &job);
+            if (st == ZIGZ_OK) st = zigz_commit_roots(job, roots.data());
+            if (st == ZIGZ_OK) st = zigz_commit_open_all(job, points, values.data(), indices.data(), leaves.data(), sib.data(), dirs.data());
+            if (job) zigz_commit_end(job);
+            for (int i = 0; i < 3; i++) (void)zigz_ctx_set_option(c, names[i], saved[i]);
+            check(c, st);
+        }
+    });
+}
+
 extern "C" int zigzh_prove(zigz_ctx *ctx, const uint8_t *program, size_t program_len, uint64_t entry_pc,
                            const uint64_t *initial_regs, size_t n_initial_regs, int has_initial_regs, size_t max_steps,
                            const uint64_t *input, size_t n_input, uint8_t **proof_out, size_t *proof_len, size_t *num_steps) {

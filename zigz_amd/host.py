@@ -36,6 +36,7 @@ SIGNATURES = {
     "zigzh_trace_initial_regs": (u64p, [vp]),
     "zigzh_trace_pin": (C.c_int, [vp, vp]),
     "zigzh_trace_upload_form": (C.c_int, [vp, C.POINTER(C.c_size_t)]),
+    "zigzh_commit_path_repeat": (C.c_int, [vp, vp, C.c_size_t, C.c_size_t, u64p, C.POINTER(C.c_int64), C.c_size_t]),
     "zigzh_trace_witness": (C.c_int, [vp, u64p]),
     "zigzh_trace_witness_dev": (C.c_int, [vp, vp, vp, C.c_size_t]),
     "zigzh_trace_witness_dev_async": (C.c_int, [vp, vp, vp, C.c_size_t]),
@@ -271,6 +272,14 @@ class Slots:
             def __exit__(self_l, *a):
                 lib.zigzh_slots_release(slots.h, self_l.raw)
         return _Lease()
+
+    def commit_path_repeat(self, d_cols, stride, nv, points, masks, reps):
+        """zigzh_commit_path_repeat: the commit path alone (slot, begin on the 43 resident columns, roots, open_all, end), `reps`
+        times back to back inside the library -- measurement of the GPU side without the interpreter in the loop."""
+        pts = np.ascontiguousarray(points, dtype=np.uint64)
+        assert pts.shape == (43, nv)
+        m = (C.c_int64 * 3)(*[int(x) for x in masks])
+        _check(lib.zigzh_commit_path_repeat(self.h, vp(d_cols), stride, nv, pts.ctypes.data_as(u64p), m, reps))
 
     def close(self):
         if getattr(self, "h", None):
