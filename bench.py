@@ -298,8 +298,9 @@ def lasso_leg(ctx, reps=5):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=20)  # (1.1 s of timed region: the lanes start in lock step, and the first cycles of a
+    # region are its slowest -- 10 steps read 3-4 % under 20, 20 within 1 % of 40)
+    ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=0, help="independent traces proven concurrently per GPU per step (0 = pick: 8.8 per "
                     "sponge server, bounded by free HBM; without the service this rank's share of the host CPUs minus 2, at most "
                     "14).  One proof alone is bound by its sequential host transcript (~27 ms on one core) against ~0.55 ms of GPU "
